@@ -1,0 +1,127 @@
+"""Pin the oracle (oracle/tspws_oracle.c) against the golden vectors produced by
+the reference itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+import abi
+
+TOL = 1e-11  # oracle and reference are both FP64; only summation grouping / FMA contraction differ
+
+
+def frame_names(g):
+    return sorted({k.split("/")[0] for k in g["frames"].files})
+
+
+def test_frame_tables(golden):
+    g = golden["frames"]
+    for name in frame_names(golden):
+        f = abi.OracleFrame(int(g[f"{name}/type"]), int(g[f"{name}/J"]), int(g[f"{name}/V"]), int(g[f"{name}/N"]),
+                            float(g[f"{name}/s0"]), float(g[f"{name}/b0"]), float(g[f"{name}/w0"]))
+        assert f.S == int(g[f"{name}/S"]), name
+        np.testing.assert_array_equal(f.L, g[f"{name}/L"], name)
+        np.testing.assert_array_equal(f.c, g[f"{name}/c"], name)
+        np.testing.assert_array_equal(f.cd, g[f"{name}/cd"], name)
+        np.testing.assert_array_equal(f.D, g[f"{name}/D"], name)
+        np.testing.assert_array_equal(f.scale, g[f"{name}/scale"], name)  # same repeated product -> bit equal
+        assert f.Cpsi == float(g[f"{name}/Cpsi"]), name
+        w, wd = f.taps()
+        off = np.concatenate([[0], np.cumsum(f.L)]).astype(np.int64)
+        e = g[f"{name}/w_head"].shape[1]
+        for s in range(f.S):
+            ws = w[off[s]:off[s + 1]]
+            np.testing.assert_allclose(ws[:e], g[f"{name}/w_head"][s], rtol=1e-14, atol=1e-300, err_msg=name)
+            np.testing.assert_allclose(ws[-e:], g[f"{name}/w_tail"][s], rtol=1e-14, atol=1e-300, err_msg=name)
+            np.testing.assert_allclose(wd[off[s]:off[s] + e], g[f"{name}/wd_head"][s], rtol=1e-14, atol=1e-300, err_msg=name)
+            assert abs(ws.sum() - g[f"{name}/w_sum"][s]) <= 1e-12 * max(1.0, np.abs(ws).sum()), name
+
+
+def test_known_answers_from_survey():
+    """SURVEY.md 8(c) [measured on the reference]."""
+    f = abi.OracleFrame(N=131072, J=14)
+    assert f.Cpsi == pytest.approx(0.29982027317664373, rel=1e-15)
+    w, _ = f.taps()
+    assert w[10] == pytest.approx(0.53112596601359841 + 0j, rel=1e-14)
+    assert f.ncoef == 524256 and f.ntaps == 1383505
+    assert abi.OracleFrame(N=2048, J=5, w0=2 * np.pi).Cpsi == pytest.approx(0.25329497516446658, rel=1e-15)
+    assert abi.OracleFrame(type=-3, N=2048, J=5, V=2, s0=1.0, b0=0.5, w0=2 ** 0.5).Cpsi == pytest.approx(2.3632718012073544, rel=1e-15)
+
+
+def test_parameter_resolution(golden):
+    g = golden["mains"]
+    names = sorted({k.split("/")[0] for k in g.files if "/in/" in k})
+    assert len(names) >= 25
+    for name in names:
+        p = abi.t_tsPWS()
+        for k in [k for k in g.files if k.startswith(f"{name}/in/")]:
+            setattr(p, k.split("/")[-1], g[k].item())
+        x = g["X"] if str(g[f"{name}/input"]) == "X" else g["Xodd"] if str(g[f"{name}/input"]) == "Xodd" else g[f"{name}/x"]
+        q = abi.resolve(p, x.shape[1], float(g[f"{name}/dt"]))
+        for k in ("J", "V", "s0", "b0", "w0", "fmin"):
+            assert getattr(q, k) == g[f"{name}/out/{k}"].item(), (name, k)
+
+
+def test_forward_inverse(golden):
+    g = golden["cwt"]
+    for name in sorted({k.split("/")[0] for k in g.files}):
+        x = g[f"{name}/x"]
+        f = abi.OracleFrame(int(g[f"{name}/type"]), int(g[f"{name}/J"]), int(g[f"{name}/V"]), len(x),
+                            float(g[f"{name}/s0"]), float(g[f"{name}/b0"]), float(g[f"{name}/w0"]))
+        Y = f.forward(x)
+        assert Y.shape == g[f"{name}/Y"].shape
+        assert abi.relerr(Y, g[f"{name}/Y"]) < TOL, name
+        assert abi.relerr(f.inverse(g[f"{name}/Y"]), g[f"{name}/xrec"]) < TOL, name
+
+
+def _case_input(g, name):
+    tag = str(g[f"{name}/input"])
+    return g["X"] if tag == "X" else g["Xodd"] if tag == "Xodd" else g[f"{name}/x"]
+
+
+def _case_params(g, name):
+    p = abi.t_tsPWS()
+    for k in [k for k in g.files if k.startswith(f"{name}/in/")]:
+        setattr(p, k.split("/")[-1], g[k].item())
+    return p
+
+
+def main_case_names(g):
+    return sorted({k.split("/")[0] for k in g.files if "/in/" in k})
+
+
+def check_main(fn, g, name, tol):
+    p = _case_params(g, name)
+    kw = dict(dt=float(g[f"{name}/dt"]), beg=float(g[f"{name}/beg"]))
+    if f"{name}/times" in g.files:
+        kw["times"] = g[f"{name}/times"]
+    r = abi.run_main(fn, p, _case_input(g, name), **kw)
+    assert r["rc"] == 0, name
+    assert abi.relerr(r["ls"], g[f"{name}/ls"]) < tol, name
+    assert abi.relerr(r["tsPWS"], g[f"{name}/tsPWS"]) < tol, name
+    for k in ("J", "V", "s0", "b0", "w0", "fold"):
+        assert getattr(r["params"], k) == g[f"{name}/out/{k}"].item(), (name, k)
+    if f"{name}/sigall_after" in g.files:  # in-place mutation contract (fold / rm)
+        assert abi.relerr(r["sigall"], g[f"{name}/sigall_after"]) < 1e-6, name
+    if f"{name}/jk_ls" in g.files:
+        np.testing.assert_array_equal(r["jk_mtr"], g[f"{name}/jk_mtr"])
+        for c in range(len(r["jk_mtr"])):
+            assert abi.relerr(r["jk_ls"][c], g[f"{name}/jk_ls"][c]) < tol, (name, c)
+            assert abi.relerr(r["jk_ts"][c], g[f"{name}/jk_ts"][c]) < tol, (name, c)
+    return r
+
+
+def test_whole_calls(golden):
+    g = golden["mains"]
+    fn = abi.oracle().orc_tspws_main
+    for name in main_case_names(g):
+        check_main(fn, g, name, 2e-7)  # outputs are float32: one ulp of the peak
+
+
+def test_example_data(golden):
+    g = golden["example32"]
+    fn = abi.oracle().orc_tspws_main
+    for name in ("ex1", "ex2", "ex3", "ex_mexhat"):
+        p = _case_params(g, name)
+        r = abi.run_main(fn, p, g["traces"], dt=float(g["dt"]), beg=float(g["beg"]))
+        assert abi.relerr(r["ls"], g[f"{name}/ls"]) < 2e-7, name
+        assert abi.relerr(r["tsPWS"], g[f"{name}/tsPWS"]) < 2e-7, name
+        assert r["params"].fold == g[f"{name}/out/fold"].item()
