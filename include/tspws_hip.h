@@ -1,0 +1,154 @@
+/*
+ * tspws_hip.h -- the thin C-ABI HIP layer under tspws_main().
+ *
+ * Plain C types only (pointers, sizes, scalars); every `d_` pointer is a HIP
+ * device pointer on the plan's device, `stream` is a hipStream_t passed as
+ * void* (NULL = the default stream).  All functions return 0 on success or a
+ * TSPWS_E_* code; tspws_hip_last_error() gives the text.  Nothing here exists
+ * in the reference (it has no device code): each entry point names the
+ * reference routine whose work it takes over, paths relative to
+ * /root/reference/src.
+ *
+ * Coefficient containers are the reference's ragged [S][N_s] layout
+ * (FWTa/wavelet_mem_v7.c:78-106) flattened: scale s starts at coef_off[s],
+ * N_s = ceil(N / D_s); complex values are interleaved (re, im) doubles.
+ */
+#ifndef TSPWS_HIP_H
+#define TSPWS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "ts_pws1f_lib.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+	TSPWS_OK        = 0,
+	TSPWS_E_ARG     = -1, /* NULL / inconsistent argument (tspws_main returns -1 for NULL too)   */
+	TSPWS_E_NOMEM   = 4,  /* host or device allocation failed (reference code, ts_pws1f_lib.c:199) */
+	TSPWS_E_NODEV   = 5,  /* no usable HIP device or kernel image                               */
+	TSPWS_E_HIP     = 6,  /* a HIP runtime call failed                                          */
+	TSPWS_E_FRAME   = 7   /* frame cannot be built (bad family id, wavelet longer than trace)   */
+};
+
+typedef struct tspws_hip_plan tspws_hip_plan;
+
+typedef struct {
+	int      type;          /* -1 / -2 / -3                                     */
+	unsigned S, V, J, N;    /* scales, voices, octaves, trace length            */
+	double   s0, b0, w0;    /* as passed to plan_create                         */
+	double   Cpsi;          /* admissibility constant                           */
+	size_t   ncoef;         /* sum of N_s  (complex coefficients per trace)     */
+	size_t   ntaps;         /* sum of L_s  (complex taps; the dual has as many) */
+	int      device;
+} tspws_hip_frame_info;
+
+/* ---- runtime helpers so that the C host needs no HIP headers ------------------ */
+int         tspws_hip_device_count(void);
+const char *tspws_hip_last_error(void);
+int  tspws_hip_alloc(void **d_ptr, size_t bytes, int device);
+int  tspws_hip_free(void *d_ptr);
+int  tspws_hip_upload(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int  tspws_hip_download(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int  tspws_hip_zero(void *d_ptr, size_t bytes, void *stream);
+int  tspws_hip_sync(void *stream);
+
+/* ---- parameters and plan ------------------------------------------------------ */
+
+/* Resolve w0 / V / b0 / s0 / J from the user's knobs, rewriting *p in place.
+ * Takes over ts_pws1f_lib.c:91-124 (host arithmetic, bit-for-bit the same rules). */
+void tspws_resolve_params(t_tsPWS *p, unsigned nsamp, float dt);
+
+/* Build the frame on `device`: geometry tables on the host, taps / dual taps generated
+ * by a device kernel, container offsets.  Takes over CreateWaveletFamily
+ * (FWTa/wavelet_def_v7.c:204-295) and the container set-up (wavelet_mem_v7.c:78-106).
+ * Argument meaning and order follow CreateWaveletFamily(type, J, V, N, s0, b0, -, w0, uni). */
+int  tspws_hip_plan_create(tspws_hip_plan **plan, int type, unsigned J, unsigned V, unsigned N,
+                           double s0, double b0, double w0, int uni, int device);
+void tspws_hip_plan_destroy(tspws_hip_plan *plan);   /* DestroyWaveletFamily, wavelet_def_v7.c:341 */
+int  tspws_hip_plan_info(const tspws_hip_plan *plan, tspws_hip_frame_info *info);
+/* host copies of the per-scale tables; any pointer may be NULL */
+int  tspws_hip_plan_tables(const tspws_hip_plan *plan, double *scale, unsigned *L, int *c, int *cd,
+                           unsigned *D, unsigned *Ns);
+/* device -> host copy of the (re,im) tap tables, 2*ntaps doubles each (tests) */
+int  tspws_hip_plan_taps(const tspws_hip_plan *plan, double *h_w, double *h_wd);
+
+/* ---- trace prologue (in place, float) ----------------------------------------- */
+/* fold: x[n] = x[max-1-n] = 0.5f*(x[n]+x[max-1-n]).   ts_pws1f_lib.c:76-86 */
+int  tspws_hip_fold(float *d_sigall, size_t mtr, size_t max, size_t ld, void *stream);
+/* remove each trace's mean (FP64 sum, float subtraction).   ts_pws1f_lib.c:159-169 */
+int  tspws_hip_remove_mean(float *d_sigall, size_t mtr, size_t max, size_t ld, void *stream);
+
+/* ---- stage 1 of the two-stage stack -------------------------------------------- */
+/* P[g][n] (+)= sum of this shard's traces whose GLOBAL index i = first + local falls in group
+ * g = floor(i*Kmax/mtr_global); P is [Kmax][ldP] doubles and is overwritten (rows of groups the
+ * shard does not touch become 0).  Takes over partial_linear_stacks, ts_pws1f_lib.c:866-881.
+ * This is the HBM-streaming kernel: every input sample is read exactly once. */
+int  tspws_hip_partial_stacks(tspws_hip_plan *plan, const float *d_sigall, size_t ld,
+                              size_t mtr_local, size_t first, size_t mtr_global, unsigned Kmax,
+                              double *d_P, size_t ldP, void *stream);
+
+/* ---- frame transforms ------------------------------------------------------------ */
+/* Forward frame CWT of ntr real traces (row stride ld elements) into d_Y[ntr][ncoef] complex.
+ * Takes over complex_1D_wavelet_dec (wavelet_v7.c:43-64) -> cdotx_dc (cdotx.c:35-72). */
+int  tspws_hip_forward_f64(tspws_hip_plan *plan, const double *d_x, size_t ntr, size_t ld, double *d_Y, void *stream);
+int  tspws_hip_forward_f32(tspws_hip_plan *plan, const float  *d_x, size_t ntr, size_t ld, double *d_Y, void *stream);
+/* Real part of the inverse frame transform of nrec coefficient sets d_Y[nrec][ncoef] into
+ * d_x[nrec][N] doubles.  Takes over Re_complex_1D_wavelet_rec (wavelet_v7.c:124-150) ->
+ * re_cdotx_upsampling_cc (cdotx.c:305-340) / re_cdotx_cc (cdotx.c:176-211). */
+int  tspws_hip_inverse(tspws_hip_plan *plan, const double *d_Y, size_t nrec, double *d_x, void *stream);
+
+/* ---- stacks in the time-scale domain ----------------------------------------------- */
+/* ST += sum_b Y_b ; PS += sum_b Y_b/|Y_b| (non-unit quotients skipped); zero_first clears
+ * ST/PS before.  The loop body of ts_pws1f_lib.c:486-494 / :897-904. */
+int  tspws_hip_accumulate(tspws_hip_plan *plan, const double *d_Y, size_t ntr, double *d_ST, double *d_PS,
+                          int zero_first, void *stream);
+/* forward + accumulate of K double-precision partial stacks.  tspws_stacks_double, :885-906 */
+int  tspws_hip_stacks_double(tspws_hip_plan *plan, const double *d_P, unsigned K, size_t ldP,
+                             double *d_ST, double *d_PS, void *stream);
+/* forward + accumulate of mtr float traces (ST/PS are cleared first).  tspws_stacks_float, :466-499 */
+int  tspws_hip_stacks_float(tspws_hip_plan *plan, const float *d_sigall, size_t mtr, size_t ld,
+                            double *d_ST, double *d_PS, void *stream);
+/* OUT = ST * weight(PS).  wu==2 && unbiased -> tspws_unbiased (:965-984) else tspws_biased (:909-943) */
+int  tspws_hip_weight(tspws_hip_plan *plan, double *d_OUT, const double *d_ST, const double *d_PS,
+                      unsigned K, unsigned M, double wu, int unbiased, void *stream);
+/* ls[n] = (float)x_st[n] / mtr (float division), tsPWS[n] = (float)x_out[n].   :233-241 */
+int  tspws_hip_epilogue(float *d_ls, float *d_tsPWS, const double *d_x_st, const double *d_x_out,
+                        size_t N, unsigned mtr, void *stream);
+
+/* ---- whole call on HBM-resident traces ------------------------------------------------ */
+/* What tspws_main does between reading `in` and writing `out`, for one shard of traces that
+ * already sits in device memory.  `p` must be resolved (tspws_resolve_params) and the plan
+ * built from it.  Split in two so that a multi-GPU caller can sum the shard results between
+ * the halves (one all-reduce of tspws_hip_reduce_buffer):
+ *   _local : two-stage  -> partial stacks of the shard        (reduce buffer = P[Kmax][N])
+ *            single     -> ST and PS of the shard's traces    (reduce buffer = ST||PS)
+ *   _finish: (two-stage: forward+accumulate of the K partials,) weight, two inverses, epilogue.
+ * d_ls / d_tsPWS receive `max` floats each. */
+int  tspws_hip_stack_local(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_sigall, size_t ld,
+                           size_t mtr_local, size_t first, size_t mtr_global, void *stream);
+int  tspws_hip_reduce_buffer(tspws_hip_plan *plan, const t_tsPWS *p, size_t mtr_global,
+                             double **d_buf, size_t *ndoubles);
+int  tspws_hip_stack_finish(tspws_hip_plan *plan, const t_tsPWS *p, size_t mtr_global,
+                            float *d_ls, float *d_tsPWS, void *stream);
+
+/* ---- jackknife (two-stage only, like the reference) ------------------------------------- */
+/* Host: deletion masks sel[C][mtr] (1 = kept) from start times.  JackknifePlans, :385-430.
+ * Returns 0, 1 for NULL arguments, -2 when time[0]==0 (no start times). */
+int  tspws_jackknife_plan(char *sel, const time_t *time, size_t mtr, unsigned d, unsigned n, unsigned C);
+/* Device: all C replicas from ONE pass over the traces.  TwoStage_jackknife_float, :719-831.
+ * d_ls_out / d_ts_out are [C][max] floats; h_mtr_out receives the C replica sizes. */
+int  tspws_hip_jackknife(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_sigall, size_t ld,
+                         size_t mtr, const char *h_sel, unsigned C,
+                         float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *stream);
+
+/* ---- synthetic ensembles for bench / tests ------------------------------------ */
+/* trace i = first+local, sample n: 0.2 sin(2pi(n-N/2)/200) exp(-((n-N/2)/(0.05N))^2/2) + U(-.5,.5) */
+int  tspws_hip_synth(float *d_sigall, size_t mtr, size_t N, size_t ld, uint64_t seed, size_t first, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSPWS_HIP_H */

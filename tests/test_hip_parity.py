@@ -1,0 +1,335 @@
+"""GPU parity tests: the HIP path (through the C-ABI of include/tspws_hip.h and the drop-in
+tspws_main) against the oracle and the golden vectors generated from the reference.
+
+Tolerance: north_star asks for 1e-5 relative (max|a-b| / max|b|) on the float32 outputs; the
+device path is FP64 like the reference, so the tests hold it to much tighter bounds:
+  * FP64 intermediates (taps, coefficients, reconstructions): 1e-11
+  * float32 outputs: 2e-6 (an ulp of the peak, plus rounding of values near a float tie)
+"""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+import abi
+from test_oracle_vs_golden import check_main, main_case_names, _case_params
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1e-11
+TOL32 = 2e-6
+NORTH_STAR_TOL = 1e-5
+
+tspws = importlib.import_module("ts-pws_amd")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = tspws.load()
+    assert lib.tspws_hip_device_count() > 0, "no MI355X visible: the HIP path cannot run (there is no CPU fallback)"
+    return lib
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def plan_for(params, N):
+    return tspws.Plan(tspws.resolve(params, N), N)
+
+
+# ---------------------------------------------------------------------------- frame
+@pytest.mark.parametrize("kw,N", [
+    (dict(), 2048), (dict(), 16501), (dict(w0=2 * np.pi), 32768), (dict(type=-3), 2048),
+    (dict(type=-2), 2048), (dict(s0=3.7, J=4), 1501), (dict(uni=1, J=3), 2048), (dict(), 131072), (dict(type=-3), 131072),
+])
+def test_frame_matches_oracle(lib, kw, N):
+    p = abi.resolve(abi.default_params(**kw), N)
+    f = abi.OracleFrame.from_params(p, N)
+    pl = tspws.Plan(p, N)
+    t = pl.tables()
+    assert pl.S == f.S and pl.ncoef == f.ncoef and pl.ntaps == f.ntaps
+    for k in ("L", "c", "cd", "D", "Ns"):
+        np.testing.assert_array_equal(t[k], getattr(f, k))
+    np.testing.assert_array_equal(t["scale"], f.scale)
+    assert pl.Cpsi == f.Cpsi
+    w, wd = pl.taps()
+    ow, owd = f.taps()
+    # device libm vs glibc: a few ulp on sincos/exp
+    assert np.max(np.abs(w - ow)) <= 1e-14 * np.max(np.abs(ow))
+    assert np.max(np.abs(wd - owd)) <= 1e-14 * np.max(np.abs(owd))
+
+
+def test_frame_known_answers(lib):
+    pl = plan_for(abi.default_params(), 131072)
+    assert pl.info.J == 14 and pl.S == 56 and pl.ncoef == 524256 and pl.ntaps == 1383505
+    assert pl.Cpsi == pytest.approx(0.29982027317664373, rel=1e-15)
+    w, _ = pl.taps()
+    assert w[10] == pytest.approx(0.53112596601359841 + 0j, rel=1e-13)
+
+
+# ---------------------------------------------------------------------- transforms
+def dev_forward(torch, pl, x):
+    xd = torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+    if xd.ndim == 1:
+        xd = xd[None, :]
+    Y = torch.zeros((xd.shape[0], pl.ncoef, 2), dtype=torch.float64, device="cuda")
+    fn = pl.lib.tspws_hip_forward_f64 if xd.dtype == torch.float64 else pl.lib.tspws_hip_forward_f32
+    tspws.check(fn(pl.h, xd.data_ptr(), xd.shape[0], xd.shape[1], Y.data_ptr(), None), "forward")
+    torch.cuda.synchronize()
+    return Y.cpu().numpy().view(np.complex128)[..., 0]
+
+
+def dev_inverse(torch, pl, Y):
+    Y = np.ascontiguousarray(np.atleast_2d(Y), np.complex128)
+    Yd = torch.as_tensor(Y.view(np.float64), device="cuda")
+    x = torch.zeros((Y.shape[0], pl.N), dtype=torch.float64, device="cuda")
+    tspws.check(pl.lib.tspws_hip_inverse(pl.h, Yd.data_ptr(), Y.shape[0], x.data_ptr(), None), "inverse")
+    torch.cuda.synchronize()
+    return x.cpu().numpy()
+
+
+def test_forward_inverse_golden(lib, torch, golden):
+    g = golden["cwt"]
+    for name in sorted({k.split("/")[0] for k in g.files}):
+        x = g[f"{name}/x"]
+        p = abi.default_params()
+        p.type, p.J, p.V = int(g[f"{name}/type"]), int(g[f"{name}/J"]), int(g[f"{name}/V"])
+        p.s0, p.b0, p.w0 = float(g[f"{name}/s0"]), float(g[f"{name}/b0"]), float(g[f"{name}/w0"])
+        pl = tspws.Plan(p, len(x))
+        Y = dev_forward(torch, pl, x)[0]
+        assert abi.relerr(Y, g[f"{name}/Y"]) < TOL64, name
+        # float32 input path gives the same coefficients for float-representable samples
+        Yf = dev_forward(torch, pl, x.astype(np.float32))[0]
+        assert abi.relerr(Yf, g[f"{name}/Y"]) < TOL64, name
+        xr = dev_inverse(torch, pl, g[f"{name}/Y"])[0]
+        assert abi.relerr(xr, g[f"{name}/xrec"]) < TOL64, name
+
+
+@pytest.mark.parametrize("kw,N,ntr", [
+    (dict(), 4096, 3), (dict(), 16501, 2), (dict(type=-3), 8192, 2), (dict(w0=2 * np.pi), 32768, 1),
+    (dict(s0=3.7, J=5), 3001, 2), (dict(uni=1, J=4), 1024, 2), (dict(), 131072, 1), (dict(type=-3), 131072, 1),
+    (dict(J=2), 64, 3), (dict(s0=7.890778, J=3), 16501, 1),
+])
+def test_forward_inverse_vs_oracle(lib, torch, kw, N, ntr):
+    p = abi.resolve(abi.default_params(**kw), N)
+    f = abi.OracleFrame.from_params(p, N)
+    pl = tspws.Plan(p, N)
+    X = abi.synth_traces(ntr, N, seed=21).astype(np.float64)
+    Y = dev_forward(torch, pl, X)
+    Yo = np.stack([f.forward(x) for x in X])
+    assert abi.relerr(Y, Yo) < TOL64
+    # per-scale check so that a small scale cannot hide behind a large one
+    off = np.concatenate([[0], np.cumsum(f.Ns)]).astype(np.int64)
+    for s in range(f.S):
+        assert abi.relerr(Y[:, off[s]:off[s + 1]], Yo[:, off[s]:off[s + 1]]) < 1e-10, s
+    xr = dev_inverse(torch, pl, Yo)
+    xo = np.stack([f.inverse(y) for y in Yo])
+    assert abi.relerr(xr, xo) < TOL64
+    # linearity of the transform pair (size-independent property)
+    if ntr >= 2:
+        Ysum = dev_forward(torch, pl, (X[0] + 2 * X[1])[None, :])[0]
+        assert abi.relerr(Ysum, Y[0] + 2 * Y[1]) < 1e-12
+
+
+def test_accumulate_and_weight(lib, torch):
+    N = 2048
+    p = abi.resolve(abi.default_params(), N)
+    f = abi.OracleFrame.from_params(p, N)
+    pl = tspws.Plan(p, N)
+    rng = np.random.default_rng(2)
+    Y = (rng.standard_normal((5, f.ncoef)) + 1j * rng.standard_normal((5, f.ncoef)))
+    Y[2, ::7] = 0.0  # exact zeros: the NaN-skip rule of the phase stack
+    Y[3, 5] = 1e-310 + 0j  # subnormal
+    ST = np.zeros(f.ncoef, np.complex128)
+    PS = np.zeros(f.ncoef, np.complex128)
+    orc = abi.oracle()
+    for y in Y:
+        yy = np.ascontiguousarray(y)
+        orc.orc_accumulate(ST.ctypes.data, PS.ctypes.data, yy.ctypes.data, f.ncoef)
+    Yd = torch.as_tensor(Y.view(np.float64), device="cuda")
+    STd = torch.zeros(2 * f.ncoef, dtype=torch.float64, device="cuda")
+    PSd = torch.zeros_like(STd)
+    tspws.check(lib.tspws_hip_accumulate(pl.h, Yd.data_ptr(), 3, STd.data_ptr(), PSd.data_ptr(), 1, None))
+    tspws.check(lib.tspws_hip_accumulate(pl.h, Yd[3:].data_ptr(), 2, STd.data_ptr(), PSd.data_ptr(), 0, None))
+    torch.cuda.synchronize()
+    assert abi.relerr(STd.cpu().numpy().view(np.complex128), ST) < 1e-14
+    assert abi.relerr(PSd.cpu().numpy().view(np.complex128), PS) < 1e-14
+    for (K, M, wu, unb) in [(5, 5, 2.0, 0), (5, 5, 1.0, 0), (5, 5, 1.5, 0), (5, 5, 2.0, 1), (1, 7, 2.0, 1), (4, 100, 2.0, 1), (5, 5, 1.0, 1)]:
+        OUT = np.zeros(f.ncoef, np.complex128)
+        orc.orc_weight(OUT.ctypes.data, ST.ctypes.data, PS.ctypes.data, f.ncoef, K, M, wu, unb)
+        OUTd = torch.zeros_like(STd)
+        tspws.check(lib.tspws_hip_weight(pl.h, OUTd.data_ptr(), STd.data_ptr(), PSd.data_ptr(), K, M, wu, unb, None))
+        torch.cuda.synchronize()
+        assert abi.relerr(OUTd.cpu().numpy().view(np.complex128), OUT) < 1e-13, (K, M, wu, unb)
+
+
+# ------------------------------------------------------------------- partial stacks
+@pytest.mark.parametrize("mtr,N,K", [(16, 2048, 4), (37, 1501, 5), (1000, 4096, 10), (7, 64, 7), (5, 1028, 1), (64, 16501, 10), (3, 8192, 3)])
+def test_partial_stacks_bit_exact_groups(lib, torch, mtr, N, K):
+    """FP64 sums of float32 samples: compare with the oracle; group membership must be exact."""
+    X = abi.synth_traces(mtr, N, seed=9)
+    P = np.zeros((K, N))
+    abi.oracle().orc_partial_stacks(P.ctypes.data, X.ctypes.data, N, mtr, K)
+    p = abi.resolve(abi.default_params(Kmax=K), N)
+    pl = tspws.Plan(p, N)
+    Xd = torch.as_tensor(X, device="cuda")
+    Pd = torch.full((K, N), np.nan, dtype=torch.float64, device="cuda")
+    tspws.check(lib.tspws_hip_partial_stacks(pl.h, Xd.data_ptr(), N, mtr, 0, mtr, K, Pd.data_ptr(), N, None))
+    torch.cuda.synchronize()
+    got = Pd.cpu().numpy()
+    assert np.max(np.abs(got - P)) <= 1e-13 * max(1.0, np.max(np.abs(P)))
+    # sharded: two shards with global indices, summed, equal the unsharded result
+    h = mtr // 3
+    A = torch.zeros_like(Pd)
+    B = torch.zeros_like(Pd)
+    tspws.check(lib.tspws_hip_partial_stacks(pl.h, Xd.data_ptr(), N, h, 0, mtr, K, A.data_ptr(), N, None))
+    tspws.check(lib.tspws_hip_partial_stacks(pl.h, Xd[h:].data_ptr(), N, mtr - h, h, mtr, K, B.data_ptr(), N, None))
+    torch.cuda.synchronize()
+    assert np.max(np.abs((A + B).cpu().numpy() - P)) <= 1e-13 * max(1.0, np.max(np.abs(P)))
+
+
+def test_prologue_kernels(lib, torch):
+    for N in (2048, 2047, 16501):
+        X = abi.synth_traces(9, N, seed=4) + np.float32(0.25)
+        Xd = torch.as_tensor(X, device="cuda").clone()
+        tspws.check(lib.tspws_hip_fold(Xd.data_ptr(), 9, N, N, None))
+        F = X.copy()
+        h = N // 2
+        v = (F[:, :h] + F[:, ::-1][:, :h]) * np.float32(0.5)
+        F[:, :h] = v
+        F[:, ::-1][:, :h] = v
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(Xd.cpu().numpy(), F)  # float ops: bit exact
+        tspws.check(lib.tspws_hip_remove_mean(Xd.data_ptr(), 9, N, N, None))
+        torch.cuda.synchronize()
+        m = (F.astype(np.float64).sum(axis=1) / N).astype(np.float32)
+        R = F - m[:, None]
+        assert np.max(np.abs(Xd.cpu().numpy() - R)) <= 1.2e-7 * np.max(np.abs(R))  # mean may round one float ulp apart
+
+
+# --------------------------------------------------------------------- whole calls
+def test_tspws_main_golden(lib, golden):
+    """The drop-in entry point on every golden case produced by the reference."""
+    g = golden["mains"]
+    for name in main_case_names(g):
+        check_main(lib.tspws_main, g, name, TOL32)
+
+
+def test_tspws_main_example_data(lib, golden):
+    g = golden["example32"]
+    for name in ("ex1", "ex2", "ex3", "ex_mexhat"):
+        p = _case_params(g, name)
+        r = abi.run_main(lib.tspws_main, p, g["traces"], dt=float(g["dt"]), beg=float(g["beg"]))
+        assert r["rc"] == 0
+        assert abi.relerr(r["ls"], g[f"{name}/ls"]) < TOL32, name
+        assert abi.relerr(r["tsPWS"], g[f"{name}/tsPWS"]) < TOL32, name
+
+
+@pytest.mark.parametrize("kw,mtr,N", [
+    (dict(), 24, 4096), (dict(Kmax=10, unbiased=1), 100, 8192), (dict(type=-3, Kmax=3), 30, 4096),
+    (dict(w0=2 * np.pi), 12, 32768), (dict(Kmax=10, unbiased=1), 40, 131072), (dict(lrm=1, wu=1.3), 10, 3000),
+])
+def test_tspws_main_vs_oracle(lib, kw, mtr, N):
+    X = abi.synth_traces(mtr, N, seed=33)
+    p = abi.default_params(**kw)
+    a = abi.run_main(lib.tspws_main, p, X)
+    b = abi.run_main(abi.oracle().orc_tspws_main, p, X)
+    assert a["rc"] == 0 and b["rc"] == 0
+    assert abi.relerr(a["ls"], b["ls"]) < TOL32 < NORTH_STAR_TOL
+    assert abi.relerr(a["tsPWS"], b["tsPWS"]) < TOL32
+
+
+def test_tspws_main_vs_reference_if_built(lib):
+    ref = abi.ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built on this machine")
+    X = abi.synth_traces(50, 8192, seed=8)
+    for kw in (dict(), dict(Kmax=10, unbiased=1), dict(type=-3)):
+        p = abi.default_params(**kw)
+        a = abi.run_main(lib.tspws_main, p, X)
+        b = abi.run_main(ref.tspws_main, p, X)
+        assert abi.relerr(a["ls"], b["ls"]) < TOL32 and abi.relerr(a["tsPWS"], b["tsPWS"]) < TOL32
+
+
+def test_jackknife_vs_oracle_many_traces(lib):
+    mtr, N = 400, 2048
+    X = abi.synth_traces(mtr, N, seed=6)
+    rng = np.random.default_rng(3)
+    times = 1262304000 + 86400 * np.sort(rng.integers(0, 3 * 365, mtr))
+    for kw in (dict(Kmax=10, jackknife_n=10, jackknife_d=1), dict(Kmax=4, unbiased=1, jackknife_n=6, jackknife_d=2, type=-3)):
+        p = abi.default_params(**kw)
+        a = abi.run_main(lib.tspws_main, p, X, times=times)
+        b = abi.run_main(abi.oracle().orc_tspws_main, p, X, times=times)
+        np.testing.assert_array_equal(a["jk_mtr"], b["jk_mtr"])
+        for c in range(len(a["jk_mtr"])):
+            assert abi.relerr(a["jk_ls"][c], b["jk_ls"][c]) < TOL32
+            assert abi.relerr(a["jk_ts"][c], b["jk_ts"][c]) < TOL32
+    # unsorted start times: deletion classes are not contiguous in trace order
+    times2 = rng.permutation(times)
+    p = abi.default_params(Kmax=5, jackknife_n=5, jackknife_d=1)
+    a = abi.run_main(lib.tspws_main, p, X[:120], times=times2[:120])
+    b = abi.run_main(abi.oracle().orc_tspws_main, p, X[:120], times=times2[:120])
+    np.testing.assert_array_equal(a["jk_mtr"], b["jk_mtr"])
+    assert max(abi.relerr(a["jk_ts"][c], b["jk_ts"][c]) for c in range(5)) < TOL32
+    # no start times: replicas are left untouched, main outputs still produced
+    z = abi.run_main(lib.tspws_main, p, X[:20], times=np.zeros(20, np.int64))
+    assert z["rc"] == 0 and not z["jk_ts"].any() and z["tsPWS"].any()
+
+
+# ------------------------------------------------------- device-resident / sharded path
+@pytest.mark.parametrize("kw", [dict(Kmax=10, unbiased=1), dict(), dict(type=-3, Kmax=4)])
+def test_device_path_and_shards(lib, torch, kw):
+    mtr, N = 64, 8192
+    p = tspws.resolve(abi.default_params(**kw), N)
+    pl = tspws.Plan(p, N)
+    Xd = tspws.synth(mtr, N, seed=5)
+    X = Xd.cpu().numpy()
+    np.testing.assert_array_equal(X, abi.synth_traces(mtr, N, seed=5) if False else X)  # (device generator is its own source)
+    b = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), X)
+    ls, ts = pl.stack(Xd)
+    torch.cuda.synchronize()
+    assert abi.relerr(ls.cpu().numpy(), b["ls"]) < TOL32
+    assert abi.relerr(ts.cpu().numpy(), b["tsPWS"]) < TOL32
+    # emulate 4 ranks on one GPU: shard-local halves, summed reduce buffers, one finish
+    total = None
+    for r in range(4):
+        f, c = tspws.shard_range(mtr, r, 4)
+        pl.stack_local(Xd[f:f + c], f, mtr)
+        buf = pl.reduce_buffer(mtr).clone()
+        total = buf if total is None else total + buf
+    pl.reduce_buffer(mtr).copy_(total)
+    ls2 = torch.empty_like(ls)
+    ts2 = torch.empty_like(ts)
+    pl.stack_finish(mtr, ls2, ts2)
+    torch.cuda.synchronize()
+    assert abi.relerr(ls2.cpu().numpy(), b["ls"]) < TOL32
+    assert abi.relerr(ts2.cpu().numpy(), b["tsPWS"]) < TOL32
+
+
+def test_synth_generator_matches_host_recipe(lib, torch):
+    Xd = tspws.synth(5, 4096, seed=7, first=3).cpu().numpy()
+    Xh = abi.synth_traces(5, 4096, seed=7, first=3)
+    assert np.max(np.abs(Xd - Xh)) <= 2e-7  # same integers; sin/exp may differ by an ulp before the float cast
+
+
+def test_full_size_properties(lib, torch):
+    """BASELINE sizes (north-star shape, fewer traces than 10k to stay in seconds): properties that
+    do not need the oracle -- group sums add up to the total, and a constant ensemble stacks to itself."""
+    mtr, N, K = 512, 131072, 10
+    p = tspws.resolve(abi.default_params(Kmax=K, unbiased=1), N)
+    pl = tspws.Plan(p, N)
+    Xd = tspws.synth(mtr, N, seed=1)
+    pl.stack_local(Xd, 0, mtr)
+    P = pl.reduce_buffer(mtr).view(K, N)
+    tot = Xd.double().sum(dim=0)
+    assert float((P.sum(dim=0) - tot).abs().max()) <= 1e-9
+    # identical traces: phase stack is fully coherent -> tsPWS == ls == ICWT(CWT(x)) (unbiased weight = 1)
+    Xc = Xd[:1].repeat(64, 1).contiguous()
+    ls, ts = pl.stack(Xc)
+    torch.cuda.synchronize()
+    assert abi.relerr(ts.cpu().numpy(), ls.cpu().numpy()) < 1e-6

@@ -1,0 +1,236 @@
+"""ts-pws_amd -- MI355X-native time-scale phase-weighted stack (ts-PWS).
+
+The product is the C-ABI shared library ``lib/libtspws_hip.so`` (hand-written
+gfx950 HIP kernels + the C host entry point ``tspws_main``; headers in
+``include/``).  This module is only the Python-side binding used by the tests
+and ``bench.py``: ctypes signatures, a ``Plan`` wrapper, and helpers that run
+the device-resident path on torch-allocated HBM buffers (torch provides device
+memory, streams and torch.distributed -- plumbing, not compute).
+
+There is no CPU fallback anywhere: if the library is missing or no HIP device
+is present the calls raise.
+
+Import with ``importlib.import_module("ts-pws_amd")`` (the directory name is
+not a Python identifier).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "lib", "libtspws_hip.so")
+
+time_t = C.c_long
+
+
+class t_tsPWS(C.Structure):
+    """include/ts_pws1f_lib.h (reference: src/ts_pws1f_lib.h:19-57)."""
+    _fields_ = [
+        ("type", C.c_int), ("uni", C.c_uint), ("J", C.c_uint), ("V", C.c_uint),
+        ("s0", C.c_double), ("b0", C.c_double), ("w0", C.c_double), ("wu", C.c_double),
+        ("fmin", C.c_double), ("Q", C.c_double), ("cycle", C.c_double),
+        ("w0set", C.c_int), ("lrm", C.c_int), ("bin", C.c_int), ("lkinst", C.c_int),
+        ("lVfix", C.c_int), ("ls0fix", C.c_int), ("lb0fix", C.c_int), ("verbose", C.c_int),
+        ("fold", C.c_int), ("unbiased", C.c_int), ("convergence", C.c_int),
+        ("subsmpl_N", C.c_uint), ("subsmpl_p", C.c_double),
+        ("jackknife_n", C.c_uint), ("jackknife_d", C.c_uint), ("obin", C.c_uint),
+        ("AllSteps", C.c_int), ("Nmax", C.c_uint), ("Kmax", C.c_uint),
+        ("kinst", C.c_char_p), ("filein", C.c_char_p), ("fileout", C.c_char_p), ("fileconv", C.c_char_p),
+    ]
+
+
+class FrameInfo(C.Structure):
+    """tspws_hip_frame_info (include/tspws_hip.h)."""
+    _fields_ = [
+        ("type", C.c_int), ("S", C.c_uint), ("V", C.c_uint), ("J", C.c_uint), ("N", C.c_uint),
+        ("s0", C.c_double), ("b0", C.c_double), ("w0", C.c_double), ("Cpsi", C.c_double),
+        ("ncoef", C.c_size_t), ("ntaps", C.c_size_t), ("device", C.c_int),
+    ]
+
+
+class TspwsError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = subprocess.run(["make", "-C", _HERE, "all"], capture_output=True, text=True)
+    if verbose or out.returncode:
+        print(out.stdout + out.stderr)
+    if out.returncode:
+        raise TspwsError("building libtspws_hip.so failed")
+    return LIB_PATH
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/tspws_hip.h + ts_pws1f_lib.h declare
+_vp, _u, _d, _sz, _i, _f = C.c_void_p, C.c_uint, C.c_double, C.c_size_t, C.c_int, C.c_float
+SYMBOLS = {
+    "tspws_main": (_i, [_vp, _vp, _vp]),
+    "tspws_hip_device_count": (_i, []),
+    "tspws_hip_last_error": (C.c_char_p, []),
+    "tspws_hip_alloc": (_i, [C.POINTER(_vp), _sz, _i]),
+    "tspws_hip_free": (_i, [_vp]),
+    "tspws_hip_upload": (_i, [_vp, _vp, _sz, _vp]),
+    "tspws_hip_download": (_i, [_vp, _vp, _sz, _vp]),
+    "tspws_hip_zero": (_i, [_vp, _sz, _vp]),
+    "tspws_hip_sync": (_i, [_vp]),
+    "tspws_resolve_params": (None, [_vp, _u, _f]),
+    "tspws_hip_plan_create": (_i, [C.POINTER(_vp), _i, _u, _u, _u, _d, _d, _d, _i, _i]),
+    "tspws_hip_plan_destroy": (None, [_vp]),
+    "tspws_hip_plan_info": (_i, [_vp, _vp]),
+    "tspws_hip_plan_tables": (_i, [_vp] + [_vp] * 6),
+    "tspws_hip_plan_taps": (_i, [_vp, _vp, _vp]),
+    "tspws_hip_fold": (_i, [_vp, _sz, _sz, _sz, _vp]),
+    "tspws_hip_remove_mean": (_i, [_vp, _sz, _sz, _sz, _vp]),
+    "tspws_hip_partial_stacks": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _u, _vp, _sz, _vp]),
+    "tspws_hip_forward_f64": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "tspws_hip_forward_f32": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "tspws_hip_inverse": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "tspws_hip_accumulate": (_i, [_vp, _vp, _sz, _vp, _vp, _i, _vp]),
+    "tspws_hip_stacks_double": (_i, [_vp, _vp, _u, _sz, _vp, _vp, _vp]),
+    "tspws_hip_stacks_float": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    "tspws_hip_weight": (_i, [_vp, _vp, _vp, _vp, _u, _u, _d, _i, _vp]),
+    "tspws_hip_epilogue": (_i, [_vp, _vp, _vp, _vp, _sz, _u, _vp]),
+    "tspws_hip_stack_local": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "tspws_hip_reduce_buffer": (_i, [_vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz)]),
+    "tspws_hip_stack_finish": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "tspws_jackknife_plan": (_i, [_vp, _vp, _sz, _u, _u, _u]),
+    "tspws_hip_jackknife": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _u, _vp, _vp, _vp, _vp]),
+    "tspws_hip_synth": (_i, [_vp, _sz, _sz, _sz, C.c_uint64, _sz, _vp]),
+}
+
+
+def load():
+    """Load libtspws_hip.so and type its entry points.  Raises when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TspwsError(f"{LIB_PATH} is missing: run __graft_entry__.build() / make -C ts-pws_amd")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the header promises a symbol the library lacks
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc:
+        raise TspwsError(f"{what} failed with code {rc}: {load().tspws_hip_last_error().decode()}")
+
+
+def resolve(params, nsamp, dt=1.0):
+    """Resolved copy of a t_tsPWS (tspws_resolve_params; reference ts_pws1f_lib.c:91-124)."""
+    p = t_tsPWS.from_buffer_copy(params)
+    load().tspws_resolve_params(C.byref(p), nsamp, dt)
+    return p
+
+
+def shard_range(mtr_global, rank, world):
+    """Contiguous trace shard [first, first+count) of `rank`."""
+    first = rank * mtr_global // world
+    last = (rank + 1) * mtr_global // world
+    return first, last - first
+
+
+class Plan:
+    """Device-resident frame (taps, tables, scratch) for one resolved parameter set."""
+
+    def __init__(self, params, N, device=0):
+        self.lib = load()
+        self.params = t_tsPWS.from_buffer_copy(params)
+        h = C.c_void_p()
+        p = self.params
+        check(self.lib.tspws_hip_plan_create(C.byref(h), p.type, p.J, p.V, N, p.s0, p.b0, p.w0, int(p.uni), device), "plan_create")
+        self.h = h
+        info = FrameInfo()
+        check(self.lib.tspws_hip_plan_info(self.h, C.byref(info)), "plan_info")
+        self.info = info
+        self.N, self.S, self.ncoef, self.ntaps, self.Cpsi = N, info.S, info.ncoef, info.ntaps, info.Cpsi
+        self.device = device
+
+    def tables(self):
+        import numpy as np
+        S = self.S
+        t = dict(scale=np.zeros(S), L=np.zeros(S, np.uint32), c=np.zeros(S, np.int32), cd=np.zeros(S, np.int32),
+                 D=np.zeros(S, np.uint32), Ns=np.zeros(S, np.uint32))
+        check(self.lib.tspws_hip_plan_tables(self.h, *[t[k].ctypes.data for k in ("scale", "L", "c", "cd", "D", "Ns")]), "plan_tables")
+        return t
+
+    def taps(self):
+        import numpy as np
+        w = np.zeros(self.ntaps, np.complex128)
+        wd = np.zeros(self.ntaps, np.complex128)
+        check(self.lib.tspws_hip_plan_taps(self.h, w.ctypes.data, wd.ctypes.data), "plan_taps")
+        return w, wd
+
+    # ---- device-resident path on torch tensors -------------------------------------
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def reduce_buffer(self, mtr_global):
+        """torch view (float64) of the buffer a multi-GPU caller all-reduces between the halves."""
+        import torch
+        ptr, n = C.c_void_p(), C.c_size_t()
+        check(self.lib.tspws_hip_reduce_buffer(self.h, C.byref(self.params), mtr_global, C.byref(ptr), C.byref(n)), "reduce_buffer")
+        return _as_tensor(ptr.value, n.value, torch.float64, self.device)
+
+    def stack_local(self, traces, first=0, mtr_global=None):
+        mtr, ld = traces.shape[0], traces.stride(0) if traces.shape[0] > 1 else traces.shape[1]
+        mtr_global = mtr if mtr_global is None else mtr_global
+        check(self.lib.tspws_hip_stack_local(self.h, C.byref(self.params), traces.data_ptr(), ld, mtr, first, mtr_global, self._stream()),
+              "stack_local")
+
+    def stack_finish(self, mtr_global, ls, ts):
+        check(self.lib.tspws_hip_stack_finish(self.h, C.byref(self.params), mtr_global, ls.data_ptr(), ts.data_ptr(), self._stream()),
+              "stack_finish")
+
+    def stack(self, traces, first=0, mtr_global=None, group=None):
+        """ls, tsPWS (float32 cuda tensors) of a shard of HBM-resident traces; with a
+        torch.distributed `group` (or an initialised default group when mtr_global is given
+        and world_size > 1) the shard results are summed with ONE all-reduce over RCCL."""
+        import torch
+        import torch.distributed as dist
+        mtr_global = traces.shape[0] if mtr_global is None else mtr_global
+        self.stack_local(traces, first, mtr_global)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.reduce_buffer(mtr_global), op=dist.ReduceOp.SUM, group=group)
+        ls = torch.empty(self.N, dtype=torch.float32, device=traces.device)
+        ts = torch.empty(self.N, dtype=torch.float32, device=traces.device)
+        self.stack_finish(mtr_global, ls, ts)
+        return ls, ts
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tspws_hip_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _as_tensor(ptr, count, dtype, device):
+    """Zero-copy torch view of library-owned device memory (via __cuda_array_interface__)."""
+    import torch
+    typestr = {torch.float64: "<f8", torch.float32: "<f4"}[dtype]
+
+    class _Holder:
+        __cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
+
+    return torch.as_tensor(_Holder(), device=f"cuda:{device}")
+
+
+def synth(mtr, N, seed=0, first=0, device=0):
+    """Seeded synthetic ensemble generated on the device (float32 [mtr][N])."""
+    import torch
+    x = torch.empty((mtr, N), dtype=torch.float32, device=f"cuda:{device}")
+    check(load().tspws_hip_synth(x.data_ptr(), mtr, N, N, seed, first, Plan._stream()), "synth")
+    return x

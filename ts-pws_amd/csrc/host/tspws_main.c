@@ -1,0 +1,138 @@
+/*
+ * tspws_main.c -- the drop-in entry point, host side, plain C.
+ *
+ * Same signature, struct layout, return codes and in/out side effects as the
+ * reference's tspws_main (/root/reference/src/ts_pws1f_lib.c:48-352); all
+ * arithmetic on the traces runs on the MI355X through the C-ABI HIP layer of
+ * include/tspws_hip.h.  There is no CPU fallback: without a usable device the
+ * call fails with TSPWS_E_NODEV (5).
+ *
+ * Covered: fold (:71-88), parameter resolution (:91-124), mean removal
+ * (:159-169), single- and two-stage stacks (:194-242), biased / unbiased
+ * weighting (:226-228), two-stage jackknife (:335-345).
+ * Not yet on the device path ("next" rows): convergence curves
+ * (:247-314) and random subsampling (:324-333); requesting them prints a notice
+ * and leaves their outputs untouched.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "tspws_hip.h"
+
+static int device_from_env(void)
+{
+	const char *e = getenv("TSPWS_DEVICE");
+	return e ? atoi(e) : 0;
+}
+
+#define TRY(call) do { rc = (call); if (rc) goto done; } while (0)
+
+int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
+{
+	if (tspws == NULL || out == NULL || in == NULL) { printf("tspws_main: NULL input\n"); return -1; }
+
+	const int    max   = in->hdr.max;
+	const size_t mtr   = tspws->Nmax ? tspws->Nmax : in->hdr.mtr;
+	const float  beg   = in->hdr.beg, dt = in->hdr.dt;
+	const unsigned nsamp = (unsigned)max;
+	const int dev = device_from_env();
+	int rc = 0, do_fold = 0;
+
+	/* fold test, same float arithmetic as :72 */
+	if (tspws->fold) {
+		if (2 * beg + (max - 1) * dt > 0.5 * dt) {
+			printf("Warning: Folding ignored. B = %f, E = %f, nsamp = %u\n", beg, beg + (max - 1) * dt, nsamp);
+			tspws->fold = 0;
+		} else do_fold = 1;
+	}
+	tspws_resolve_params(tspws, nsamp, dt);
+
+	if (tspws->verbose) {
+		printf("Sequence length = %d, dt = %f\n", nsamp, dt);
+		printf("  PWS power = %f\n", tspws->wu);
+		if (tspws->Kmax) printf("  Two-stage on, %d groups\n", tspws->Kmax); else printf("  Two-stage off\n");
+		printf("  unbiased %s\n  rm %s\n  fold %s\n", tspws->unbiased ? "on" : "off", tspws->lrm ? "on" : "off", tspws->fold ? "on" : "off");
+		printf("Mother wavelet: %s\n", tspws->type == -1 ? "complex Morlet" : tspws->type == -2 ? "exact complex Morlet" : "complex Mexican hat");
+		printf("Sampling of the time-frequency domain:\n");
+		printf("         V = %d, J = %d, b0 = %f, s0 = %f, w0 = %f\n", tspws->V, tspws->J, tspws->b0, tspws->s0, tspws->w0);
+		printf("This is: fmax = %f Hz, fmin = %f Hz\n", tspws->w0 / (2 * PI * tspws->s0 * dt),
+		       tspws->w0 / (2 * PI * dt * tspws->s0 * pow(2, tspws->J - 1 / (double)tspws->V)));
+		printf("         Q = %f (equivalently cycles = %f)\n", tspws->w0 / (2 * sqrt(log(2))), tspws->w0 * sqrt(log(2)) / PI);
+		if (tspws->jackknife_n > 0 && tspws->jackknife_d > 0)
+			printf("Jackknife Resampling:\n  n = %d, d = %d\n", tspws->jackknife_n, tspws->jackknife_d);
+		printf("Engine: MI355X HIP path, device %d\n\n", dev);
+	}
+
+	if (tspws_hip_device_count() <= dev) {
+		printf("tspws_main: no usable HIP device (%s)\n", tspws_hip_last_error());
+		return TSPWS_E_NODEV;
+	}
+
+	tspws_hip_plan *plan = NULL;
+	float *d_sig = NULL, *d_out = NULL, *d_jk = NULL;
+	char *sel = NULL;
+	float *stage = NULL;
+	const size_t ld = (size_t)max;
+
+	if (!mtr) return 0; /* the reference builds the family and returns 0 without touching out (:194) */
+
+	rc = tspws_hip_plan_create(&plan, tspws->type, tspws->J, tspws->V, nsamp, tspws->s0, tspws->b0, tspws->w0, (int)tspws->uni, dev);
+	if (rc) {
+		printf("tspws_main: cannot build the wavelet frame (%s)\n", tspws_hip_last_error());
+		/* CreateWaveletFamily failure surfaces as 4 in the reference (container creation fails, :199-204) */
+		return rc == TSPWS_E_NODEV ? rc : TSPWS_E_NOMEM;
+	}
+
+	TRY(tspws_hip_alloc((void **)&d_sig, mtr * ld * sizeof(float), dev));
+	TRY(tspws_hip_alloc((void **)&d_out, 2 * ld * sizeof(float), dev));
+	TRY(tspws_hip_upload(d_sig, in->sigall, mtr * ld * sizeof(float), NULL));
+
+	/* in-place prologue on the device, then mirrored back: the caller sees the same mutated
+	 * sigall the reference leaves behind (:83-84, :167) */
+	if (do_fold) TRY(tspws_hip_fold(d_sig, mtr, (size_t)max, ld, NULL));
+	if (tspws->lrm) TRY(tspws_hip_remove_mean(d_sig, mtr, (size_t)max, ld, NULL));
+	if (do_fold || tspws->lrm) TRY(tspws_hip_download(in->sigall, d_sig, mtr * ld * sizeof(float), NULL));
+
+	TRY(tspws_hip_stack_local(plan, tspws, d_sig, ld, mtr, 0, mtr, NULL));
+	TRY(tspws_hip_stack_finish(plan, tspws, mtr, d_out, d_out + ld, NULL));
+	TRY(tspws_hip_download(out->ls, d_out, ld * sizeof(float), NULL));
+	TRY(tspws_hip_download(out->tsPWS, d_out + ld, ld * sizeof(float), NULL));
+
+	if (tspws->convergence)
+		printf("tspws_main: convergence curves are not on the HIP path yet; outputs left untouched.\n");
+	if (tspws->subsmpl_N > 0 && tspws->subsmpl_p > 0)
+		printf("tspws_main: random subsampling is not on the HIP path yet; outputs left untouched.\n");
+
+	if (tspws->jackknife_n > 0 && tspws->jackknife_d > 0 && tspws->Kmax && tspws->Kmax <= mtr) {
+		const unsigned C = out->M;
+		if (C && out->ls_subsmpl && out->tsPWS_subsmpl && out->mtr_subsmpl) {
+			sel = (char *)malloc((size_t)C * mtr);
+			if (!sel) { rc = TSPWS_E_NOMEM; goto done; }
+			const int pr = tspws_jackknife_plan(sel, in->time, mtr, tspws->jackknife_d, tspws->jackknife_n, C);
+			if (pr == 0) {
+				TRY(tspws_hip_alloc((void **)&d_jk, 2 * (size_t)C * ld * sizeof(float), dev));
+				TRY(tspws_hip_jackknife(plan, tspws, d_sig, ld, mtr, sel, C, d_jk, d_jk + (size_t)C * ld, out->mtr_subsmpl, NULL));
+				stage = (float *)malloc(2 * (size_t)C * ld * sizeof(float));
+				if (!stage) { rc = TSPWS_E_NOMEM; goto done; }
+				TRY(tspws_hip_download(stage, d_jk, 2 * (size_t)C * ld * sizeof(float), NULL));
+				for (unsigned c = 0; c < C; c++) {
+					memcpy(out->ls_subsmpl[c], stage + (size_t)c * ld, ld * sizeof(float));
+					memcpy(out->tsPWS_subsmpl[c], stage + ((size_t)C + c) * ld, ld * sizeof(float));
+				}
+			} else
+				printf("tspws_main: jackknife needs trace start times (binary input); replicas left untouched.\n");
+		}
+	}
+
+done:
+	if (rc) printf("tspws_main: HIP path failed (%d: %s)\n", rc, tspws_hip_last_error());
+	free(stage);
+	free(sel);
+	tspws_hip_free(d_jk);
+	tspws_hip_free(d_out);
+	tspws_hip_free(d_sig);
+	tspws_hip_plan_destroy(plan);
+	return rc;
+}

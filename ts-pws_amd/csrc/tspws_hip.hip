@@ -1,0 +1,1121 @@
+// tspws_hip.hip -- gfx950 (MI355X) kernels and the thin C-ABI declared in include/tspws_hip.h.
+//
+// Layout in HBM
+//   traces      float  [mtr][ld]          row-major, one trace per row (the reference's sigall)
+//   partials    double [Kmax][ldP]        stage-1 group sums of the two-stage stack
+//   taps        double2 [ntaps]           ragged per scale, tap_off[s] .. ; dual taps likewise
+//   coefficients double2 [ncoef]          ragged [S][N_s], coef_off[s] ..  (N_s = ceil(N/D_s))
+// All arithmetic on the path is FP64 (the reference is double / double complex throughout);
+// MFMA is deliberately unused: the per-scale FIRs are skinny 1-D correlations.
+//
+// Reference citations are relative to /root/reference/src.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "tspws_hip.h"
+
+#ifndef TSPWS_PI
+#define TSPWS_PI 3.14159265358979328
+#endif
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+extern "C" const char *tspws_hip_last_error(void) { return g_err.c_str(); }
+
+static int fail(int code, const char *what, hipError_t e = hipSuccess)
+{
+	g_err = what;
+	if (e != hipSuccess) { g_err += ": "; g_err += hipGetErrorString(e); }
+	return code;
+}
+
+#define HIP_TRY(expr)                                                              \
+	do {                                                                           \
+		hipError_t e_ = (expr);                                                    \
+		if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? TSPWS_E_NOMEM : TSPWS_E_HIP, #expr, e_); \
+	} while (0)
+
+static inline hipStream_t S_(void *s) { return (hipStream_t)s; }
+
+// ------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------
+struct ScaleDesc {
+	unsigned L, D, Ns;
+	int c, cd;
+	unsigned pad;
+	unsigned long long tap_off, coef_off;
+	double scale, gain; // gain = ln2 / (2 Cpsi V scale), wavelet_v7.c:145
+};
+
+struct Chunk { // one streaming work item of the partial-stack kernel
+	unsigned long long t0; // first local trace
+	unsigned count;        // traces
+	unsigned row;          // destination row (group / class)
+};
+
+enum { SCR_Y = 0, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_N };
+
+struct tspws_hip_plan {
+	int device = 0, type = -1;
+	unsigned S = 0, V = 0, J = 0, N = 0;
+	double s0 = 0, b0 = 0, w0 = 0, Cpsi = 0;
+	size_t ncoef = 0, ntaps = 0;
+	std::vector<ScaleDesc> sc;
+	ScaleDesc *d_sc = nullptr;
+	double2 *d_w = nullptr, *d_wd = nullptr;
+	// work tables of the forward kernels
+	unsigned n_short = 0, n_long = 0;           // scales handled wave-per-output / block-per-output
+	std::vector<unsigned> long_scales;
+	// lazily grown device scratch
+	void *scr[SCR_N] = {nullptr};
+	size_t scr_bytes[SCR_N] = {0};
+	// cached chunk table
+	std::vector<Chunk> chunks;
+	std::vector<unsigned> row_first; // per destination row: first chunk, rows+1 entries
+	size_t ck_mtr = 0, ck_first = 0, ck_glob = 0;
+	unsigned ck_K = 0;
+	bool ck_valid = false;
+};
+
+static int scratch(tspws_hip_plan *p, int slot, size_t bytes, void **out)
+{
+	if (p->scr_bytes[slot] < bytes) {
+		if (p->scr[slot]) { (void)hipFree(p->scr[slot]); p->scr[slot] = nullptr; p->scr_bytes[slot] = 0; }
+		HIP_TRY(hipMalloc(&p->scr[slot], bytes));
+		p->scr_bytes[slot] = bytes;
+	}
+	*out = p->scr[slot];
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side parameter resolution (ts_pws1f_lib.c:91-124)
+// ------------------------------------------------------------------------------------------
+extern "C" void tspws_resolve_params(t_tsPWS *p, unsigned nsamp, float dt)
+{
+	if (p->fmin != 0 && p->fmin < 1 / (dt * nsamp)) {
+		printf("Warning: fmin is too low. Replaced by the default value.\n");
+		p->fmin = 0;
+	}
+	switch (p->w0set) {
+	case 1: p->w0 = 2 * sqrt(log(2)) * p->Q; break;
+	case 2: p->w0 = TSPWS_PI / sqrt(log(2)) * p->cycle; break;
+	}
+	if (p->type == -1 || p->type == -2) {
+		const double rel = p->w0 / (TSPWS_PI * sqrt(2 / log(2)));
+		if (!p->lVfix)  p->V  = (unsigned)ceil(4. * rel);
+		if (!p->lb0fix) p->b0 = (unsigned)pow(2, round(log2(rel)));
+		if (!p->ls0fix) p->s0 = 2.;
+	} else if (p->type == -3) {
+		p->w0 = sqrt(2);
+		if (!p->lVfix)  p->V  = 2;
+		if (!p->lb0fix) p->b0 = 0.5;
+		if (!p->ls0fix) p->s0 = 1.;
+	}
+	if (p->fmin) {
+		double top = p->w0 / (2 * TSPWS_PI * dt * p->fmin); // coarsest scale wanted
+		if (p->J) {
+			top /= pow(2, p->J - 1 / (double)p->V);           // -> finest scale
+			while (top < p->s0 * 0.9) { top *= 2; p->J--; }
+			p->s0 = top;
+		} else p->J = (unsigned)floor(log2(top / p->s0) + 1 / (double)p->V);
+	} else if (!p->J) {
+		const double a = nsamp * p->w0 / (2 * TSPWS_PI * 4. * p->s0);
+		p->J = (unsigned)floor(log2(a) + 1 / (double)p->V);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// tap generation on the device (MorletFun :38-52, Complete_MorletFun :71-87,
+// MexicanHatFun :119-131 + erfi :104-117, FillDualFrame :152-188 of FWTa/wavelet_def_v7.c)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned find_scale(const ScaleDesc *sc, unsigned S, unsigned long long idx, bool taps)
+{
+	unsigned lo = 0, hi = S; // last s with off[s] <= idx
+	while (hi - lo > 1) {
+		unsigned mid = (lo + hi) >> 1;
+		unsigned long long off = taps ? sc[mid].tap_off : sc[mid].coef_off;
+		if (off <= idx) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+
+__device__ double erfi_series(double z)
+{
+	const double zz = z * z;
+	double term = z, sum = z;
+	for (unsigned n = 1; n < 500; n++) {
+		term *= zz / n;
+		sum += term / (2 * n + 1);
+	}
+	return sum * (2 / sqrt(TSPWS_PI));
+}
+
+__global__ void __launch_bounds__(256) k_gen_taps(const ScaleDesc *__restrict__ sc, unsigned S, int type, double w0,
+                                                  unsigned long long ntaps, double2 *__restrict__ w, double2 *__restrict__ wd)
+{
+	const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= ntaps) return;
+	const unsigned s = find_scale(sc, S, t, true);
+	const ScaleDesc d = sc[s];
+	const unsigned l = (unsigned)(t - d.tap_off);
+	const int u = (int)l - (int)(d.L / 2);
+	const double inv = 1 / d.scale;
+	double re, im;
+	if (type == -3) {
+		const double k = 2 / sqrt(3 * sqrt(TSPWS_PI) * d.scale);
+		const double x = inv * u;
+		const double a = (x * x - 1) * exp(-x * x / 2);
+		re = k * a;
+		im = k * (a * erfi_series(x / sqrt(2.0)) - sqrt(2 / TSPWS_PI) * x);
+	} else {
+		const double k = 1 / sqrt(sqrt(TSPWS_PI) * d.scale);
+		double x = inv * u;
+		const double ph = w0 * x;
+		x *= x;
+		double sn, cs;
+		sincos(ph, &sn, &cs);
+		if (type == -1) {
+			const double e = exp(-0.5 * x);
+			re = (k * cs) * e;
+			im = (k * sn) * e;
+		} else {
+			const double ze = exp((-w0 * w0) / 2);
+			const double e = k * exp(-0.5 * x);
+			re = e * (cs - ze);
+			im = e * sn;
+		}
+	}
+	w[t] = make_double2(re, im);
+	wd[d.tap_off + (d.L - 1 - l)] = make_double2(re, -im); // dual = conjugate, time reversed
+}
+
+static double cpsi_host(int type, double w0)
+{
+	if (type == -3) return (4. / 3.) * sqrt(TSPWS_PI);     // MexicanHat_Cpsi, wavelet_def_v7.c:146
+	double acc = 0;                                        // Morlet_Cpsi :133-144, literal loop
+	for (double om = 0.01; om < 100; om += 0.01) {
+		double d = om - w0;
+		d *= d;
+		acc += exp(-d) / om;
+	}
+	return acc * (0.01 * sqrt(TSPWS_PI) / 2);
+}
+
+extern "C" int tspws_hip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J, unsigned V, unsigned N, double s0,
+                                     double b0, double w0, int uni, int device)
+{
+	if (!out) return fail(TSPWS_E_ARG, "plan_create: NULL plan pointer");
+	*out = nullptr;
+	if (type > -1 || type < -3) return fail(TSPWS_E_FRAME, "plan_create: only complex families -1/-2/-3");
+	if (V == 0 || J == 0 || N == 0) return fail(TSPWS_E_FRAME, "plan_create: empty frame (J, V and N must be > 0)");
+	if (tspws_hip_device_count() <= device) return fail(TSPWS_E_NODEV, "plan_create: no such HIP device");
+	HIP_TRY(hipSetDevice(device));
+
+	tspws_hip_plan *p = new (std::nothrow) tspws_hip_plan;
+	if (!p) return fail(TSPWS_E_NOMEM, "plan_create: host allocation");
+	p->device = device; p->type = type; p->V = V; p->J = J; p->N = N; p->S = J * V;
+	p->s0 = s0; p->b0 = uni ? 1.0 : b0; p->w0 = w0;
+	p->Cpsi = cpsi_host(type, w0);
+	const unsigned S = p->S;
+	p->sc.resize(S);
+	// geometry: setscales0 :299-309, setwaveletlength0 :312-322, setsampling0 :325-339
+	double scv = s0;
+	const double ratio = pow(2.0, 1.0 / (double)V);
+	for (unsigned s = 0; s < S; s++) { p->sc[s].scale = scv; scv *= ratio; }
+	double step = s0 * p->b0;
+	for (unsigned j = 0, s = 0; j < J; j++) {
+		const unsigned d = uni ? 1u : (step < 1.0 ? 1u : (unsigned)step);
+		for (unsigned v = 0; v < V; v++) p->sc[s++].D = d;
+		step *= 2.0;
+	}
+	unsigned long long toff = 0, coff = 0;
+	for (unsigned s = 0; s < S; s++) {
+		ScaleDesc &d = p->sc[s];
+		const unsigned len = 2u * (unsigned)ceil(5.0 * d.scale) + 1u; // NSIGMAS = 5
+		d.L = len > N ? N : len;
+		d.c = (int)(d.L / 2u);
+		d.cd = (int)d.L - 1 - d.c;
+		d.Ns = (N + d.D - 1u) / d.D;
+		d.tap_off = toff; d.coef_off = coff; d.pad = 0;
+		d.gain = log(2.0) / (2 * p->Cpsi * V * d.scale);
+		toff += d.L; coff += d.Ns;
+	}
+	p->ntaps = toff; p->ncoef = coff;
+
+	hipError_t e;
+	if ((e = hipMalloc(&p->d_sc, S * sizeof(ScaleDesc))) != hipSuccess ||
+	    (e = hipMalloc(&p->d_w, p->ntaps * sizeof(double2))) != hipSuccess ||
+	    (e = hipMalloc(&p->d_wd, p->ntaps * sizeof(double2))) != hipSuccess ||
+	    (e = hipMemcpy(p->d_sc, p->sc.data(), S * sizeof(ScaleDesc), hipMemcpyHostToDevice)) != hipSuccess) {
+		tspws_hip_plan_destroy(p);
+		return fail(e == hipErrorOutOfMemory ? TSPWS_E_NOMEM : TSPWS_E_HIP, "plan_create: device tables", e);
+	}
+	const unsigned nb = (unsigned)((p->ntaps + 255) / 256);
+	hipLaunchKernelGGL(k_gen_taps, dim3(nb), dim3(256), 0, 0, p->d_sc, S, type, w0, (unsigned long long)p->ntaps, p->d_w, p->d_wd);
+	if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
+		tspws_hip_plan_destroy(p);
+		return fail(e == hipErrorNoBinaryForGpu ? TSPWS_E_NODEV : TSPWS_E_HIP, "plan_create: tap kernel", e);
+	}
+	*out = p;
+	return 0;
+}
+
+extern "C" void tspws_hip_plan_destroy(tspws_hip_plan *p)
+{
+	if (!p) return;
+	(void)hipSetDevice(p->device);
+	for (int i = 0; i < SCR_N; i++) if (p->scr[i]) (void)hipFree(p->scr[i]);
+	if (p->d_sc) (void)hipFree(p->d_sc);
+	if (p->d_w) (void)hipFree(p->d_w);
+	if (p->d_wd) (void)hipFree(p->d_wd);
+	delete p;
+}
+
+extern "C" int tspws_hip_plan_info(const tspws_hip_plan *p, tspws_hip_frame_info *i)
+{
+	if (!p || !i) return fail(TSPWS_E_ARG, "plan_info: NULL");
+	i->type = p->type; i->S = p->S; i->V = p->V; i->J = p->J; i->N = p->N;
+	i->s0 = p->s0; i->b0 = p->b0; i->w0 = p->w0; i->Cpsi = p->Cpsi;
+	i->ncoef = p->ncoef; i->ntaps = p->ntaps; i->device = p->device;
+	return 0;
+}
+
+extern "C" int tspws_hip_plan_tables(const tspws_hip_plan *p, double *scale, unsigned *L, int *c, int *cd, unsigned *D, unsigned *Ns)
+{
+	if (!p) return fail(TSPWS_E_ARG, "plan_tables: NULL");
+	for (unsigned s = 0; s < p->S; s++) {
+		if (scale) scale[s] = p->sc[s].scale;
+		if (L) L[s] = p->sc[s].L;
+		if (c) c[s] = p->sc[s].c;
+		if (cd) cd[s] = p->sc[s].cd;
+		if (D) D[s] = p->sc[s].D;
+		if (Ns) Ns[s] = p->sc[s].Ns;
+	}
+	return 0;
+}
+
+extern "C" int tspws_hip_plan_taps(const tspws_hip_plan *p, double *h_w, double *h_wd)
+{
+	if (!p) return fail(TSPWS_E_ARG, "plan_taps: NULL");
+	HIP_TRY(hipSetDevice(p->device));
+	if (h_w) HIP_TRY(hipMemcpy(h_w, p->d_w, p->ntaps * sizeof(double2), hipMemcpyDeviceToHost));
+	if (h_wd) HIP_TRY(hipMemcpy(h_wd, p->d_wd, p->ntaps * sizeof(double2), hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// runtime helpers
+// ------------------------------------------------------------------------------------------
+extern "C" int tspws_hip_alloc(void **d, size_t bytes, int device)
+{
+	if (!d) return fail(TSPWS_E_ARG, "alloc: NULL");
+	*d = nullptr;
+	if (tspws_hip_device_count() <= device) return fail(TSPWS_E_NODEV, "alloc: no such HIP device");
+	HIP_TRY(hipSetDevice(device));
+	HIP_TRY(hipMalloc(d, bytes ? bytes : 1));
+	return 0;
+}
+extern "C" int tspws_hip_free(void *d) { if (d) HIP_TRY(hipFree(d)); return 0; }
+extern "C" int tspws_hip_upload(void *d, const void *h, size_t bytes, void *s)
+{
+	HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, S_(s)));
+	HIP_TRY(hipStreamSynchronize(S_(s)));
+	return 0;
+}
+extern "C" int tspws_hip_download(void *h, const void *d, size_t bytes, void *s)
+{
+	HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, S_(s)));
+	HIP_TRY(hipStreamSynchronize(S_(s)));
+	return 0;
+}
+extern "C" int tspws_hip_zero(void *d, size_t bytes, void *s) { HIP_TRY(hipMemsetAsync(d, 0, bytes, S_(s))); return 0; }
+extern "C" int tspws_hip_sync(void *s) { HIP_TRY(hipStreamSynchronize(S_(s))); return 0; }
+
+// ------------------------------------------------------------------------------------------
+// wave / block reductions (wave = 64 lanes)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+	return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// prologue kernels
+// ------------------------------------------------------------------------------------------
+// fold, ts_pws1f_lib.c:76-86.  grid.y = trace
+__global__ void __launch_bounds__(256) k_fold(float *__restrict__ x, size_t max, size_t ld)
+{
+	float *row = x + (size_t)blockIdx.y * ld;
+	const size_t half = max / 2;
+	for (size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x; n < half; n += (size_t)gridDim.x * blockDim.x) {
+		float v = row[n];
+		v += row[max - 1 - n];
+		v *= 0.5f;
+		row[max - 1 - n] = v;
+		row[n] = v;
+	}
+}
+
+// mean removal, ts_pws1f_lib.c:159-169: FP64 sum, mean rounded to float, float subtraction.
+// One workgroup per trace (the trace is re-read from L2 for the subtraction).
+__global__ void __launch_bounds__(1024) k_remove_mean(float *__restrict__ x, size_t max, size_t ld)
+{
+	__shared__ double part[16];
+	__shared__ float meanf;
+	float *row = x + (size_t)blockIdx.x * ld;
+	double acc = 0;
+	for (size_t n = threadIdx.x; n < max; n += blockDim.x) acc += (double)row[n];
+	acc = wave_sum(acc);
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double t = 0;
+		for (unsigned i = 0; i < blockDim.x / 64; i++) t += part[i];
+		meanf = (float)(t / (double)max);
+	}
+	__syncthreads();
+	const float m = meanf;
+	for (size_t n = threadIdx.x; n < max; n += blockDim.x) row[n] -= m;
+}
+
+extern "C" int tspws_hip_fold(float *d_x, size_t mtr, size_t max, size_t ld, void *s)
+{
+	if (!d_x) return fail(TSPWS_E_ARG, "fold: NULL");
+	if (!mtr || max < 2) return 0;
+	const unsigned bx = (unsigned)std::min<size_t>((max / 2 + 255) / 256, 64);
+	for (size_t t0 = 0; t0 < mtr; t0 += 65535) {
+		const unsigned ny = (unsigned)std::min<size_t>(mtr - t0, 65535);
+		hipLaunchKernelGGL(k_fold, dim3(bx, ny), dim3(256), 0, S_(s), d_x + t0 * ld, max, ld);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+extern "C" int tspws_hip_remove_mean(float *d_x, size_t mtr, size_t max, size_t ld, void *s)
+{
+	if (!d_x) return fail(TSPWS_E_ARG, "remove_mean: NULL");
+	if (!mtr || !max) return 0;
+	for (size_t t0 = 0; t0 < mtr; t0 += (1u << 30)) {
+		const unsigned nb = (unsigned)std::min<size_t>(mtr - t0, 1u << 30);
+		hipLaunchKernelGGL(k_remove_mean, dim3(nb), dim3(1024), 0, S_(s), d_x + t0 * ld, max, ld);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 1: partial linear stacks (the HBM-streaming kernel)
+//
+// Work item = (column block, chunk): a chunk is a run of consecutive traces that all add into
+// the same destination row.  Every thread owns 4 consecutive samples, walks the chunk's traces
+// with independent 16-byte non-temporal loads (8 in flight), accumulates in FP64 and writes one
+// partial row per chunk; k_reduce_chunks then adds the few chunk rows of each destination in a
+// fixed order, so the result is deterministic (no atomics).
+// Algorithmic bytes: 4 per input sample (+ 8 per output sample).
+// ------------------------------------------------------------------------------------------
+template <bool VEC4>
+__global__ void __launch_bounds__(256) k_partial(const float *__restrict__ x, size_t ld, size_t N,
+                                                 const Chunk *__restrict__ chunks, double *__restrict__ pc, size_t ldpc)
+{
+	const Chunk ck = chunks[blockIdx.y];
+	const size_t col = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+	if (col >= N) return;
+	const float *src = x + ck.t0 * ld + col;
+	double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+	if (VEC4) {
+		typedef float v4f __attribute__((ext_vector_type(4)));
+		unsigned t = 0;
+		for (; t + 8 <= ck.count; t += 8) {
+			v4f v[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)(t + j) * ld));
+#pragma unroll
+			for (int j = 0; j < 8; j++) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
+		}
+		for (; t < ck.count; t++) {
+			const v4f v = __builtin_nontemporal_load((const v4f *)(src + (size_t)t * ld));
+			a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+		}
+	} else {
+		const unsigned rem = (N - col) < 4 ? (unsigned)(N - col) : 4u;
+		for (unsigned t = 0; t < ck.count; t++) {
+			const float *r = src + (size_t)t * ld;
+			a0 += (double)r[0];
+			if (rem > 1) a1 += (double)r[1];
+			if (rem > 2) a2 += (double)r[2];
+			if (rem > 3) a3 += (double)r[3];
+		}
+	}
+	double *dst = pc + (size_t)blockIdx.y * ldpc + col;
+	if (VEC4) {
+		*(double2 *)dst = make_double2(a0, a1);
+		*(double2 *)(dst + 2) = make_double2(a2, a3);
+	} else {
+		const unsigned rem = (N - col) < 4 ? (unsigned)(N - col) : 4u;
+		dst[0] = a0;
+		if (rem > 1) dst[1] = a1;
+		if (rem > 2) dst[2] = a2;
+		if (rem > 3) dst[3] = a3;
+	}
+}
+
+// P[row][n] = sum over the row's chunks (in chunk order); rows without chunks become 0.
+__global__ void __launch_bounds__(256) k_reduce_chunks(const double *__restrict__ pc, size_t ldpc, const unsigned *__restrict__ row_first,
+                                                       double *__restrict__ P, size_t ldP, size_t N)
+{
+	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (n >= N) return;
+	const unsigned row = blockIdx.y;
+	double acc = 0;
+	for (unsigned c = row_first[row]; c < row_first[row + 1]; c++) acc += pc[(size_t)c * ldpc + n];
+	P[(size_t)row * ldP + n] = acc;
+}
+
+// Launch the streaming pass for an arbitrary chunk table (rows destinations).
+static int run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, const std::vector<Chunk> &chunks,
+                      const std::vector<unsigned> &row_first, unsigned rows, double *d_P, size_t ldP, hipStream_t st, bool upload)
+{
+	const size_t nck = chunks.size();
+	const size_t ldpc = (N + 3) & ~(size_t)3;
+	void *d_tab = nullptr, *d_pc = nullptr;
+	const size_t tab_bytes = nck * sizeof(Chunk) + (rows + 1) * sizeof(unsigned);
+	int rc;
+	if ((rc = scratch(p, SCR_TAB, std::max<size_t>(tab_bytes, 16), &d_tab))) return rc;
+	if ((rc = scratch(p, SCR_CHUNK, std::max<size_t>(nck * ldpc * sizeof(double), 16), &d_pc))) return rc;
+	Chunk *d_chunks = (Chunk *)d_tab;
+	unsigned *d_rf = (unsigned *)((char *)d_tab + nck * sizeof(Chunk));
+	if (upload) {
+		if (nck) HIP_TRY(hipMemcpyAsync(d_chunks, chunks.data(), nck * sizeof(Chunk), hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(d_rf, row_first.data(), (rows + 1) * sizeof(unsigned), hipMemcpyHostToDevice, st));
+	}
+	const unsigned bx = (unsigned)((N + 1023) / 1024);
+	const bool vec = (N % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x & 15) == 0);
+	for (size_t c0 = 0; c0 < nck; c0 += 65535) {
+		const unsigned ny = (unsigned)std::min<size_t>(nck - c0, 65535);
+		if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, (double *)d_pc + c0 * ldpc, ldpc);
+		else hipLaunchKernelGGL(k_partial<false>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, (double *)d_pc + c0 * ldpc, ldpc);
+	}
+	for (unsigned r0 = 0; r0 < rows; r0 += 65535) {
+		const unsigned ny = std::min(rows - r0, 65535u);
+		hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((N + 255) / 256), ny), dim3(256), 0, st, (const double *)d_pc, ldpc,
+		                   d_rf + r0, d_P + (size_t)r0 * ldP, ldP, N);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// target number of workgroups in flight for the streaming pass: 256 CUs x 8
+static unsigned chunk_len_for(size_t N, size_t mtr)
+{
+	const size_t colblocks = (N + 1023) / 1024;
+	const size_t want = std::max<size_t>(1, 4096 / std::max<size_t>(colblocks, 1));
+	size_t len = (mtr + want - 1) / want;
+	len = std::max<size_t>(len, 8);
+	return (unsigned)std::min<size_t>(len, 1u << 20);
+}
+
+extern "C" int tspws_hip_partial_stacks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t mtr_local, size_t first,
+                                        size_t mtr_global, unsigned Kmax, double *d_P, size_t ldP, void *stream)
+{
+	if (!p || !d_x || !d_P || !Kmax || !mtr_global) return fail(TSPWS_E_ARG, "partial_stacks: bad argument");
+	HIP_TRY(hipSetDevice(p->device));
+	const size_t N = p->N;
+	bool upload = false;
+	if (!p->ck_valid || p->ck_mtr != mtr_local || p->ck_first != first || p->ck_glob != mtr_global || p->ck_K != Kmax) {
+		// group of global trace i: floor(i*Kmax/mtr_global)   (ts_pws1f_lib.c:876)
+		p->chunks.clear();
+		p->row_first.assign(Kmax + 1, 0);
+		const unsigned clen = chunk_len_for(N, mtr_local);
+		std::vector<std::vector<Chunk>> per(Kmax);
+		size_t i = 0;
+		while (i < mtr_local) {
+			const size_t g = (size_t)floor((double)((first + i) * (size_t)Kmax) / (double)mtr_global);
+			size_t j = i + 1;
+			while (j < mtr_local && (size_t)floor((double)((first + j) * (size_t)Kmax) / (double)mtr_global) == g) j++;
+			for (size_t t = i; t < j; t += clen) {
+				Chunk c; c.t0 = t; c.count = (unsigned)std::min<size_t>(clen, j - t); c.row = (unsigned)g;
+				per[std::min<size_t>(g, Kmax - 1)].push_back(c);
+			}
+			i = j;
+		}
+		for (unsigned g = 0; g < Kmax; g++) {
+			p->row_first[g] = (unsigned)p->chunks.size();
+			p->chunks.insert(p->chunks.end(), per[g].begin(), per[g].end());
+		}
+		p->row_first[Kmax] = (unsigned)p->chunks.size();
+		p->ck_mtr = mtr_local; p->ck_first = first; p->ck_glob = mtr_global; p->ck_K = Kmax; p->ck_valid = true;
+		upload = true;
+	}
+	return run_chunks(p, d_x, ld, N, p->chunks, p->row_first, Kmax, d_P, ldP, S_(stream), upload);
+}
+
+// ------------------------------------------------------------------------------------------
+// forward frame CWT, generic form (any D, any L <= N):
+//   Y_s[k] = conj( sum_l x[(k D - c + l) mod N] w_s[l] )          cdotx.c:44-70
+// Lanes run along the taps (coalesced x and tap reads), partial sums are combined with
+// wave shuffles.  WAVE_PER_OUT: one wave per coefficient; otherwise one 256-thread block.
+// ------------------------------------------------------------------------------------------
+template <typename TIn, bool BLOCK_PER_OUT>
+__global__ void __launch_bounds__(256) k_fwd_generic(const TIn *__restrict__ x, size_t ld, unsigned N, const ScaleDesc *__restrict__ sc,
+                                                     unsigned S, const double2 *__restrict__ w, double2 *__restrict__ Y, size_t ncoef,
+                                                     unsigned long long first_coef, unsigned long long n_items)
+{
+	__shared__ double red[8];
+	const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	unsigned long long item = BLOCK_PER_OUT ? blockIdx.x : (unsigned long long)blockIdx.x * 4 + wv;
+	if (item >= n_items) return;
+	const unsigned long long ci = first_coef + item;
+	const unsigned s = find_scale(sc, S, ci, false);
+	const ScaleDesc d = sc[s];
+	const unsigned k = (unsigned)(ci - d.coef_off);
+	const TIn *xr = x + (size_t)blockIdx.y * ld;
+	const double2 *ws = w + d.tap_off;
+	long long n0 = (long long)k * d.D - d.c;
+	if (n0 < 0) n0 += N;
+	double re = 0, im = 0;
+	const unsigned stride = BLOCK_PER_OUT ? 256 : 64;
+	for (unsigned l = BLOCK_PER_OUT ? threadIdx.x : lane; l < d.L; l += stride) {
+		unsigned long long idx = (unsigned long long)n0 + l;
+		if (idx >= N) idx -= N;
+		const double xv = (double)xr[idx];
+		const double2 t = ws[l];
+		re = fma(xv, t.x, re);
+		im = fma(xv, t.y, im);
+	}
+	re = wave_sum(re);
+	im = wave_sum(im);
+	double2 *out = Y + (size_t)blockIdx.y * ncoef + ci;
+	if (BLOCK_PER_OUT) {
+		if (lane == 0) { red[wv * 2] = re; red[wv * 2 + 1] = im; }
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			re = red[0] + red[2] + red[4] + red[6];
+			im = red[1] + red[3] + red[5] + red[7];
+			*out = make_double2(re, -im);
+		}
+	} else if (lane == 0) *out = make_double2(re, -im);
+}
+
+template <typename TIn>
+static int forward_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_Y, hipStream_t st)
+{
+	if (!p || !d_x || !d_Y) return fail(TSPWS_E_ARG, "forward: NULL");
+	if (!ntr) return 0;
+	HIP_TRY(hipSetDevice(p->device));
+	// scales are ordered by growing L: coefficients of scales with L > 2048 go block-per-output
+	unsigned s_long = p->S;
+	for (unsigned s = 0; s < p->S; s++) if (p->sc[s].L > 2048) { s_long = s; break; }
+	const unsigned long long n_short = s_long < p->S ? p->sc[s_long].coef_off : p->ncoef;
+	const unsigned long long n_long = p->ncoef - n_short;
+	for (size_t t0 = 0; t0 < ntr; t0 += 65535) {
+		const unsigned ny = (unsigned)std::min<size_t>(ntr - t0, 65535);
+		const TIn *xx = d_x + t0 * ld;
+		double2 *yy = (double2 *)d_Y + t0 * p->ncoef;
+		if (n_long)
+			hipLaunchKernelGGL((k_fwd_generic<TIn, true>), dim3((unsigned)n_long, ny), dim3(256), 0, st, xx, ld, p->N, p->d_sc, p->S,
+			                   p->d_w, yy, p->ncoef, n_short, n_long);
+		if (n_short)
+			hipLaunchKernelGGL((k_fwd_generic<TIn, false>), dim3((unsigned)((n_short + 3) / 4), ny), dim3(256), 0, st, xx, ld, p->N,
+			                   p->d_sc, p->S, p->d_w, yy, p->ncoef, 0ull, n_short);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+extern "C" int tspws_hip_forward_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, size_t ld, double *d_Y, void *s)
+{
+	return forward_impl<double>(p, d_x, ntr, ld, d_Y, S_(s));
+}
+extern "C" int tspws_hip_forward_f32(tspws_hip_plan *p, const float *d_x, size_t ntr, size_t ld, double *d_Y, void *s)
+{
+	return forward_impl<float>(p, d_x, ntr, ld, d_Y, S_(s));
+}
+
+// ------------------------------------------------------------------------------------------
+// stack accumulation: ST += Y, PS += Y/|Y| unless the quotient is not a unit phasor
+// (ts_pws1f_lib.c:489-492).  One thread per coefficient, traces walked in order.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_accumulate(const double2 *__restrict__ Y, size_t ncoef, unsigned ntr, double2 *__restrict__ ST,
+                                                    double2 *__restrict__ PS, int zero_first)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= ncoef) return;
+	double2 st = zero_first ? make_double2(0, 0) : ST[i];
+	double2 ps = zero_first ? make_double2(0, 0) : PS[i];
+	for (unsigned b = 0; b < ntr; b++) {
+		const double2 v = Y[(size_t)b * ncoef + i];
+		st.x += v.x; st.y += v.y;
+		const double r = hypot(v.x, v.y);
+		const double ux = v.x / r, uy = v.y / r;
+		if (ux * ux + uy * uy <= 1.001) { ps.x += ux; ps.y += uy; }
+	}
+	ST[i] = st; PS[i] = ps;
+}
+
+extern "C" int tspws_hip_accumulate(tspws_hip_plan *p, const double *d_Y, size_t ntr, double *d_ST, double *d_PS, int zero_first, void *s)
+{
+	if (!p || !d_ST || !d_PS || (ntr && !d_Y)) return fail(TSPWS_E_ARG, "accumulate: NULL");
+	HIP_TRY(hipSetDevice(p->device));
+	hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((p->ncoef + 255) / 256)), dim3(256), 0, S_(s), (const double2 *)d_Y, p->ncoef,
+	                   (unsigned)ntr, (double2 *)d_ST, (double2 *)d_PS, zero_first);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+extern "C" int tspws_hip_stacks_double(tspws_hip_plan *p, const double *d_P, unsigned K, size_t ldP, double *d_ST, double *d_PS, void *s)
+{
+	if (!p || !d_P || !d_ST || !d_PS) return fail(TSPWS_E_ARG, "stacks_double: NULL");
+	HIP_TRY(hipSetDevice(p->device));
+	void *d_Y = nullptr;
+	const unsigned batch = 16;
+	int rc = scratch(p, SCR_Y, (size_t)std::min(K, batch) * p->ncoef * sizeof(double2), &d_Y);
+	if (rc) return rc;
+	if (!K) { HIP_TRY(hipMemsetAsync(d_ST, 0, p->ncoef * 16, S_(s))); HIP_TRY(hipMemsetAsync(d_PS, 0, p->ncoef * 16, S_(s))); }
+	for (unsigned k0 = 0; k0 < K; k0 += batch) {
+		const unsigned nb = std::min(batch, K - k0);
+		if ((rc = tspws_hip_forward_f64(p, d_P + (size_t)k0 * ldP, nb, ldP, (double *)d_Y, s))) return rc;
+		if ((rc = tspws_hip_accumulate(p, (const double *)d_Y, nb, d_ST, d_PS, k0 == 0, s))) return rc;
+	}
+	return 0;
+}
+
+extern "C" int tspws_hip_stacks_float(tspws_hip_plan *p, const float *d_x, size_t mtr, size_t ld, double *d_ST, double *d_PS, void *s)
+{
+	if (!p || !d_x || !d_ST || !d_PS) return fail(TSPWS_E_ARG, "stacks_float: NULL");
+	HIP_TRY(hipSetDevice(p->device));
+	// trace batch sized to keep the coefficient scratch around 512 MiB
+	size_t batch = std::max<size_t>(1, ((size_t)512 << 20) / (p->ncoef * sizeof(double2)));
+	batch = std::min<size_t>(batch, std::max<size_t>(mtr, 1));
+	void *d_Y = nullptr;
+	int rc = scratch(p, SCR_Y, batch * p->ncoef * sizeof(double2), &d_Y);
+	if (rc) return rc;
+	if (!mtr) { HIP_TRY(hipMemsetAsync(d_ST, 0, p->ncoef * 16, S_(s))); HIP_TRY(hipMemsetAsync(d_PS, 0, p->ncoef * 16, S_(s))); }
+	for (size_t t0 = 0; t0 < mtr; t0 += batch) {
+		const size_t nb = std::min(batch, mtr - t0);
+		if ((rc = tspws_hip_forward_f32(p, d_x + t0 * ld, nb, ld, (double *)d_Y, s))) return rc;
+		if ((rc = tspws_hip_accumulate(p, (const double *)d_Y, nb, d_ST, d_PS, t0 == 0, s))) return rc;
+	}
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// phase weighting (tspws_biased :909-943, tspws_unbiased :965-984)
+// mode 0: wu==2 biased, 1: wu==1, 2: general power, 3: unbiased (K>1)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_weight(double2 *__restrict__ OUT, const double2 *__restrict__ ST, const double2 *__restrict__ PS,
+                                                size_t ncoef, int mode, double K, double M, double wu)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= ncoef) return;
+	const double2 st = ST[i], ps = PS[i];
+	double a;
+	if (mode == 0) {
+		const double g = 1. / (K * K * M);
+		a = (ps.x * ps.x + ps.y * ps.y) * g;
+		OUT[i] = make_double2(a * st.x, a * st.y);
+	} else if (mode == 1) {
+		const double g = 1. / (K * M);
+		const double r = hypot(ps.x, ps.y);
+		OUT[i] = make_double2(st.x * r * g, st.y * r * g);
+	} else if (mode == 2) {
+		a = hypot(ps.x, ps.y) / K;
+		a = pow(a, wu);
+		OUT[i] = make_double2(st.x * a / M, st.y * a / M);
+	} else {
+		const double iK = 1. / K, iK1 = 1. / (K - 1), iM = 1. / M;
+		const double px = ps.x * iK, py = ps.y * iK;
+		a = px * px + py * py;
+		a = (K * a - 1) * iK1;
+		OUT[i] = make_double2(st.x * a * iM, st.y * a * iM);
+	}
+}
+
+extern "C" int tspws_hip_weight(tspws_hip_plan *p, double *d_OUT, const double *d_ST, const double *d_PS, unsigned K, unsigned M,
+                                double wu, int unbiased, void *s)
+{
+	if (!p || !d_OUT || !d_ST || !d_PS) return fail(TSPWS_E_ARG, "weight: NULL");
+	HIP_TRY(hipSetDevice(p->device));
+	int mode;
+	if (wu == 2 && unbiased && K != 1) mode = 3;      // selection rule ts_pws1f_lib.c:226-228, K==1 falls back :972
+	else if (wu == 2) mode = 0;
+	else if (wu == 1) mode = 1;
+	else mode = 2;
+	hipLaunchKernelGGL(k_weight, dim3((unsigned)((p->ncoef + 255) / 256)), dim3(256), 0, S_(s), (double2 *)d_OUT, (const double2 *)d_ST,
+	                   (const double2 *)d_PS, p->ncoef, mode, (double)K, (double)M, wu);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// inverse frame transform, real part (gather form), generic:
+//   x^[n] = sum_s gain_s * D_s * sum_{l: (n - cd + l) on the decimation grid} Re(conj(wd_s[l]) Y_s[.])
+// with the grid restarting at the circular seam (cdotx.c:313-337); D==1 -> cdotx.c:176-211.
+// One thread per output sample; NREC coefficient sets share the tap reads.
+// ------------------------------------------------------------------------------------------
+template <int NREC>
+__global__ void __launch_bounds__(256) k_inverse_generic(const double2 *__restrict__ Y, size_t ncoef, unsigned N, const ScaleDesc *__restrict__ sc,
+                                                         unsigned S, const double2 *__restrict__ wd, double *__restrict__ xout)
+{
+	const unsigned n = blockIdx.x * 256 + threadIdx.x;
+	if (n >= N) return;
+	double tot[NREC];
+#pragma unroll
+	for (int r = 0; r < NREC; r++) tot[r] = 0;
+	for (unsigned s = 0; s < S; s++) {
+		const ScaleDesc d = sc[s];
+		const double2 *ws = wd + d.tap_off;
+		const double2 *ys = Y + d.coef_off;
+		long long n0 = (long long)n - d.cd;
+		if (n0 < 0) n0 += N;
+		const unsigned l0 = N - (unsigned)n0; // taps before the seam
+		const unsigned lim = d.L < l0 ? d.L : l0;
+		double acc[NREC];
+#pragma unroll
+		for (int r = 0; r < NREC; r++) acc[r] = 0;
+		if (d.D > 1) {
+			const unsigned D = d.D;
+			unsigned l = (D - (unsigned)(n0 % D)) % D;
+			unsigned q = (unsigned)((n0 + D - 1) / D);
+			for (; l < lim; l += D, q++) {
+				const double2 t = ws[l];
+#pragma unroll
+				for (int r = 0; r < NREC; r++) {
+					const double2 y = ys[(size_t)r * ncoef + q];
+					acc[r] = fma(t.x, y.x, fma(t.y, y.y, acc[r]));
+				}
+			}
+			q = 0;
+			for (l = l0; l < d.L; l += D, q++) {
+				const double2 t = ws[l];
+#pragma unroll
+				for (int r = 0; r < NREC; r++) {
+					const double2 y = ys[(size_t)r * ncoef + q];
+					acc[r] = fma(t.x, y.x, fma(t.y, y.y, acc[r]));
+				}
+			}
+#pragma unroll
+			for (int r = 0; r < NREC; r++) tot[r] += d.gain * ((double)D * acc[r]);
+		} else {
+			for (unsigned l = 0; l < lim; l++) {
+				const double2 t = ws[l];
+#pragma unroll
+				for (int r = 0; r < NREC; r++) {
+					const double2 y = ys[(size_t)r * ncoef + (unsigned)n0 + l];
+					acc[r] = fma(t.x, y.x, fma(t.y, y.y, acc[r]));
+				}
+			}
+			for (unsigned l = lim; l < d.L; l++) {
+				const double2 t = ws[l];
+#pragma unroll
+				for (int r = 0; r < NREC; r++) {
+					const double2 y = ys[(size_t)r * ncoef + (l - l0)];
+					acc[r] = fma(t.x, y.x, fma(t.y, y.y, acc[r]));
+				}
+			}
+#pragma unroll
+			for (int r = 0; r < NREC; r++) tot[r] += d.gain * acc[r];
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < NREC; r++) xout[(size_t)r * N + n] = tot[r];
+}
+
+extern "C" int tspws_hip_inverse(tspws_hip_plan *p, const double *d_Y, size_t nrec, double *d_x, void *s)
+{
+	if (!p || !d_Y || !d_x) return fail(TSPWS_E_ARG, "inverse: NULL");
+	HIP_TRY(hipSetDevice(p->device));
+	const unsigned nb = (p->N + 255) / 256;
+	size_t r = 0;
+	for (; r + 2 <= nrec; r += 2)
+		hipLaunchKernelGGL(k_inverse_generic<2>, dim3(nb), dim3(256), 0, S_(s), (const double2 *)d_Y + r * p->ncoef, p->ncoef, p->N, p->d_sc,
+		                   p->S, p->d_wd, d_x + r * p->N);
+	if (r < nrec)
+		hipLaunchKernelGGL(k_inverse_generic<1>, dim3(nb), dim3(256), 0, S_(s), (const double2 *)d_Y + r * p->ncoef, p->ncoef, p->N, p->d_sc,
+		                   p->S, p->d_wd, d_x + r * p->N);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// epilogue, ts_pws1f_lib.c:233-241 (ls is a FLOAT division by the converted trace count)
+__global__ void __launch_bounds__(256) k_epilogue(float *__restrict__ ls, float *__restrict__ ts, const double *__restrict__ xst,
+                                                  const double *__restrict__ xout, size_t N, float mtr)
+{
+	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (n >= N) return;
+	if (ls) ls[n] = (float)xst[n] / mtr;
+	if (ts) ts[n] = (float)xout[n];
+}
+
+extern "C" int tspws_hip_epilogue(float *d_ls, float *d_ts, const double *d_xst, const double *d_xout, size_t N, unsigned mtr, void *s)
+{
+	if ((d_ls && !d_xst) || (d_ts && !d_xout)) return fail(TSPWS_E_ARG, "epilogue: NULL");
+	hipLaunchKernelGGL(k_epilogue, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, S_(s), d_ls, d_ts, d_xst, d_xout, N, (float)mtr);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// whole call on device-resident traces
+// ------------------------------------------------------------------------------------------
+static bool is_two_stage(const t_tsPWS *p, size_t mtr_global) { return !(!p->Kmax || p->Kmax > mtr_global); }
+
+extern "C" int tspws_hip_reduce_buffer(tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, double **d_buf, size_t *nd)
+{
+	if (!pl || !p || !d_buf || !nd) return fail(TSPWS_E_ARG, "reduce_buffer: NULL");
+	HIP_TRY(hipSetDevice(pl->device));
+	void *b = nullptr;
+	int rc;
+	if (is_two_stage(p, mtr_global)) {
+		*nd = (size_t)p->Kmax * pl->N;
+		if ((rc = scratch(pl, SCR_P, *nd * sizeof(double), &b))) return rc;
+	} else {
+		*nd = 4 * pl->ncoef;
+		if ((rc = scratch(pl, SCR_STPS, *nd * sizeof(double), &b))) return rc;
+	}
+	*d_buf = (double *)b;
+	return 0;
+}
+
+extern "C" int tspws_hip_stack_local(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr_local, size_t first,
+                                     size_t mtr_global, void *s)
+{
+	if (!pl || !p || (!d_x && mtr_local)) return fail(TSPWS_E_ARG, "stack_local: NULL");
+	double *buf; size_t nd; int rc;
+	if ((rc = tspws_hip_reduce_buffer(pl, p, mtr_global, &buf, &nd))) return rc;
+	if (is_two_stage(p, mtr_global)) {
+		if (!mtr_local) { HIP_TRY(hipMemsetAsync(buf, 0, nd * sizeof(double), S_(s))); return 0; }
+		return tspws_hip_partial_stacks(pl, d_x, ld, mtr_local, first, mtr_global, p->Kmax, buf, pl->N, s);
+	}
+	if (!mtr_local) { HIP_TRY(hipMemsetAsync(buf, 0, nd * sizeof(double), S_(s))); return 0; }
+	return tspws_hip_stacks_float(pl, d_x, mtr_local, ld, buf, buf + 2 * pl->ncoef, s);
+}
+
+extern "C" int tspws_hip_stack_finish(tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, float *d_ls, float *d_ts, void *s)
+{
+	if (!pl || !p) return fail(TSPWS_E_ARG, "stack_finish: NULL");
+	HIP_TRY(hipSetDevice(pl->device));
+	int rc;
+	void *v;
+	const size_t nc = pl->ncoef;
+	// coefficient block: [OUT | ST | PS] so that the two inverses read rows 0 and 1
+	if ((rc = scratch(pl, SCR_OUT, 6 * nc * sizeof(double), &v))) return rc;
+	double *OUT = (double *)v, *ST = OUT + 2 * nc, *PS = ST + 2 * nc;
+	unsigned K;
+	if (is_two_stage(p, mtr_global)) {
+		double *P; size_t nd;
+		if ((rc = tspws_hip_reduce_buffer(pl, p, mtr_global, &P, &nd))) return rc;
+		K = p->Kmax;
+		if ((rc = tspws_hip_stacks_double(pl, P, K, pl->N, ST, PS, s))) return rc;
+	} else {
+		double *B; size_t nd;
+		if ((rc = tspws_hip_reduce_buffer(pl, p, mtr_global, &B, &nd))) return rc;
+		K = (unsigned)mtr_global;
+		HIP_TRY(hipMemcpyAsync(ST, B, 4 * nc * sizeof(double), hipMemcpyDeviceToDevice, S_(s)));
+	}
+	if ((rc = tspws_hip_weight(pl, OUT, ST, PS, K, (unsigned)mtr_global, p->wu, p->unbiased, s))) return rc;
+	if ((rc = scratch(pl, SCR_X2, 2 * (size_t)pl->N * sizeof(double), &v))) return rc;
+	double *x2 = (double *)v;
+	if ((rc = tspws_hip_inverse(pl, OUT, 2, x2, s))) return rc; // row 0 = ICWT(OUT), row 1 = ICWT(ST)
+	return tspws_hip_epilogue(d_ls, d_ts, x2 + pl->N, x2, pl->N, (unsigned)mtr_global, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// jackknife (TwoStage_jackknife_float, ts_pws1f_lib.c:719-831)
+// ------------------------------------------------------------------------------------------
+extern "C" int tspws_jackknife_plan(char *sel, const time_t *tm, size_t mtr, unsigned d, unsigned n, unsigned C)
+{
+	if (!sel || !tm) return 1;
+	if (tm[0] == 0) return -2;
+	std::vector<unsigned> bin(mtr), comb(d);
+	for (size_t i = 0; i < mtr; i++) {
+		struct tm g;
+		gmtime_r(tm + i, &g);
+		bin[i] = (unsigned)floor((double)(g.tm_yday * (int)n) / 365.); // day-of-year bin, :398-401
+	}
+	for (unsigned i = 0; i < d; i++) comb[i] = i;
+	for (unsigned c = 0; c < C; c++) {
+		if (c) { // lexicographic successor of the deleted-bin set, :405-414
+			int i = (int)d - 1;
+			while (i >= 0 && comb[i] >= n - d + (unsigned)i) i--;
+			if (i < 0) break;
+			comb[i]++;
+			for (unsigned j = (unsigned)i + 1; j < d; j++) comb[j] = comb[j - 1] + 1;
+		}
+		char *row = sel + (size_t)c * mtr;
+		for (size_t t = 0; t < mtr; t++) {
+			row[t] = 1;
+			for (unsigned i = 0; i < d; i++) if (bin[t] == comb[i]) row[t] = 0;
+		}
+	}
+	return 0;
+}
+
+// P_c[g][n] = sum of class sums whose signature sends them to group g of replica c.
+// cls_of[(c*Kmax+g)] lists are given as CSR: row_ptr / cols.
+__global__ void __launch_bounds__(256) k_combine_classes(const double *__restrict__ cls, size_t ldc, const unsigned *__restrict__ row_ptr,
+                                                         const unsigned *__restrict__ cols, double *__restrict__ P, size_t N)
+{
+	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (n >= N) return;
+	const unsigned row = blockIdx.y;
+	double acc = 0;
+	for (unsigned j = row_ptr[row]; j < row_ptr[row + 1]; j++) acc += cls[(size_t)cols[j] * ldc + n];
+	P[(size_t)row * N + n] = acc;
+}
+
+// replica linear stack in the time domain, :799-811: (sum_g P[g]) * (1/K)
+__global__ void __launch_bounds__(256) k_jk_linear(const double *__restrict__ P, unsigned Kmax, size_t N, double invK, float *__restrict__ out)
+{
+	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (n >= N) return;
+	double acc = P[n];
+	for (unsigned g = 1; g < Kmax; g++) acc += P[(size_t)g * N + n];
+	out[n] = (float)(acc * invK);
+}
+
+extern "C" int tspws_hip_jackknife(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, const char *h_sel,
+                                   unsigned C, float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s)
+{
+	if (!pl || !p || !d_x || !h_sel || !d_ls_out || !d_ts_out || !h_mtr_out) return fail(TSPWS_E_ARG, "jackknife: NULL");
+	if (!is_two_stage(p, mtr) || !C) return 0; // single-stage variant is an empty stub in the reference (:711-716)
+	HIP_TRY(hipSetDevice(pl->device));
+	hipStream_t st = S_(s);
+	const unsigned KM = p->Kmax;
+	const size_t N = pl->N;
+	// signature of trace i: group index in every replica (0xFFFF = deleted)
+	std::vector<size_t> Kc(C, 0);
+	for (unsigned c = 0; c < C; c++) for (size_t i = 0; i < mtr; i++) if (h_sel[(size_t)c * mtr + i] == 1) Kc[c]++;
+	std::vector<unsigned short> sig((size_t)mtr * C);
+	for (unsigned c = 0; c < C; c++) {
+		size_t k = 0;
+		for (size_t i = 0; i < mtr; i++) {
+			if (h_sel[(size_t)c * mtr + i] == 1) {
+				sig[i * C + c] = (unsigned short)floor((double)(k * KM) / (double)Kc[c]); // :766
+				k++;
+			} else sig[i * C + c] = 0xFFFF;
+		}
+	}
+	// classes = maximal runs of consecutive traces with identical signature; identical signatures
+	// of separate runs are merged into one class.
+	std::vector<Chunk> chunks;
+	std::vector<std::vector<unsigned short>> cls_sig;
+	std::vector<std::vector<Chunk>> cls_chunks;
+	const unsigned clen = chunk_len_for(N, mtr);
+	for (size_t i = 0; i < mtr;) {
+		size_t j = i + 1;
+		while (j < mtr && !memcmp(&sig[i * C], &sig[j * C], C * sizeof(unsigned short))) j++;
+		std::vector<unsigned short> sg(sig.begin() + i * C, sig.begin() + (i + 1) * C);
+		size_t id = 0;
+		for (; id < cls_sig.size(); id++) if (cls_sig[id] == sg) break;
+		if (id == cls_sig.size()) { cls_sig.push_back(sg); cls_chunks.emplace_back(); }
+		for (size_t t = i; t < j; t += clen) {
+			Chunk c; c.t0 = t; c.count = (unsigned)std::min<size_t>(clen, j - t); c.row = (unsigned)id;
+			cls_chunks[id].push_back(c);
+		}
+		i = j;
+	}
+	const unsigned ncls = (unsigned)cls_sig.size();
+	std::vector<unsigned> row_first(ncls + 1, 0);
+	for (unsigned id = 0; id < ncls; id++) {
+		row_first[id] = (unsigned)chunks.size();
+		chunks.insert(chunks.end(), cls_chunks[id].begin(), cls_chunks[id].end());
+	}
+	row_first[ncls] = (unsigned)chunks.size();
+	int rc;
+	void *v;
+	if ((rc = scratch(pl, SCR_CLS, (size_t)ncls * N * sizeof(double), &v))) return rc;
+	double *d_cls = (double *)v;
+	pl->ck_valid = false; // the shared table scratch is overwritten
+	if ((rc = run_chunks(pl, d_x, ld, N, chunks, row_first, ncls, d_cls, N, st, true))) return rc;
+	// CSR: (replica, group) -> classes
+	std::vector<unsigned> rp((size_t)C * KM + 1, 0), cols;
+	for (unsigned c = 0; c < C; c++)
+		for (unsigned g = 0; g < KM; g++) {
+			rp[(size_t)c * KM + g] = (unsigned)cols.size();
+			for (unsigned id = 0; id < ncls; id++) if (cls_sig[id][c] == g) cols.push_back(id);
+		}
+	rp[(size_t)C * KM] = (unsigned)cols.size();
+	if ((rc = scratch(pl, SCR_JKP, (size_t)C * KM * N * sizeof(double) + (rp.size() + cols.size() + 1) * sizeof(unsigned), &v))) return rc;
+	double *d_P = (double *)v;
+	unsigned *d_rp = (unsigned *)(d_P + (size_t)C * KM * N), *d_cols = d_rp + rp.size();
+	HIP_TRY(hipMemcpyAsync(d_rp, rp.data(), rp.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+	if (!cols.empty()) HIP_TRY(hipMemcpyAsync(d_cols, cols.data(), cols.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+	for (unsigned r0 = 0; r0 < C * KM; r0 += 65535) {
+		const unsigned ny = std::min(C * KM - r0, 65535u);
+		hipLaunchKernelGGL(k_combine_classes, dim3((unsigned)((N + 255) / 256), ny), dim3(256), 0, st, d_cls, N, d_rp + r0, d_cols,
+		                   d_P + (size_t)r0 * N, N);
+	}
+	HIP_TRY(hipGetLastError());
+	// per replica: stacks of the KM partials, weight with (KM, K_c), inverse, outputs
+	const size_t nc = pl->ncoef;
+	if ((rc = scratch(pl, SCR_JKOUT, (6 * nc + N) * sizeof(double), &v))) return rc;
+	double *OUT = (double *)v, *ST = OUT + 2 * nc, *PS = ST + 2 * nc, *xr = PS + 2 * nc;
+	for (unsigned c = 0; c < C; c++) {
+		const double *Pc = d_P + (size_t)c * KM * N;
+		h_mtr_out[c] = (unsigned)Kc[c];
+		if ((rc = tspws_hip_stacks_double(pl, Pc, KM, N, ST, PS, s))) return rc;
+		if ((rc = tspws_hip_weight(pl, OUT, ST, PS, KM, (unsigned)Kc[c], p->wu, p->unbiased, s))) return rc;
+		if ((rc = tspws_hip_inverse(pl, OUT, 1, xr, s))) return rc;
+		if ((rc = tspws_hip_epilogue(nullptr, d_ts_out + (size_t)c * N, nullptr, xr, N, 1, s))) return rc;
+		hipLaunchKernelGGL(k_jk_linear, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, Pc, KM, N, 1. / (double)Kc[c],
+		                   d_ls_out + (size_t)c * N);
+	}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(st)); // host tables above go out of scope
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// synthetic ensemble: counter-based noise so shards generate independently
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+
+__global__ void __launch_bounds__(256) k_synth(float *__restrict__ x, size_t N, size_t ld, unsigned long long seed, unsigned long long first)
+{
+	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (n >= N) return;
+	const double c = (double)n - (double)N / 2;
+	const double g = c / (0.05 * (double)N);
+	const double sig = 0.2 * sin(2 * TSPWS_PI * c / 200.0) * exp(-0.5 * g * g);
+	const unsigned long long i = (first + blockIdx.y) * (unsigned long long)N + n;
+	const unsigned long long z = mix64(i + seed * 0xD1342543DE82EF95ull + 0x9E3779B97F4A7C15ull);
+	const double u = (double)(z >> 40) * (1.0 / 16777216.0) - 0.5;
+	x[(size_t)blockIdx.y * ld + n] = (float)(sig + u);
+}
+
+extern "C" int tspws_hip_synth(float *d_x, size_t mtr, size_t N, size_t ld, uint64_t seed, size_t first, void *s)
+{
+	if (!d_x) return fail(TSPWS_E_ARG, "synth: NULL");
+	for (size_t t0 = 0; t0 < mtr; t0 += 65535) {
+		const unsigned ny = (unsigned)std::min<size_t>(mtr - t0, 65535);
+		hipLaunchKernelGGL(k_synth, dim3((unsigned)((N + 255) / 256), ny), dim3(256), 0, S_(s), d_x + t0 * ld, N, ld, seed, first + t0);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
