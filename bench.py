@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- stacked samples/s of the ts-PWS hot path on MI355X.
+
+Workload (BASELINE.json `metric`: "Morlet ts-PWS, 10k x 131072", configs[2]): per GPU 10 000
+synthetic traces x 131 072 samples, default Morlet frame (V=4, J=14, 56 scales), two-stage stack
+with 10 groups + unbiased phase coherence.  One step = one whole tspws_main-equivalent call on
+HBM-resident traces: partial stacks -> (all-reduce when N>1) -> 10 forward frame CWTs + phase
+stack -> weight -> 2 inverse CWTs -> float outputs.  Weak scaling: every rank holds its own
+10 000-trace shard of a (N x 10 000)-trace ensemble (configs[4] at N=8 is 80k of its 100k).
+
+Prints ONE JSON line (see the driver contract); N=1 adds the CPU baseline timed on this host.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--traces", type=int, default=10000, help="traces per GPU")
+    ap.add_argument("--samples", type=int, default=131072)
+    ap.add_argument("--kmax", type=int, default=10)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import abi
+    tspws = importlib.import_module("ts-pws_amd")
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+
+    mtr_local, N, K = args.traces, args.samples, args.kmax
+    mtr_global = mtr_local * world
+    first = rank * mtr_local
+    params = tspws.resolve(abi.default_params(Kmax=K, unbiased=1), N)
+    plan = tspws.Plan(params, N, device=local)
+    X = tspws.synth(mtr_local, N, seed=1, first=first, device=local)
+    lib = tspws.load()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ls = torch.empty(N, dtype=torch.float32, device=X.device)
+    ts = torch.empty(N, dtype=torch.float32, device=X.device)
+    red = plan.reduce_buffer(mtr_global)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        plan.stack_local(X, first, mtr_global)      # the HBM-streaming stage (k_partial + chunk reduce)
+        if i is not None:
+            ev[i][1].record()
+        if world > 1:
+            dist.all_reduce(red, op=dist.ReduceOp.SUM)  # ONE RCCL all-reduce of P[Kmax][N] (fp64)
+        plan.stack_finish(mtr_global, ls, ts)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=X.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    stream_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    alg_bytes = 4.0 * mtr_local * N + 8.0 * K * N   # read every float32 sample once + write the K fp64 partials
+    achieved = alg_bytes / (stream_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "pmc_partial_stacks.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    res = {
+        "metric": "stacked samples/s (Morlet ts-PWS, 10k x 131072)",
+        "value": mtr_global * N * args.steps / dt,
+        "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{mtr_local} traces/GPU x {N} samples, Morlet w0=pi*sqrt(2/ln2) V=4 J={params.J}, "
+                               f"two-stage K={K} + unbiased phase coherence (BASELINE configs[2]); HBM-resident float32 traces",
+                   "traces_total": mtr_global, "parallelism": f"trace-sharded x{world}, one fp64 all-reduce of P[K][N]"},
+        "roofline": {"bound": "hbm", "kernel": "k_partial (+k_reduce_chunks)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": stream_ms},
+        "whole_call_frac_of_hbm_roofline": (alg_bytes / (dt / args.steps) / 1e9) / HBM_PEAK_GBS,
+    }
+
+    if world == 1 and rank == 0 and not args.no_cpu:
+        res["cpu_baseline"] = cpu_baseline(abi, X, params_in=abi.default_params(Kmax=K, unbiased=1), ls=ls, ts=ts, N=N, mtr=mtr_local)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(abi, X, params_in, ls, ts, N, mtr):
+    """Time the CPU path on this host on the SAME traces: the reference itself when oracle/_ref
+    was built (kind "reference"), else this repo's restatement (kind "port").  Bounded sample:
+    at most 10 000 traces (the reference needs ~3 s for them on an 8-core Xeon)."""
+    import numpy as np
+    ref = abi.ref()
+    fn, kind = (ref.tspws_main, "reference") if ref is not None else (abi.oracle().orc_tspws_main, "port")
+    n = min(mtr, 10000)
+    Xh = X[:n].cpu().numpy()
+    import ctypes as C
+    x = Xh  # run_main copies; avoid a second 5 GB copy by calling directly
+    p = abi.t_tsPWS.from_buffer_copy(params_in)
+    out = abi.t_tsPWS_out()
+    l = np.zeros(N, np.float32)
+    t = np.zeros(N, np.float32)
+    out.ls = l.ctypes.data_as(C.POINTER(C.c_float))
+    out.tsPWS = t.ctypes.data_as(C.POINTER(C.c_float))
+    d = abi.t_data()
+    d.sigall = x.ctypes.data_as(C.POINTER(C.c_float))
+    d.hdr.max, d.hdr.mtr, d.hdr.dt, d.hdr.beg = N, n, 1.0, 0.0
+    t0 = time.perf_counter()
+    rc = fn(C.byref(p), C.byref(out), C.byref(d))
+    sec = time.perf_counter() - t0
+    base = {"value": n * N / sec, "unit": "samples/s", "cores": os.cpu_count(), "kind": kind, "seconds": sec, "rc": rc,
+            "sample": f"{n} x {N} of the same synthetic traces (copied from HBM), whole tspws_main call, OpenMP team = all cores "
+                      f"(the reference's trace loop is serial, so ~1 core does the work)"}
+    if n == mtr:  # full-size parity of the GPU result against the CPU result on identical inputs
+        base["gpu_vs_cpu_relerr"] = {"ls": abi.relerr(ls.cpu().numpy(), l), "tsPWS": abi.relerr(ts.cpu().numpy(), t)}
+    return base
+
+
+if __name__ == "__main__":
+    main()
