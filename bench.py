@@ -156,7 +156,8 @@ def cpu_baseline(abi, X, params_in, ls, ts, N, mtr):
             "sample": f"{n} x {N} of the same synthetic traces (copied from HBM), whole tspws_main call, OpenMP team = all cores "
                       f"(the reference's trace loop is serial, so ~1 core does the work)"}
     if n == mtr:  # full-size parity of the GPU result against the CPU result on identical inputs
-        base["gpu_vs_cpu_relerr"] = {"ls": abi.relerr(ls.cpu().numpy(), l), "tsPWS": abi.relerr(ts.cpu().numpy(), t)}
+        base["gpu_vs_cpu_relerr"] = {"ls": abi.relerr(ls.cpu().numpy(), l), "tsPWS": abi.relerr(ts.cpu().numpy(), t),
+                                     "max_abs_ls": float(np.abs(l).max()), "max_abs_tsPWS": float(np.abs(t).max())}
     return base
 
 

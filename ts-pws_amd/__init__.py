@@ -109,6 +109,13 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise TspwsError(f"{LIB_PATH} is missing: run __graft_entry__.build() / make -C ts-pws_amd")
+        # torch wheels bundle their own libamdhip64 (SONAME libamdhip64.so.7) but request it by file
+        # name; importing torch FIRST makes the loader hand that same runtime to this library, so a
+        # process never ends up with two HIP runtimes (streams / events would not be shared).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the header promises a symbol the library lacks
