@@ -1,0 +1,232 @@
+// fwd_poly.h -- register-tiled polyphase forward frame CWT for gfx950 (included by tspws_hip.hip).
+//
+//   Y_s[k] = conj( sum_l x[(k D - c + l) mod N] w_s[l] )                  (cdotx.c:44-70)
+//
+// Decomposition.  Write l = q D + m (phase m in [0,D), q in [0,Q), Q = ceil(L/D)).  Output k at tap
+// (q,m) reads x[(k+q) D + m - c]: for a fixed phase the decimating FIR is an ordinary stride-1
+// correlation between the "row" sequence j -> x[j D + m - c] and the Q-tap sub-filter q -> w[q D + m].
+//
+//   thread  = (output group g of R consecutive k, phase m, B traces)
+//   lanes   = consecutive phases m  (so a wave reads 64 consecutive samples / taps: coalesced),
+//             DL = min(nextpow2(D),64) lanes per group, 64/DL groups per wave
+//   window  = R rows of x per trace held in registers, advanced one row per tap (R-way reuse of x,
+//             R*B-way reuse of the tap); the q loop is unrolled R times so the rotation is static
+//   phases  = D > 64: a thread walks `cps` chunks of 64 phases; the D/64 chunks of a scale are split
+//             over `nsplit` waves so that every wave runs a similar number of steps (long filters at
+//             coarse scales have few outputs: the parallelism comes from the taps)
+//   reduce  = the DL phase-lanes of a group are combined with a shuffle reduce-scatter (each of the
+//             2*B*R partial sums crosses the wave once), split partials go to `part` and are summed
+//             by the accumulate / gather kernels in split order (deterministic, no atomics).
+//
+// FP64 FMA only; MFMA unused by design (skinny FIRs).  Works for any D and any N (explicit wrap).
+#pragma once
+
+#define FWD_R 8
+
+__device__ __forceinline__ unsigned wrap_index(long long idx, unsigned N)
+{
+	if (idx < 0) idx += N;
+	while (idx >= (long long)N) idx -= N;
+	return (unsigned)idx;
+}
+
+// Reduce-scatter over the low `nbits` lane bits.  Stage J (lane bit J) halves the live value count:
+// a lane whose bit is set keeps the upper half, its partner the lower half, each adds what the other
+// sends.  All register indices are compile-time.  On return the lane holds `n` finished sums which are
+// entries first .. first+n-1 of the original vector; once a single value is left the remaining bits are
+// plain butterflies (those lanes end up with duplicates).
+template <int NV, int J>
+struct ReduceScatter {
+	static __device__ __forceinline__ void run(double (&v)[NV], unsigned nbits, unsigned lane, int &n, unsigned &first)
+	{
+		constexpr int NCUR = NV >> J;
+		if constexpr (NCUR > 1) {
+			if ((unsigned)J < nbits) {
+				constexpr int half = NCUR / 2;
+				const unsigned mask = 1u << J;
+				const bool up = (lane & mask) != 0;
+#pragma unroll
+				for (int i = 0; i < half; i++) {
+					const double send = up ? v[i] : v[i + half];
+					const double keep = up ? v[i + half] : v[i];
+					v[i] = keep + __shfl_xor(send, (int)mask, 64);
+				}
+				n = half;
+				if (up) first += (unsigned)half;
+				ReduceScatter<NV, J + 1>::run(v, nbits, lane, n, first);
+			}
+		} else {
+			for (unsigned bit = (unsigned)J; bit < nbits; bit++) v[0] += __shfl_xor(v[0], 1 << bit, 64);
+		}
+	}
+};
+
+template <typename TIn, int B>
+__global__ void __launch_bounds__(256) k_fwd_poly(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned N,
+                                                  const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
+                                                  double2 *__restrict__ part, size_t npart, unsigned total_waves)
+{
+	constexpr int R = FWD_R;
+	const unsigned lane = threadIdx.x & 63;
+	const unsigned wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (wid >= total_waves) return;
+	// scale of this wave: last s with wave_off[s] <= wid
+	unsigned lo = 0, hi = S;
+	while (hi - lo > 1) {
+		const unsigned mid = (lo + hi) >> 1;
+		if (sc[mid].wave_off <= wid) lo = mid; else hi = mid;
+	}
+	const ScaleDesc d = sc[lo];
+	const unsigned wl = wid - d.wave_off;
+	const unsigned split = wl / d.ngw, gb = wl - split * d.ngw;
+	const unsigned lane_m = lane & (d.DL - 1);
+	const unsigned g = gb * (64u / d.DL) + (lane >> d.logDL);
+	const unsigned k0 = g * R;
+	const double2 *ws = w + d.tap_off;
+
+	const TIn *xb[B];
+#pragma unroll
+	for (int b = 0; b < B; b++) {
+		unsigned t = blockIdx.y * B + b;
+		if (t >= ntr) t = ntr - 1;
+		xb[b] = x + (size_t)t * ld;
+	}
+	double ar[B][R], ai[B][R];
+#pragma unroll
+	for (int b = 0; b < B; b++)
+#pragma unroll
+		for (int r = 0; r < R; r++) { ar[b][r] = 0; ai[b][r] = 0; }
+
+	for (unsigned ci = 0; ci < d.cps; ci++) {
+		const unsigned chunk = split * d.cps + ci;
+		if (chunk >= d.MC) break;
+		const unsigned m = chunk * 64 + lane_m;
+		const bool mvalid = m < d.D;
+		const unsigned mm = mvalid ? m : 0; // idle phase lanes read valid addresses, contribute nothing
+		const long long base = (long long)k0 * d.D + mm - d.c;
+		double xw[B][R];
+#pragma unroll
+		for (int j = 0; j < R - 1; j++) {
+			const unsigned idx = wrap_index(base + (long long)j * d.D, N);
+#pragma unroll
+			for (int b = 0; b < B; b++) xw[b][j] = (double)xb[b][idx];
+		}
+		unsigned l = mm;
+		unsigned q = 0;
+		long long row = base + (long long)(R - 1) * d.D; // next row to fetch
+		for (; q + R <= d.Q; q += R) {
+#pragma unroll
+			for (int u = 0; u < R; u++) {
+				const unsigned idx = wrap_index(row, N);
+#pragma unroll
+				for (int b = 0; b < B; b++) xw[b][(u + R - 1) % R] = (double)xb[b][idx];
+				const double2 t = ws[l < d.L ? l : d.L - 1];
+				if (mvalid && l < d.L) {
+#pragma unroll
+					for (int b = 0; b < B; b++)
+#pragma unroll
+						for (int r = 0; r < R; r++) {
+							ar[b][r] = fma(xw[b][(u + r) % R], t.x, ar[b][r]);
+							ai[b][r] = fma(xw[b][(u + r) % R], t.y, ai[b][r]);
+						}
+				}
+				l += d.D;
+				row += d.D;
+			}
+		}
+		for (; q < d.Q; q++) { // tail: explicit window shift
+			const unsigned idx = wrap_index(row, N);
+#pragma unroll
+			for (int b = 0; b < B; b++) xw[b][R - 1] = (double)xb[b][idx];
+			const double2 t = ws[l < d.L ? l : d.L - 1];
+			if (mvalid && l < d.L) {
+#pragma unroll
+				for (int b = 0; b < B; b++)
+#pragma unroll
+					for (int r = 0; r < R; r++) {
+						ar[b][r] = fma(xw[b][r], t.x, ar[b][r]);
+						ai[b][r] = fma(xw[b][r], t.y, ai[b][r]);
+					}
+			}
+#pragma unroll
+			for (int b = 0; b < B; b++)
+#pragma unroll
+				for (int r = 0; r < R - 1; r++) xw[b][r] = xw[b][r + 1];
+			l += d.D;
+			row += d.D;
+		}
+	}
+
+	// ---- combine the DL phase lanes of each group: reduce-scatter over lane bits 0..logDL-1 ----
+	constexpr int NV = 2 * B * R;
+	double v[NV];
+#pragma unroll
+	for (int b = 0; b < B; b++)
+#pragma unroll
+		for (int r = 0; r < R; r++) { v[(b * R + r) * 2] = ar[b][r]; v[(b * R + r) * 2 + 1] = ai[b][r]; }
+	int n = NV;
+	unsigned first = 0; // index of v[0] in the original numbering
+	ReduceScatter<NV, 0>::run(v, d.logDL, lane, n, first);
+	// lane bits at or above log2(NV) were plain butterflies: those lanes carry duplicates, the lowest writes
+	unsigned dup_mask = 0;
+	for (unsigned bit = 0; bit < d.logDL; bit++) if ((NV >> bit) <= 1) dup_mask |= 1u << bit;
+	if (lane & dup_mask) return;
+	double *pout[B];
+#pragma unroll
+	for (int b = 0; b < B; b++) {
+		const unsigned t = blockIdx.y * B + b;
+		pout[b] = (t < ntr) ? (double *)(part + (size_t)t * npart + d.part_off + (size_t)split * d.Ns) : nullptr;
+	}
+#pragma unroll
+	for (int i = 0; i < NV; i++) {
+		if (i < n) {
+			const unsigned id = first + i;          // ((b*R + r)*2 + ri)
+			const unsigned ri = id & 1, r = (id >> 1) % R, b = (id >> 1) / R;
+			const unsigned k = k0 + r;
+			if (k < d.Ns) {
+				double *dst = nullptr;
+#pragma unroll
+				for (int bb = 0; bb < B; bb++) if (b == (unsigned)bb) dst = pout[bb];
+				if (dst) dst[(size_t)k * 2 + ri] = ri ? -v[i] : v[i]; // conj
+			}
+		}
+	}
+}
+
+// Y[b][coef] = sum over the scale's split partials (plain coefficient layout; API / tests)
+__global__ void __launch_bounds__(256) k_gather_parts(const double2 *__restrict__ part, size_t npart, const ScaleDesc *__restrict__ sc,
+                                                      unsigned S, double2 *__restrict__ Y, size_t ncoef)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= ncoef) return;
+	const unsigned s = find_scale(sc, S, i, false);
+	const ScaleDesc d = sc[s];
+	const double2 *p = part + (size_t)blockIdx.y * npart + d.part_off + (i - d.coef_off);
+	double2 a = p[0];
+	for (unsigned sp = 1; sp < d.nsplit; sp++) { const double2 t = p[(size_t)sp * d.Ns]; a.x += t.x; a.y += t.y; }
+	Y[(size_t)blockIdx.y * ncoef + i] = a;
+}
+
+// ST += sum_b Y_b ; PS += sum_b Y_b/|Y_b|  straight from the split partials (ts_pws1f_lib.c:489-492)
+__global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restrict__ part, size_t npart, const ScaleDesc *__restrict__ sc,
+                                                          unsigned S, size_t ncoef, unsigned ntr, double2 *__restrict__ ST,
+                                                          double2 *__restrict__ PS, int zero_first)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= ncoef) return;
+	const unsigned s = find_scale(sc, S, i, false);
+	const ScaleDesc d = sc[s];
+	const double2 *p0 = part + d.part_off + (i - d.coef_off);
+	double2 st = zero_first ? make_double2(0, 0) : ST[i];
+	double2 ps = zero_first ? make_double2(0, 0) : PS[i];
+	for (unsigned b = 0; b < ntr; b++) {
+		const double2 *p = p0 + (size_t)b * npart;
+		double2 v = p[0];
+		for (unsigned sp = 1; sp < d.nsplit; sp++) { const double2 t = p[(size_t)sp * d.Ns]; v.x += t.x; v.y += t.y; }
+		st.x += v.x; st.y += v.y;
+		const double r = hypot(v.x, v.y);
+		const double ux = v.x / r, uy = v.y / r;
+		if (ux * ux + uy * uy <= 1.001) { ps.x += ux; ps.y += uy; }
+	}
+	ST[i] = st; PS[i] = ps;
+}

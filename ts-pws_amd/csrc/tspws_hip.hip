@@ -53,9 +53,16 @@ static inline hipStream_t S_(void *s) { return (hipStream_t)s; }
 struct ScaleDesc {
 	unsigned L, D, Ns;
 	int c, cd;
-	unsigned pad;
+	unsigned Q;                 // ceil(L / D): taps per phase
 	unsigned long long tap_off, coef_off;
-	double scale, gain; // gain = ln2 / (2 Cpsi V scale), wavelet_v7.c:145
+	double scale, gain;         // gain = ln2 / (2 Cpsi V scale), wavelet_v7.c:145
+	// work decomposition of the polyphase forward kernel (fwd_poly.h)
+	unsigned DL, logDL;         // phase lanes per output group (power of two <= 64)
+	unsigned MC, cps, nsplit;   // 64-phase chunks, chunks per wave, waves sharing one output group
+	unsigned ngw;               // group-blocks (waves) per split
+	unsigned wave_off;          // first wave of this scale in the launch
+	unsigned pad;
+	unsigned long long part_off; // offset of this scale's [nsplit][Ns] partial block
 };
 
 struct Chunk { // one streaming work item of the partial-stack kernel
@@ -64,13 +71,15 @@ struct Chunk { // one streaming work item of the partial-stack kernel
 	unsigned row;          // destination row (group / class)
 };
 
-enum { SCR_Y = 0, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_N };
+enum { SCR_Y = 0, SCR_PART, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_N };
 
 struct tspws_hip_plan {
 	int device = 0, type = -1;
 	unsigned S = 0, V = 0, J = 0, N = 0;
 	double s0 = 0, b0 = 0, w0 = 0, Cpsi = 0;
 	size_t ncoef = 0, ntaps = 0;
+	size_t npart = 0;          // complex partial coefficients per trace (sum of nsplit*Ns)
+	unsigned fwd_waves = 0;    // waves per trace batch of k_fwd_poly
 	std::vector<ScaleDesc> sc;
 	ScaleDesc *d_sc = nullptr;
 	double2 *d_w = nullptr, *d_wd = nullptr;
@@ -260,6 +269,28 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 		toff += d.L; coff += d.Ns;
 	}
 	p->ntaps = toff; p->ncoef = coff;
+	{ // polyphase forward decomposition: aim at ~FWD_STEPS tap steps per wave
+		const unsigned R = 8, FWD_STEPS = 96;
+		unsigned woff = 0;
+		unsigned long long poff = 0;
+		for (unsigned s = 0; s < S; s++) {
+			ScaleDesc &d = p->sc[s];
+			d.Q = (d.L + d.D - 1) / d.D;
+			unsigned dl = 1, lg = 0;
+			while (dl < d.D && dl < 64) { dl <<= 1; lg++; }
+			d.DL = dl; d.logDL = lg;
+			d.MC = d.D > 64 ? (d.D + 63) / 64 : 1;
+			unsigned cps = std::max(1u, (FWD_STEPS + d.Q / 2) / std::max(1u, d.Q));
+			d.cps = std::min(cps, d.MC);
+			d.nsplit = (d.MC + d.cps - 1) / d.cps;
+			const unsigned NG = (d.Ns + R - 1) / R, GW = 64 / d.DL;
+			d.ngw = (NG + GW - 1) / GW;
+			d.wave_off = woff; d.part_off = poff;
+			woff += d.ngw * d.nsplit;
+			poff += (unsigned long long)d.nsplit * d.Ns;
+		}
+		p->fwd_waves = woff; p->npart = poff;
+	}
 
 	hipError_t e;
 	if ((e = hipMalloc(&p->d_sc, S * sizeof(ScaleDesc))) != hipSuccess ||
@@ -618,7 +649,7 @@ __global__ void __launch_bounds__(256) k_fwd_generic(const TIn *__restrict__ x, 
 }
 
 template <typename TIn>
-static int forward_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_Y, hipStream_t st)
+static int forward_generic(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_Y, hipStream_t st)
 {
 	if (!p || !d_x || !d_Y) return fail(TSPWS_E_ARG, "forward: NULL");
 	if (!ntr) return 0;
@@ -638,6 +669,55 @@ static int forward_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld
 		if (n_short)
 			hipLaunchKernelGGL((k_fwd_generic<TIn, false>), dim3((unsigned)((n_short + 3) / 4), ny), dim3(256), 0, st, xx, ld, p->N,
 			                   p->d_sc, p->S, p->d_w, yy, p->ncoef, 0ull, n_short);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+#include "fwd_poly.h"
+
+// Forward transform of ntr traces into the split-partial layout part[ntr][npart].
+template <typename TIn>
+static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double2 *d_part, hipStream_t st)
+{
+	const unsigned nb = (p->fwd_waves + 3) / 4;
+	if (ntr == 1) {
+		hipLaunchKernelGGL((k_fwd_poly<TIn, 1>), dim3(nb, 1), dim3(256), 0, st, d_x, ld, 1u, p->N, p->d_sc, p->S, p->d_w, d_part, p->npart,
+		                   p->fwd_waves);
+	} else {
+		for (size_t t0 = 0; t0 < ntr; t0 += 2 * 32768) {
+			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, 2 * 32768);
+			hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nb, (nt + 1) / 2), dim3(256), 0, st, d_x + t0 * ld, ld, nt, p->N, p->d_sc, p->S,
+			                   p->d_w, d_part + t0 * p->npart, p->npart, p->fwd_waves);
+		}
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+static bool use_generic_forward()
+{
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("TSPWS_FWD_GENERIC"); v = (e && *e == '1') ? 1 : 0; }
+	return v == 1;
+}
+
+template <typename TIn>
+static int forward_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_Y, hipStream_t st)
+{
+	if (!p || !d_x || !d_Y) return fail(TSPWS_E_ARG, "forward: NULL");
+	if (!ntr) return 0;
+	HIP_TRY(hipSetDevice(p->device));
+	if (use_generic_forward()) return forward_generic<TIn>(p, d_x, ntr, ld, d_Y, st);
+	const size_t batch = std::min<size_t>(ntr, std::max<size_t>(2, (((size_t)256 << 20) / (p->npart * sizeof(double2))) & ~(size_t)1));
+	void *v;
+	int rc = scratch(p, SCR_PART, batch * p->npart * sizeof(double2), &v);
+	if (rc) return rc;
+	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
+		const size_t nb = std::min(batch, ntr - t0);
+		if ((rc = forward_parts<TIn>(p, d_x + t0 * ld, nb, ld, (double2 *)v, st))) return rc;
+		hipLaunchKernelGGL(k_gather_parts, dim3((unsigned)((p->ncoef + 255) / 256), (unsigned)nb), dim3(256), 0, st, (const double2 *)v,
+		                   p->npart, p->d_sc, p->S, (double2 *)d_Y + t0 * p->ncoef, p->ncoef);
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
@@ -683,40 +763,49 @@ extern "C" int tspws_hip_accumulate(tspws_hip_plan *p, const double *d_Y, size_t
 	return 0;
 }
 
+template <typename TIn>
+static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, void *s)
+{
+	HIP_TRY(hipSetDevice(p->device));
+	hipStream_t st = S_(s);
+	if (!ntr) { HIP_TRY(hipMemsetAsync(d_ST, 0, p->ncoef * 16, st)); HIP_TRY(hipMemsetAsync(d_PS, 0, p->ncoef * 16, st)); return 0; }
+	int rc;
+	if (use_generic_forward()) {
+		size_t batch = std::max<size_t>(1, ((size_t)256 << 20) / (p->ncoef * sizeof(double2)));
+		batch = std::min(batch, ntr);
+		void *d_Y = nullptr;
+		if ((rc = scratch(p, SCR_Y, batch * p->ncoef * sizeof(double2), &d_Y))) return rc;
+		for (size_t t0 = 0; t0 < ntr; t0 += batch) {
+			const size_t nb = std::min(batch, ntr - t0);
+			if ((rc = forward_generic<TIn>(p, d_x + t0 * ld, nb, ld, (double *)d_Y, st))) return rc;
+			if ((rc = tspws_hip_accumulate(p, (const double *)d_Y, nb, d_ST, d_PS, t0 == 0, s))) return rc;
+		}
+		return 0;
+	}
+	// trace batch sized to keep the partial-coefficient scratch around 256 MiB (even, for the 2-trace tiles)
+	const size_t batch = std::min<size_t>(ntr, std::max<size_t>(2, (((size_t)256 << 20) / (p->npart * sizeof(double2))) & ~(size_t)1));
+	void *v;
+	if ((rc = scratch(p, SCR_PART, batch * p->npart * sizeof(double2), &v))) return rc;
+	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
+		const size_t nb = std::min(batch, ntr - t0);
+		if ((rc = forward_parts<TIn>(p, d_x + t0 * ld, nb, ld, (double2 *)v, st))) return rc;
+		hipLaunchKernelGGL(k_accumulate_parts, dim3((unsigned)((p->ncoef + 255) / 256)), dim3(256), 0, st, (const double2 *)v, p->npart,
+		                   p->d_sc, p->S, p->ncoef, (unsigned)nb, (double2 *)d_ST, (double2 *)d_PS, t0 == 0 ? 1 : 0);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
 extern "C" int tspws_hip_stacks_double(tspws_hip_plan *p, const double *d_P, unsigned K, size_t ldP, double *d_ST, double *d_PS, void *s)
 {
 	if (!p || !d_P || !d_ST || !d_PS) return fail(TSPWS_E_ARG, "stacks_double: NULL");
-	HIP_TRY(hipSetDevice(p->device));
-	void *d_Y = nullptr;
-	const unsigned batch = 16;
-	int rc = scratch(p, SCR_Y, (size_t)std::min(K, batch) * p->ncoef * sizeof(double2), &d_Y);
-	if (rc) return rc;
-	if (!K) { HIP_TRY(hipMemsetAsync(d_ST, 0, p->ncoef * 16, S_(s))); HIP_TRY(hipMemsetAsync(d_PS, 0, p->ncoef * 16, S_(s))); }
-	for (unsigned k0 = 0; k0 < K; k0 += batch) {
-		const unsigned nb = std::min(batch, K - k0);
-		if ((rc = tspws_hip_forward_f64(p, d_P + (size_t)k0 * ldP, nb, ldP, (double *)d_Y, s))) return rc;
-		if ((rc = tspws_hip_accumulate(p, (const double *)d_Y, nb, d_ST, d_PS, k0 == 0, s))) return rc;
-	}
-	return 0;
+	return stacks_impl<double>(p, d_P, K, ldP, d_ST, d_PS, s);
 }
 
 extern "C" int tspws_hip_stacks_float(tspws_hip_plan *p, const float *d_x, size_t mtr, size_t ld, double *d_ST, double *d_PS, void *s)
 {
 	if (!p || !d_x || !d_ST || !d_PS) return fail(TSPWS_E_ARG, "stacks_float: NULL");
-	HIP_TRY(hipSetDevice(p->device));
-	// trace batch sized to keep the coefficient scratch around 512 MiB
-	size_t batch = std::max<size_t>(1, ((size_t)512 << 20) / (p->ncoef * sizeof(double2)));
-	batch = std::min<size_t>(batch, std::max<size_t>(mtr, 1));
-	void *d_Y = nullptr;
-	int rc = scratch(p, SCR_Y, batch * p->ncoef * sizeof(double2), &d_Y);
-	if (rc) return rc;
-	if (!mtr) { HIP_TRY(hipMemsetAsync(d_ST, 0, p->ncoef * 16, S_(s))); HIP_TRY(hipMemsetAsync(d_PS, 0, p->ncoef * 16, S_(s))); }
-	for (size_t t0 = 0; t0 < mtr; t0 += batch) {
-		const size_t nb = std::min(batch, mtr - t0);
-		if ((rc = tspws_hip_forward_f32(p, d_x + t0 * ld, nb, ld, (double *)d_Y, s))) return rc;
-		if ((rc = tspws_hip_accumulate(p, (const double *)d_Y, nb, d_ST, d_PS, t0 == 0, s))) return rc;
-	}
-	return 0;
+	return stacks_impl<float>(p, d_x, mtr, ld, d_ST, d_PS, s);
 }
 
 // ------------------------------------------------------------------------------------------
