@@ -68,7 +68,9 @@ __global__ void __launch_bounds__(256) k_fwd_poly(const TIn *__restrict__ x, siz
 {
 	constexpr int R = FWD_R;
 	const unsigned lane = threadIdx.x & 63;
-	const unsigned wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+	// readfirstlane makes the wave index provably uniform: the scale lookup and the whole descriptor then
+	// live in SGPRs (scalar loads, scalar branches) instead of VGPRs
+	const unsigned wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	if (wid >= total_waves) return;
 	// scale of this wave: last s with wave_off[s] <= wid
 	unsigned lo = 0, hi = S;
@@ -97,63 +99,53 @@ __global__ void __launch_bounds__(256) k_fwd_poly(const TIn *__restrict__ x, siz
 #pragma unroll
 		for (int r = 0; r < R; r++) { ar[b][r] = 0; ai[b][r] = 0; }
 
+	const unsigned Dw = d.D % N; // row advance, pre-reduced so one conditional subtraction re-wraps (D may exceed N on tiny traces)
 	for (unsigned ci = 0; ci < d.cps; ci++) {
 		const unsigned chunk = split * d.cps + ci;
 		if (chunk >= d.MC) break;
 		const unsigned m = chunk * 64 + lane_m;
 		const bool mvalid = m < d.D;
 		const unsigned mm = mvalid ? m : 0; // idle phase lanes read valid addresses, contribute nothing
-		const long long base = (long long)k0 * d.D + mm - d.c;
+		// row j of this thread is x[(k0 + j) D + m - c  (mod N)]; keep the wrapped index incrementally
+		unsigned row = wrap_index((long long)k0 * d.D + mm - d.c, N);
 		double xw[B][R];
 #pragma unroll
 		for (int j = 0; j < R - 1; j++) {
-			const unsigned idx = wrap_index(base + (long long)j * d.D, N);
 #pragma unroll
-			for (int b = 0; b < B; b++) xw[b][j] = (double)xb[b][idx];
+			for (int b = 0; b < B; b++) xw[b][j] = (double)xb[b][row];
+			row += Dw; if (row >= N) row -= N;
 		}
 		unsigned l = mm;
-		unsigned q = 0;
-		long long row = base + (long long)(R - 1) * d.D; // next row to fetch
-		for (; q + R <= d.Q; q += R) {
+		for (unsigned q = 0; q < d.Q; q += R) {
+			// issue every load of the block first (R rows per trace + R taps), then R tap steps of FMAs
+			const unsigned nsteps = d.Q - q; // >= R for a full block
+			double xn[B][R];
+			double2 tp[R];
 #pragma unroll
 			for (int u = 0; u < R; u++) {
-				const unsigned idx = wrap_index(row, N);
 #pragma unroll
-				for (int b = 0; b < B; b++) xw[b][(u + R - 1) % R] = (double)xb[b][idx];
-				const double2 t = ws[l < d.L ? l : d.L - 1];
-				if (mvalid && l < d.L) {
+				for (int b = 0; b < B; b++) xn[b][u] = (double)xb[b][row];
+				row += Dw; if (row >= N) row -= N;
+				const unsigned lu = l + (unsigned)u * d.D;
+				const bool ok = mvalid && lu < d.L;
+				tp[u] = ws[ok ? lu : 0];
+				if (!ok) tp[u] = make_double2(0.0, 0.0); // taps past the filter end / idle lanes contribute exactly nothing
+			}
+#pragma unroll
+			for (int u = 0; u < R; u++) {
+				if ((unsigned)u < nsteps) { // wave-uniform: only the last, partial block skips steps
+#pragma unroll
+					for (int b = 0; b < B; b++) xw[b][(u + R - 1) % R] = xn[b][u];
 #pragma unroll
 					for (int b = 0; b < B; b++)
 #pragma unroll
 						for (int r = 0; r < R; r++) {
-							ar[b][r] = fma(xw[b][(u + r) % R], t.x, ar[b][r]);
-							ai[b][r] = fma(xw[b][(u + r) % R], t.y, ai[b][r]);
+							ar[b][r] = fma(xw[b][(u + r) % R], tp[u].x, ar[b][r]);
+							ai[b][r] = fma(xw[b][(u + r) % R], tp[u].y, ai[b][r]);
 						}
 				}
-				l += d.D;
-				row += d.D;
 			}
-		}
-		for (; q < d.Q; q++) { // tail: explicit window shift
-			const unsigned idx = wrap_index(row, N);
-#pragma unroll
-			for (int b = 0; b < B; b++) xw[b][R - 1] = (double)xb[b][idx];
-			const double2 t = ws[l < d.L ? l : d.L - 1];
-			if (mvalid && l < d.L) {
-#pragma unroll
-				for (int b = 0; b < B; b++)
-#pragma unroll
-					for (int r = 0; r < R; r++) {
-						ar[b][r] = fma(xw[b][r], t.x, ar[b][r]);
-						ai[b][r] = fma(xw[b][r], t.y, ai[b][r]);
-					}
-			}
-#pragma unroll
-			for (int b = 0; b < B; b++)
-#pragma unroll
-				for (int r = 0; r < R - 1; r++) xw[b][r] = xw[b][r + 1];
-			l += d.D;
-			row += d.D;
+			l += (unsigned)R * d.D;
 		}
 	}
 
@@ -193,6 +185,23 @@ __global__ void __launch_bounds__(256) k_fwd_poly(const TIn *__restrict__ x, siz
 	}
 }
 
+// PS += Y/|Y| unless the quotient is not a unit phasor (Y == 0 gives NaN and is skipped), ts_pws1f_lib.c:491-492.
+// Fast path: one rsqrt instead of hypot + two divisions whenever |Y|^2 is comfortably inside the double range;
+// the literal form handles the rest (zeros, subnormals, huge values).
+__device__ __forceinline__ void add_unit_phasor(double2 &ps, const double2 v)
+{
+	const double r2 = fma(v.x, v.x, v.y * v.y);
+	if (r2 > 1e-280 && r2 < 1e280) {
+		const double inv = rsqrt(r2);
+		ps.x = fma(v.x, inv, ps.x);
+		ps.y = fma(v.y, inv, ps.y);
+	} else {
+		const double r = hypot(v.x, v.y);
+		const double ux = v.x / r, uy = v.y / r;
+		if (ux * ux + uy * uy <= 1.001) { ps.x += ux; ps.y += uy; }
+	}
+}
+
 // Y[b][coef] = sum over the scale's split partials (plain coefficient layout; API / tests)
 __global__ void __launch_bounds__(256) k_gather_parts(const double2 *__restrict__ part, size_t npart, const ScaleDesc *__restrict__ sc,
                                                       unsigned S, double2 *__restrict__ Y, size_t ncoef)
@@ -207,26 +216,38 @@ __global__ void __launch_bounds__(256) k_gather_parts(const double2 *__restrict_
 	Y[(size_t)blockIdx.y * ncoef + i] = a;
 }
 
-// ST += sum_b Y_b ; PS += sum_b Y_b/|Y_b|  straight from the split partials (ts_pws1f_lib.c:489-492)
+// ST += sum_b Y_b ; PS += sum_b Y_b/|Y_b|  straight from the split partials (ts_pws1f_lib.c:489-492).
+// One block = 256 consecutive coefficients of ONE scale (acc_off[s] = first block of scale s), so the scale
+// lookup and descriptor reads are wave-uniform scalar work.
 __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restrict__ part, size_t npart, const ScaleDesc *__restrict__ sc,
-                                                          unsigned S, size_t ncoef, unsigned ntr, double2 *__restrict__ ST,
-                                                          double2 *__restrict__ PS, int zero_first)
+                                                          unsigned S, unsigned ntr, double2 *__restrict__ ST, double2 *__restrict__ PS,
+                                                          int zero_first)
 {
-	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	if (i >= ncoef) return;
-	const unsigned s = find_scale(sc, S, i, false);
-	const ScaleDesc d = sc[s];
-	const double2 *p0 = part + d.part_off + (i - d.coef_off);
+	unsigned lo = 0, hi = S;
+	while (hi - lo > 1) {
+		const unsigned mid = (lo + hi) >> 1;
+		if (sc[mid].acc_off <= blockIdx.x) lo = mid; else hi = mid;
+	}
+	const unsigned Ns = sc[lo].Ns, nsplit = sc[lo].nsplit;
+	const unsigned k = (blockIdx.x - sc[lo].acc_off) * 256 + threadIdx.x;
+	if (k >= Ns) return;
+	const size_t i = sc[lo].coef_off + k;
+	const double2 *p0 = part + sc[lo].part_off + k;
 	double2 st = zero_first ? make_double2(0, 0) : ST[i];
 	double2 ps = zero_first ? make_double2(0, 0) : PS[i];
 	for (unsigned b = 0; b < ntr; b++) {
 		const double2 *p = p0 + (size_t)b * npart;
 		double2 v = p[0];
-		for (unsigned sp = 1; sp < d.nsplit; sp++) { const double2 t = p[(size_t)sp * d.Ns]; v.x += t.x; v.y += t.y; }
+		// split partials in groups of 8 independent loads (nsplit is block-uniform), summed in split order
+		for (unsigned sp = 1; sp < nsplit; sp += 8) {
+			double2 t[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++) t[j] = (sp + j < nsplit) ? p[(size_t)(sp + j) * Ns] : make_double2(0.0, 0.0);
+#pragma unroll
+			for (int j = 0; j < 8; j++) { v.x += t[j].x; v.y += t[j].y; }
+		}
 		st.x += v.x; st.y += v.y;
-		const double r = hypot(v.x, v.y);
-		const double ux = v.x / r, uy = v.y / r;
-		if (ux * ux + uy * uy <= 1.001) { ps.x += ux; ps.y += uy; }
+		add_unit_phasor(ps, v);
 	}
 	ST[i] = st; PS[i] = ps;
 }

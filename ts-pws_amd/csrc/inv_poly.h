@@ -1,0 +1,141 @@
+// inv_poly.h -- register-tiled polyphase inverse frame transform (real part) for gfx950.
+//
+//   x^[n] = sum_s gain_s D_s sum_{l : D_s | (n - cd_s + l)} Re( conj(wd_s[l]) Y_s[(n - cd_s + l)/D_s] )
+//                                                   (wavelet_v7.c:138-147, cdotx.c:305-340 / :176-211)
+//
+// Fast path: scales whose decimation divides N (then the zero-stuffed grid is circular and the seam
+// restart of cdotx.c:331-332 coincides with plain mod-N_s indexing).  Write n - cd = a D + rho; only taps
+// l = q D + mu, mu = (-rho) mod D, land on the grid and hit coefficient a + q + (rho > 0).  For a fixed
+// output phase the inverse is therefore a stride-1 correlation between the coefficient row and a Q-tap
+// sub-filter -- the same sliding-window structure as the forward kernel, but with NO reduction across
+// lanes: every thread owns its outputs.
+//
+//   work item = (octave, output phase n0 in [0,D), group of R outputs n0 + (gR+r) D, NREC coefficient sets)
+//   lanes     = consecutive n0 (taps and outputs coalesced; the coefficient row is wave-uniform when D >= 64)
+//   all V voices of the octave (same D) are summed in registers; octave sums go to obuf[octave][rec][N]
+//   and k_inv_combine adds the <= J octave rows (+ the generic-path row) in a fixed order.
+#pragma once
+
+#define INV_R 8
+
+struct OctDesc {
+	unsigned s0, nv;        // first scale, voices
+	unsigned D, Ns;
+	unsigned DL, logDL, MC; // lanes per phase block, 64-phase chunks
+	unsigned ngw;           // group-blocks per chunk
+	unsigned wave_off;
+	unsigned slot;          // row of obuf
+	unsigned pad0, pad1;
+};
+
+template <int NREC>
+__global__ void __launch_bounds__(256) k_inv_poly(const double2 *__restrict__ Y, size_t ncoef, unsigned N, const ScaleDesc *__restrict__ sc,
+                                                  const OctDesc *__restrict__ oc, unsigned noct, const double2 *__restrict__ wd,
+                                                  double *__restrict__ obuf, size_t slot_stride, unsigned total_waves)
+{
+	constexpr int R = INV_R;
+	const unsigned lane = threadIdx.x & 63;
+	const unsigned wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	if (wid >= total_waves) return;
+	unsigned lo = 0, hi = noct;
+	while (hi - lo > 1) {
+		const unsigned mid = (lo + hi) >> 1;
+		if (oc[mid].wave_off <= wid) lo = mid; else hi = mid;
+	}
+	const OctDesc o = oc[lo];
+	const unsigned wl = wid - o.wave_off;
+	const unsigned chunk = wl / o.ngw, gb = wl - chunk * o.ngw;
+	const unsigned n0 = chunk * 64 + (lane & (o.DL - 1));
+	const unsigned g = gb * (64u / o.DL) + (lane >> o.logDL);
+	const bool live = n0 < o.D && g * R < o.Ns;
+	const unsigned n0c = n0 < o.D ? n0 : 0;
+	const unsigned D = o.D, Ns = o.Ns;
+
+	double acc[NREC][R];
+#pragma unroll
+	for (int c = 0; c < NREC; c++)
+#pragma unroll
+		for (int r = 0; r < R; r++) acc[c][r] = 0;
+
+	for (unsigned v = 0; v < o.nv; v++) {
+		const ScaleDesc d = sc[o.s0 + v];
+		const double2 *ws = wd + d.tap_off;
+		const double2 *ys = Y + d.coef_off;
+		// n - cd = a D + rho for n = n0 + (gR + r) D
+		const long long t = (long long)n0c - d.cd;
+		long long a = t >= 0 ? t / D : -((-t + D - 1) / D);
+		const unsigned rho = (unsigned)(t - a * (long long)D);
+		const unsigned mu = rho ? D - rho : 0;
+		a += (long long)g * R + (rho ? 1 : 0);
+		long long am = a % (long long)Ns;
+		if (am < 0) am += Ns;
+		unsigned row = (unsigned)am;               // coefficient index of window slot 0
+		const double gD = d.gain * (double)D;
+		double2 yw[NREC][R];
+#pragma unroll
+		for (int j = 0; j < R - 1; j++) {
+#pragma unroll
+			for (int c = 0; c < NREC; c++) yw[c][j] = ys[(size_t)c * ncoef + row];
+			if (++row == Ns) row = 0;
+		}
+		unsigned l = mu, q = 0;
+		for (; q + R <= d.Q; q += R) {
+#pragma unroll
+			for (int u = 0; u < R; u++) {
+#pragma unroll
+				for (int c = 0; c < NREC; c++) yw[c][(u + R - 1) % R] = ys[(size_t)c * ncoef + row];
+				if (++row == Ns) row = 0;
+				double2 tp = ws[l < d.L ? l : d.L - 1];
+				if (l < d.L) {
+					tp.x *= gD; tp.y *= gD;
+#pragma unroll
+					for (int c = 0; c < NREC; c++)
+#pragma unroll
+						for (int r = 0; r < R; r++)
+							acc[c][r] = fma(tp.x, yw[c][(u + r) % R].x, fma(tp.y, yw[c][(u + r) % R].y, acc[c][r]));
+				}
+				l += D;
+			}
+		}
+		for (; q < d.Q; q++) {
+#pragma unroll
+			for (int c = 0; c < NREC; c++) yw[c][R - 1] = ys[(size_t)c * ncoef + row];
+			if (++row == Ns) row = 0;
+			double2 tp = ws[l < d.L ? l : d.L - 1];
+			if (l < d.L) {
+				tp.x *= gD; tp.y *= gD;
+#pragma unroll
+				for (int c = 0; c < NREC; c++)
+#pragma unroll
+					for (int r = 0; r < R; r++) acc[c][r] = fma(tp.x, yw[c][r].x, fma(tp.y, yw[c][r].y, acc[c][r]));
+			}
+#pragma unroll
+			for (int c = 0; c < NREC; c++)
+#pragma unroll
+				for (int r = 0; r < R - 1; r++) yw[c][r] = yw[c][r + 1];
+			l += D;
+		}
+	}
+	if (!live) return;
+	double *dst = obuf + (size_t)o.slot * slot_stride;
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		const unsigned k = g * R + r;
+		if (k < Ns) {
+			const size_t n = (size_t)n0 + (size_t)k * D;
+#pragma unroll
+			for (int c = 0; c < NREC; c++) dst[(size_t)c * N + n] = acc[c][r];
+		}
+	}
+}
+
+// x^[rec][n] = sum of the obuf rows (fixed order)
+__global__ void __launch_bounds__(256) k_inv_combine(const double *__restrict__ obuf, size_t slot_stride, unsigned nslots, size_t total,
+                                                     double *__restrict__ xout)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= total) return;
+	double a = obuf[i];
+	for (unsigned s = 1; s < nslots; s++) a += obuf[(size_t)s * slot_stride + i];
+	xout[i] = a;
+}

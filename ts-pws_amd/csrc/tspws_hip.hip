@@ -61,9 +61,12 @@ struct ScaleDesc {
 	unsigned MC, cps, nsplit;   // 64-phase chunks, chunks per wave, waves sharing one output group
 	unsigned ngw;               // group-blocks (waves) per split
 	unsigned wave_off;          // first wave of this scale in the launch
-	unsigned pad;
+	unsigned inv_fast;          // 1: D divides N, handled by the polyphase inverse (inv_poly.h)
+	unsigned acc_off, pad;      // first 256-coefficient block of this scale in k_accumulate_parts
 	unsigned long long part_off; // offset of this scale's [nsplit][Ns] partial block
 };
+
+struct OctDesc;
 
 struct Chunk { // one streaming work item of the partial-stack kernel
 	unsigned long long t0; // first local trace
@@ -71,7 +74,7 @@ struct Chunk { // one streaming work item of the partial-stack kernel
 	unsigned row;          // destination row (group / class)
 };
 
-enum { SCR_Y = 0, SCR_PART, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_N };
+enum { SCR_Y = 0, SCR_PART, SCR_OBUF, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_N };
 
 struct tspws_hip_plan {
 	int device = 0, type = -1;
@@ -80,6 +83,9 @@ struct tspws_hip_plan {
 	size_t ncoef = 0, ntaps = 0;
 	size_t npart = 0;          // complex partial coefficients per trace (sum of nsplit*Ns)
 	unsigned fwd_waves = 0;    // waves per trace batch of k_fwd_poly
+	unsigned acc_blocks = 0;   // blocks of k_accumulate_parts
+	unsigned inv_waves = 0, inv_noct = 0, inv_ngeneric = 0; // polyphase inverse: waves, octave items, scales left to the generic kernel
+	struct OctDesc *d_oc = nullptr;
 	std::vector<ScaleDesc> sc;
 	ScaleDesc *d_sc = nullptr;
 	double2 *d_w = nullptr, *d_wd = nullptr;
@@ -222,6 +228,8 @@ static double cpsi_host(int type, double w0)
 	return acc * (0.01 * sqrt(TSPWS_PI) / 2);
 }
 
+static int build_inverse_items(tspws_hip_plan *p); // defined next to the inverse kernels
+
 extern "C" int tspws_hip_device_count(void)
 {
 	int n = 0;
@@ -264,7 +272,7 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 		d.c = (int)(d.L / 2u);
 		d.cd = (int)d.L - 1 - d.c;
 		d.Ns = (N + d.D - 1u) / d.D;
-		d.tap_off = toff; d.coef_off = coff; d.pad = 0;
+		d.tap_off = toff; d.coef_off = coff;
 		d.gain = log(2.0) / (2 * p->Cpsi * V * d.scale);
 		toff += d.L; coff += d.Ns;
 	}
@@ -291,6 +299,11 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 		}
 		p->fwd_waves = woff; p->npart = poff;
 	}
+	for (unsigned s = 0; s < S; s++) {
+		p->sc[s].inv_fast = (N % p->sc[s].D == 0) ? 1u : 0u;
+		p->sc[s].acc_off = p->acc_blocks; p->sc[s].pad = 0;
+		p->acc_blocks += (p->sc[s].Ns + 255) / 256;
+	}
 
 	hipError_t e;
 	if ((e = hipMalloc(&p->d_sc, S * sizeof(ScaleDesc))) != hipSuccess ||
@@ -300,6 +313,7 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 		tspws_hip_plan_destroy(p);
 		return fail(e == hipErrorOutOfMemory ? TSPWS_E_NOMEM : TSPWS_E_HIP, "plan_create: device tables", e);
 	}
+	if (int rc = build_inverse_items(p)) { tspws_hip_plan_destroy(p); return rc; }
 	const unsigned nb = (unsigned)((p->ntaps + 255) / 256);
 	hipLaunchKernelGGL(k_gen_taps, dim3(nb), dim3(256), 0, 0, p->d_sc, S, type, w0, (unsigned long long)p->ntaps, p->d_w, p->d_wd);
 	if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
@@ -315,6 +329,7 @@ extern "C" void tspws_hip_plan_destroy(tspws_hip_plan *p)
 	if (!p) return;
 	(void)hipSetDevice(p->device);
 	for (int i = 0; i < SCR_N; i++) if (p->scr[i]) (void)hipFree(p->scr[i]);
+	if (p->d_oc) (void)hipFree(p->d_oc);
 	if (p->d_sc) (void)hipFree(p->d_sc);
 	if (p->d_w) (void)hipFree(p->d_w);
 	if (p->d_wd) (void)hipFree(p->d_wd);
@@ -746,9 +761,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const double2 *__restrict__ 
 	for (unsigned b = 0; b < ntr; b++) {
 		const double2 v = Y[(size_t)b * ncoef + i];
 		st.x += v.x; st.y += v.y;
-		const double r = hypot(v.x, v.y);
-		const double ux = v.x / r, uy = v.y / r;
-		if (ux * ux + uy * uy <= 1.001) { ps.x += ux; ps.y += uy; }
+		add_unit_phasor(ps, v);
 	}
 	ST[i] = st; PS[i] = ps;
 }
@@ -789,8 +802,8 @@ static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld,
 	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
 		const size_t nb = std::min(batch, ntr - t0);
 		if ((rc = forward_parts<TIn>(p, d_x + t0 * ld, nb, ld, (double2 *)v, st))) return rc;
-		hipLaunchKernelGGL(k_accumulate_parts, dim3((unsigned)((p->ncoef + 255) / 256)), dim3(256), 0, st, (const double2 *)v, p->npart,
-		                   p->d_sc, p->S, p->ncoef, (unsigned)nb, (double2 *)d_ST, (double2 *)d_PS, t0 == 0 ? 1 : 0);
+		hipLaunchKernelGGL(k_accumulate_parts, dim3(p->acc_blocks), dim3(256), 0, st, (const double2 *)v, p->npart, p->d_sc, p->S,
+		                   (unsigned)nb, (double2 *)d_ST, (double2 *)d_PS, t0 == 0 ? 1 : 0);
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
@@ -864,7 +877,7 @@ extern "C" int tspws_hip_weight(tspws_hip_plan *p, double *d_OUT, const double *
 // ------------------------------------------------------------------------------------------
 template <int NREC>
 __global__ void __launch_bounds__(256) k_inverse_generic(const double2 *__restrict__ Y, size_t ncoef, unsigned N, const ScaleDesc *__restrict__ sc,
-                                                         unsigned S, const double2 *__restrict__ wd, double *__restrict__ xout)
+                                                         unsigned S, const double2 *__restrict__ wd, double *__restrict__ xout, int only_slow)
 {
 	const unsigned n = blockIdx.x * 256 + threadIdx.x;
 	if (n >= N) return;
@@ -873,6 +886,7 @@ __global__ void __launch_bounds__(256) k_inverse_generic(const double2 *__restri
 	for (int r = 0; r < NREC; r++) tot[r] = 0;
 	for (unsigned s = 0; s < S; s++) {
 		const ScaleDesc d = sc[s];
+		if (only_slow && d.inv_fast) continue;
 		const double2 *ws = wd + d.tap_off;
 		const double2 *ys = Y + d.coef_off;
 		long long n0 = (long long)n - d.cd;
@@ -930,18 +944,80 @@ __global__ void __launch_bounds__(256) k_inverse_generic(const double2 *__restri
 	for (int r = 0; r < NREC; r++) xout[(size_t)r * N + n] = tot[r];
 }
 
+#include "inv_poly.h"
+
+// work list of the polyphase inverse: one item group per run of consecutive scales with the same D
+static int build_inverse_items(tspws_hip_plan *p)
+{
+	std::vector<OctDesc> oc;
+	unsigned woff = 0;
+	p->inv_ngeneric = 0;
+	for (unsigned s = 0; s < p->S;) {
+		unsigned e = s + 1;
+		while (e < p->S && p->sc[e].D == p->sc[s].D) e++;
+		if (!p->sc[s].inv_fast) { p->inv_ngeneric += e - s; s = e; continue; }
+		OctDesc o;
+		memset(&o, 0, sizeof o);
+		o.s0 = s; o.nv = e - s; o.D = p->sc[s].D; o.Ns = p->sc[s].Ns;
+		unsigned dl = 1, lg = 0;
+		while (dl < o.D && dl < 64) { dl <<= 1; lg++; }
+		o.DL = dl; o.logDL = lg;
+		o.MC = o.D > 64 ? (o.D + 63) / 64 : 1;
+		const unsigned NG = (o.Ns + INV_R - 1) / INV_R, GW = 64 / o.DL;
+		o.ngw = (NG + GW - 1) / GW;
+		o.wave_off = woff; o.slot = (unsigned)oc.size();
+		woff += o.MC * o.ngw;
+		oc.push_back(o);
+		s = e;
+	}
+	p->inv_waves = woff; p->inv_noct = (unsigned)oc.size();
+	if (!oc.empty()) {
+		HIP_TRY(hipMalloc(&p->d_oc, oc.size() * sizeof(OctDesc)));
+		HIP_TRY(hipMemcpy(p->d_oc, oc.data(), oc.size() * sizeof(OctDesc), hipMemcpyHostToDevice));
+	}
+	return 0;
+}
+
+static bool use_generic_inverse()
+{
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("TSPWS_INV_GENERIC"); v = (e && *e == '1') ? 1 : 0; }
+	return v == 1;
+}
+
+template <int NREC>
+static int inverse_launch(tspws_hip_plan *p, const double2 *Y, double *x, hipStream_t st)
+{
+	const unsigned nb = (p->N + 255) / 256;
+	if (use_generic_inverse() || p->inv_noct == 0) {
+		hipLaunchKernelGGL(k_inverse_generic<NREC>, dim3(nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->S, p->d_wd, x, 0);
+		return 0;
+	}
+	const unsigned nslots = p->inv_noct + (p->inv_ngeneric ? 1 : 0);
+	const size_t slot = (size_t)NREC * p->N;
+	void *v;
+	int rc = scratch(p, SCR_OBUF, (size_t)nslots * slot * sizeof(double), &v);
+	if (rc) return rc;
+	double *obuf = (double *)v;
+	hipLaunchKernelGGL(k_inv_poly<NREC>, dim3((p->inv_waves + 3) / 4), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->d_oc, p->inv_noct,
+	                   p->d_wd, obuf, slot, p->inv_waves);
+	if (p->inv_ngeneric)
+		hipLaunchKernelGGL(k_inverse_generic<NREC>, dim3(nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->S, p->d_wd,
+		                   obuf + (size_t)p->inv_noct * slot, 1);
+	hipLaunchKernelGGL(k_inv_combine, dim3((unsigned)((slot + 255) / 256)), dim3(256), 0, st, obuf, slot, nslots, slot, x);
+	return 0;
+}
+
 extern "C" int tspws_hip_inverse(tspws_hip_plan *p, const double *d_Y, size_t nrec, double *d_x, void *s)
 {
 	if (!p || !d_Y || !d_x) return fail(TSPWS_E_ARG, "inverse: NULL");
 	HIP_TRY(hipSetDevice(p->device));
-	const unsigned nb = (p->N + 255) / 256;
 	size_t r = 0;
+	int rc;
 	for (; r + 2 <= nrec; r += 2)
-		hipLaunchKernelGGL(k_inverse_generic<2>, dim3(nb), dim3(256), 0, S_(s), (const double2 *)d_Y + r * p->ncoef, p->ncoef, p->N, p->d_sc,
-		                   p->S, p->d_wd, d_x + r * p->N);
+		if ((rc = inverse_launch<2>(p, (const double2 *)d_Y + r * p->ncoef, d_x + r * p->N, S_(s)))) return rc;
 	if (r < nrec)
-		hipLaunchKernelGGL(k_inverse_generic<1>, dim3(nb), dim3(256), 0, S_(s), (const double2 *)d_Y + r * p->ncoef, p->ncoef, p->N, p->d_sc,
-		                   p->S, p->d_wd, d_x + r * p->N);
+		if ((rc = inverse_launch<1>(p, (const double2 *)d_Y + r * p->ncoef, d_x + r * p->N, S_(s)))) return rc;
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
