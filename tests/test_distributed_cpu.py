@@ -1,0 +1,105 @@
+"""world_size-2 gloo test of the trace-sharded path on CPU.
+
+The product's multi-GPU orchestration (ts-pws_amd.stack_sharded: shard-local half -> ONE all-reduce ->
+finish) is exercised with an oracle-backed stand-in for the device plan (tests may use the oracle as the
+checker); the sharded result must equal the unsharded oracle call."""
+import ctypes as C
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import abi
+
+tspws = importlib.import_module("ts-pws_amd")
+
+
+class OraclePlan:
+    """CPU stand-in with the interface stack_sharded needs; arithmetic by the oracle."""
+
+    def __init__(self, params, N):
+        self.p = abi.resolve(params, N)
+        self.N = N
+        self.f = abi.OracleFrame.from_params(self.p, N)
+        self.buf = None
+
+    def two_stage(self, mtr_global):
+        return bool(self.p.Kmax) and self.p.Kmax <= mtr_global
+
+    def reduce_buffer(self, mtr_global):
+        n = self.p.Kmax * self.N if self.two_stage(mtr_global) else 4 * self.f.ncoef
+        if self.buf is None or self.buf.numel() != n:
+            self.buf = torch.zeros(n, dtype=torch.float64)
+        return self.buf
+
+    def stack_local(self, traces, first, mtr_global):
+        x = traces.numpy()
+        buf = self.reduce_buffer(mtr_global)
+        buf.zero_()
+        if self.two_stage(mtr_global):
+            P = buf.numpy().reshape(self.p.Kmax, self.N)
+            for i in range(x.shape[0]):
+                g = int(np.floor(float((first + i) * self.p.Kmax) / float(mtr_global)))  # ts_pws1f_lib.c:876, GLOBAL index
+                P[g] += x[i].astype(np.float64)
+        else:
+            nc = self.f.ncoef
+            ST = buf.numpy()[:2 * nc].view(np.complex128)
+            PS = buf.numpy()[2 * nc:].view(np.complex128)
+            for i in range(x.shape[0]):
+                Y = self.f.forward(x[i].astype(np.float64))
+                abi.oracle().orc_accumulate(ST.ctypes.data, PS.ctypes.data, Y.ctypes.data, nc)
+
+    def stack_finish(self, mtr_global, ls, ts):
+        nc = self.f.ncoef
+        orc = abi.oracle()
+        if self.two_stage(mtr_global):
+            K = self.p.Kmax
+            P = self.buf.numpy().reshape(K, self.N)
+            ST = np.zeros(nc, np.complex128)
+            PS = np.zeros(nc, np.complex128)
+            for g in range(K):
+                Y = self.f.forward(P[g])
+                orc.orc_accumulate(ST.ctypes.data, PS.ctypes.data, Y.ctypes.data, nc)
+        else:
+            K = mtr_global
+            ST = self.buf.numpy()[:2 * nc].view(np.complex128).copy()
+            PS = self.buf.numpy()[2 * nc:].view(np.complex128).copy()
+        OUT = np.zeros(nc, np.complex128)
+        orc.orc_weight(OUT.ctypes.data, ST.ctypes.data, PS.ctypes.data, nc, K, mtr_global, self.p.wu, self.p.unbiased)
+        ts.copy_(torch.from_numpy(self.f.inverse(OUT).astype(np.float32)))
+        ls.copy_(torch.from_numpy(self.f.inverse(ST).astype(np.float32) / np.float32(mtr_global)))
+
+
+def _worker(rank, world, port, kw, mtr, N, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X = abi.synth_traces(mtr, N, seed=17)
+        first, count = tspws.shard_range(mtr, rank, world)
+        plan = OraclePlan(abi.default_params(**kw), N)
+        ls, ts = tspws.stack_sharded(plan, torch.from_numpy(X[first:first + count]), first, mtr)
+        np.save(os.path.join(out_dir, f"ls{rank}.npy"), ls.numpy())
+        np.save(os.path.join(out_dir, f"ts{rank}.npy"), ts.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("kw", [dict(Kmax=5, unbiased=1), dict(), dict(Kmax=3, type=-3)])
+def test_two_rank_shards_match_unsharded(tmp_path, kw):
+    mtr, N, world = 23, 1024, 2  # odd trace count: shards of 11 and 12, group boundaries inside shards
+    mp.spawn(_worker, args=(world, _free_port(), kw, mtr, N, str(tmp_path)), nprocs=world, join=True)
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), abi.synth_traces(mtr, N, seed=17))
+    for r in range(world):
+        assert abi.relerr(np.load(tmp_path / f"ls{r}.npy"), want["ls"]) < 2e-6
+        assert abi.relerr(np.load(tmp_path / f"ts{r}.npy"), want["tsPWS"]) < 2e-6

@@ -198,19 +198,8 @@ class Plan:
               "stack_finish")
 
     def stack(self, traces, first=0, mtr_global=None, group=None):
-        """ls, tsPWS (float32 cuda tensors) of a shard of HBM-resident traces; with a
-        torch.distributed `group` (or an initialised default group when mtr_global is given
-        and world_size > 1) the shard results are summed with ONE all-reduce over RCCL."""
-        import torch
-        import torch.distributed as dist
-        mtr_global = traces.shape[0] if mtr_global is None else mtr_global
-        self.stack_local(traces, first, mtr_global)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.reduce_buffer(mtr_global), op=dist.ReduceOp.SUM, group=group)
-        ls = torch.empty(self.N, dtype=torch.float32, device=traces.device)
-        ts = torch.empty(self.N, dtype=torch.float32, device=traces.device)
-        self.stack_finish(mtr_global, ls, ts)
-        return ls, ts
+        """ls, tsPWS (float32 cuda tensors) of a shard of HBM-resident traces; see stack_sharded."""
+        return stack_sharded(self, traces, first, mtr_global, group)
 
     def close(self):
         if getattr(self, "h", None):
@@ -222,6 +211,28 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+
+def stack_sharded(plan, traces, first=0, mtr_global=None, group=None):
+    """One tspws_main-equivalent call over a trace-sharded ensemble.
+
+    Every rank holds a contiguous shard `traces` whose first row is global trace `first` of
+    `mtr_global`.  The shard-local half produces a sum over traces (two-stage: the Kmax partial
+    stacks, group index taken from the GLOBAL trace index; single-stage: ST||PS); ONE all-reduce
+    (RCCL over xGMI on GPUs, backend "nccl") adds the shards; every rank then finishes (K forward
+    CWTs, weight, two inverses) redundantly -- that part is tiny.  With world_size 1 (or no process
+    group) there is no collective at all.  `plan` only needs stack_local / reduce_buffer /
+    stack_finish / N, so the CPU tests drive the same orchestration with an oracle-backed plan."""
+    import torch
+    import torch.distributed as dist
+    mtr_global = traces.shape[0] if mtr_global is None else mtr_global
+    plan.stack_local(traces, first, mtr_global)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(plan.reduce_buffer(mtr_global), op=dist.ReduceOp.SUM, group=group)
+    ls = torch.empty(plan.N, dtype=torch.float32, device=traces.device)
+    ts = torch.empty(plan.N, dtype=torch.float32, device=traces.device)
+    plan.stack_finish(mtr_global, ls, ts)
+    return ls, ts
 
 
 def _as_tensor(ptr, count, dtype, device):
