@@ -272,3 +272,28 @@ def synth_traces(mtr, N, seed=0, first=0):
         z = z ^ (z >> np.uint64(31))
     u = (z >> np.uint64(40)).astype(np.float64) * (1.0 / (1 << 24)) - 0.5
     return (sig[None, :] + u).astype(np.float32)
+
+
+# ------------------------------------------------------------------- SAC files --
+def write_sac(path, data, delta, b, year=None, jday=None, kstnm="STA", big_endian=False):
+    """Minimal SAC v6 writer for test inputs (632-byte header + float32 samples)."""
+    data = np.asarray(data, np.float32)
+    fl = np.full(70, -12345.0, np.float32)
+    it = np.full(40, -12345, np.int32)
+    fl[0], fl[5], fl[6] = delta, b, b + (len(data) - 1) * delta
+    it[6], it[9], it[15], it[35], it[36], it[37], it[38], it[39] = 6, len(data), 1, 1, 0, 1, 1, 0
+    if year is not None:
+        it[0], it[1], it[2], it[3], it[4], it[5] = year, jday, 0, 0, 0, 0
+    k = bytearray(b"-12345  " * 24)
+    k[8:24] = b"-12345          "
+    k[0:8] = kstnm.encode().ljust(8)[:8]
+    e = ">" if big_endian else "<"
+    with open(path, "wb") as f:
+        f.write(fl.astype(e + "f4").tobytes() + it.astype(e + "i4").tobytes() + bytes(k) + data.astype(e + "f4").tobytes())
+
+
+def read_sac(path):
+    raw = open(path, "rb").read()
+    fl = np.frombuffer(raw, "<f4", 70, 0)
+    it = np.frombuffer(raw, "<i4", 40, 280)
+    return dict(f=fl, i=it, k=raw[440:632], data=np.frombuffer(raw, "<f4", int(it[9]), 632).copy())

@@ -1,0 +1,351 @@
+/*
+ * ts_pws -- SAC-file command-line front-end of the MI355X ts-PWS engine.
+ *
+ * Same command line, input conventions and output files as the reference front-end
+ * (/root/reference/src/ts_pws1f.c:139-431): first argument = text file listing SAC files (or an msacs
+ * binary with `bin`), then key=value / bare-word options matched by prefix in the reference's order
+ * (:163-215); outputs tl[_X].sac and ts_pws[_X].sac (+ jackknife replicas), fold trimming as :322-328.
+ * The stacking itself is tspws_main() from libtspws_hip.so.  SAC I/O is this repo's own minimal
+ * implementation (sacio_min.c) because SAC's sacio.a is not available.
+ *
+ * Extension over the reference: when reading a SAC list, each trace's start time is taken from the SAC
+ * reference time (nzyear/nzjday/...), so the jackknife also works without an msacs file (the reference
+ * leaves `time` zero there and runs on uninitialised masks).
+ */
+#include <ctype.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "sacio_min.h"
+#include "ts_pws1f_lib.h"
+
+static int is_uint(const char *s)
+{
+	while (*s == ' ') s++;
+	if (*s == '+') s++;
+	const char *d = s;
+	while (isdigit((unsigned char)*s)) s++;
+	return *s == '\0' && s > d;
+}
+
+static int is_double(const char *s)
+{
+	while (*s == ' ') s++;
+	if (*s == '+' || *s == '-') s++;
+	while (isdigit((unsigned char)*s)) s++;
+	if (*s == '.') { s++; while (isdigit((unsigned char)*s)) s++; }
+	return *s == '\0';
+}
+
+/* invalid numbers are ignored, as in the reference (the parse status is never checked, :163-215) */
+static void rd_uint(unsigned *x, const char *s) { if (is_uint(s)) *x = (unsigned)atoi(s); else fprintf(stderr, "ts_pws: ignoring bad unsigned value '%s'\n", s); }
+static void rd_double(double *x, const char *s) { if (is_double(s)) *x = atof(s); else fprintf(stderr, "ts_pws: ignoring bad value '%s'\n", s); }
+
+static unsigned binomial(unsigned n, unsigned d)
+{
+	if (d > n - d) d = n - d;
+	unsigned out = 1;
+	for (unsigned i = n - d + 1; i <= n; i++) out *= i;
+	for (unsigned i = 2; i <= d; i++) out /= i;
+	return out;
+}
+
+static void usage(void)
+{
+	puts("\nTime-scale phase-weighted stack (ts-PWS) on AMD MI355X -- drop-in for ts_pws (Ventosa et al., GJI 2017).\n"
+	     "USAGE: ts_pws filelist [options]\n"
+	     "  filelist           text file with one SAC file per line (or an msacs binary with `bin`)\n"
+	     "  wu=2               phase-weight power            J= V= s0= b0= fmin=   frame sampling\n"
+	     "  Q= | cycles= | cyc= | w0=   Morlet shape         MexHat   complex Mexican-hat frame\n"
+	     "  rm  fold  uni  verbose  unbiased                 TwoStage[=10]   two-stage stack\n"
+	     "  jackknife_n= jackknife_d=   (TwoStage only)      obin   replicas to one msacs file\n"
+	     "  Nmax=              use the first Nmax traces     osac=X kinst=S  output naming / header\n"
+	     "  convergence[=ref.sac] AllSteps subsmpl_N= subsmpl_prob=   accepted; not on the HIP path yet\n"
+	     "OUTPUT: tl[_X].sac (linear stack), ts_pws[_X].sac (ts-PWS), *_subsmpl_<m>.sac replicas.\n"
+	     "Device: environment variable TSPWS_DEVICE (default 0).\n");
+}
+
+static int starts(const char *a, const char *p) { return !strncmp(a, p, strlen(p)); }
+
+/* ---- input --------------------------------------------------------------------------------- */
+static char **read_list(const char *path, unsigned *n_out)
+{
+	FILE *f = fopen(path, "r");
+	if (!f) return NULL;
+	size_t cap = 64, n = 0;
+	char **v = (char **)malloc(cap * sizeof *v), line[1024];
+	while (v && fgets(line, sizeof line, f)) {
+		char *nl = strchr(line, '\n');
+		if (nl) *nl = '\0';
+		if (n == cap) { cap *= 2; v = (char **)realloc(v, cap * sizeof *v); if (!v) break; }
+		v[n++] = strdup(line);
+	}
+	fclose(f);
+	*n_out = (unsigned)n;
+	return v;
+}
+
+static void trim_copy(char dst[9], const char *src8)
+{
+	memcpy(dst, src8, 8);
+	dst[8] = '\0';
+}
+
+/* reference: ReadData, ts_pws1f.c:570-723 */
+static int read_data(t_data *in, const char *filein, int bin, int verbose)
+{
+	t_hdr *hdr = &in->hdr;
+	if (bin) {
+		FILE *f = fopen(filein, "rb");
+		if (!f) { printf("tspws_main: cannot open the %s file\n", filein); return -2; }
+		msacs_header b;
+		if (fread(&b, sizeof b, 1, f) != 1) printf("tspws_main: %s is shorter than predicted (header).\n", filein);
+		hdr->max = (int)b.nlags; hdr->mtr = b.nseq;
+		hdr->evla = b.stlat1; hdr->evlo = b.stlon1; hdr->stla = b.stlat2; hdr->stlo = b.stlon2; hdr->stel = b.stel2;
+		hdr->dt = (b.lag2 - b.lag1) / (float)(b.nlags - 1);
+		hdr->beg = b.lag1;
+		trim_copy(hdr->net1, b.net1); trim_copy(hdr->sta1, b.sta1); trim_copy(hdr->loc1, b.loc1); trim_copy(hdr->chn1, b.chn1);
+		trim_copy(hdr->net2, b.net2); trim_copy(hdr->sta2, b.sta2); trim_copy(hdr->loc2, b.loc2); trim_copy(hdr->chn2, b.chn2);
+		const size_t mtr = hdr->mtr, max = (size_t)hdr->max;
+		in->sigall = (float *)calloc((mtr * max) > 0 ? mtr * max : 1, sizeof(float));
+		in->time = (time_t *)calloc(mtr ? mtr : 1, sizeof(time_t));
+		in->lag0 = (float *)calloc(mtr ? mtr : 1, sizeof(float));
+		if (!in->sigall || !in->time || !in->lag0) { fclose(f); return 4; }
+		if (fread(in->time, sizeof(time_t), mtr, f) != mtr) printf("tspws_main: %s is shorter than predicted (time).\n", filein);
+		if (fread(in->lag0, sizeof(float), mtr, f) != mtr) printf("tspws_main: %s is shorter than predicted (lag0).\n", filein);
+		if (fread(in->sigall, sizeof(float), mtr * max, f) != mtr * max) printf("tspws_main: %s is shorter than predicted (data).\n", filein);
+		fclose(f);
+		return 0;
+	}
+	unsigned nfiles = 0;
+	char **files = read_list(filein, &nfiles);
+	if (!files) { printf("tspws_main: cannot read the %s file\n", filein); return -2; }
+	if (!nfiles) { printf("tspws_main: nothing to do, %s is empty!\n", filein); free(files); hdr->mtr = 0; return 0; }
+	sac_header h;
+	int npts = 0, rc = sac_read(files[0], &h, NULL, 0, &npts);
+	if (rc) { printf("\a tspws_main: Error reading %s header (nerr=%d).\n", files[0], rc); return 2; }
+	if (h.f[SAC_F_DELTA] == SAC_UNDEF_F || h.f[SAC_F_B] == SAC_UNDEF_F || npts <= 0) {
+		printf("\a tspws_main: Error reading %s header, npts/delta/b is not defined!\n", files[0]);
+		return 2;
+	}
+	hdr->max = npts; hdr->mtr = nfiles;
+	hdr->dt = h.f[SAC_F_DELTA]; hdr->beg = h.f[SAC_F_B];
+	hdr->stla = h.f[SAC_F_STLA]; hdr->stlo = h.f[SAC_F_STLO]; hdr->stel = h.f[SAC_F_STEL];
+	hdr->evla = h.f[SAC_F_EVLA]; hdr->evlo = h.f[SAC_F_EVLO];
+	if (verbose && (hdr->stla == SAC_UNDEF_F || hdr->evla == SAC_UNDEF_F)) printf("tspws_main: station/event coordinates are not defined in %s.\n", files[0]);
+	sac_get_k(&h, SAC_K_KNETWK, 8, hdr->net2); sac_get_k(&h, SAC_K_KSTNM, 8, hdr->sta2);
+	sac_get_k(&h, SAC_K_KHOLE, 8, hdr->loc2); sac_get_k(&h, SAC_K_KCMPNM, 8, hdr->chn2);
+	sac_get_k(&h, SAC_K_KUSER0, 8, hdr->net1); sac_get_k(&h, SAC_K_KEVNM, 8, hdr->sta1);
+	sac_get_k(&h, SAC_K_KUSER1, 8, hdr->loc1); sac_get_k(&h, SAC_K_KUSER2, 8, hdr->chn1);
+
+	const size_t max = (size_t)npts;
+	in->sigall = (float *)calloc((size_t)nfiles * max, sizeof(float));
+	in->time = (time_t *)calloc(nfiles, sizeof(time_t));
+	in->lag0 = (float *)calloc(nfiles, sizeof(float));
+	if (!in->sigall || !in->time || !in->lag0) {
+		printf("tspws_main: Out of memory when reading %s (mtr = %u, npts = %d)\n", filein, nfiles, npts);
+		return 4;
+	}
+	const float dt1 = hdr->dt, beg1 = hdr->beg;
+	unsigned kept = 0;
+	for (unsigned i = 0; i < nfiles; i++) {
+		float *dst = in->sigall + (size_t)kept * max;
+		int n = 0;
+		memset(dst, 0, max * sizeof(float));
+		rc = sac_read(files[i], &h, dst, npts, &n);
+		if (rc) { printf("tspws_main: Error reading %s file (nerr=%d)\n", files[i], rc); return -2; }
+		if (n > npts) printf("tspws_main: WARNING: using only %d samples on %u trace\n", npts, i);
+		else if (n < npts) printf("tspws_main: WARNING: trace %u has only %d samples\n", i, n);
+		if (fabs(h.f[SAC_F_DELTA] - dt1) > dt1 * 0.01) { /* :695-706 */
+			printf("tspws_main: WARNING: trace %u has a different dt !\ntspws_main: WARNING: skipping trace %u\n", i, i);
+			continue;
+		}
+		if (fabs(beg1 - h.f[SAC_F_B]) > dt1) {
+			printf("tspws_main: WARNING: trace %u has a different beg !\ntspws_main: WARNING: skipping trace %u\n", i, i);
+			continue;
+		}
+		in->time[kept] = sac_reference_time(&h);
+		kept++;
+	}
+	/* The reference keeps hdr->mtr at the file count even when traces were skipped (:708), which makes it
+	 * stack trailing zero rows; this front-end stacks exactly the traces it kept. */
+	hdr->mtr = kept;
+	for (unsigned i = 0; i < nfiles; i++) free(files[i]);
+	free(files);
+	for (unsigned i = 0; i < kept; i++) {
+		const float *x = in->sigall + (size_t)i * max;
+		size_t n = 0;
+		while (n < max && x[n] == 0.f) n++;
+		if (n == max) printf("tspws_main: %s, trace %u of %u is ZERO\n", filein, i, kept);
+	}
+	return 0;
+}
+
+/* ---- output -------------------------------------------------------------------------------- */
+/* reference: wrsac, ts_pws1f.c:725-763 */
+static int write_sac(const char *name, const float *y, const t_hdr *hdr, const char *kinst, float user0)
+{
+	sac_header h;
+	sac_new_header(&h);
+	h.i[SAC_I_IZTYPE] = 11; /* IO */
+	h.i[SAC_I_NPTS] = hdr->max;
+	h.f[SAC_F_DELTA] = hdr->dt; h.f[SAC_F_B] = hdr->beg; h.f[SAC_F_USER0] = user0;
+	h.f[SAC_F_STLA] = hdr->stla; h.f[SAC_F_STLO] = hdr->stlo; h.f[SAC_F_STEL] = hdr->stel;
+	h.f[SAC_F_EVLA] = hdr->evla; h.f[SAC_F_EVLO] = hdr->evlo;
+	sac_set_k(&h, SAC_K_KINST, 8, kinst);
+	sac_set_k(&h, SAC_K_KNETWK, 8, hdr->net2); sac_set_k(&h, SAC_K_KSTNM, 8, hdr->sta2);
+	sac_set_k(&h, SAC_K_KHOLE, 8, hdr->loc2); sac_set_k(&h, SAC_K_KCMPNM, 8, hdr->chn2);
+	sac_set_k(&h, SAC_K_KUSER0, 8, hdr->net1); sac_set_k(&h, SAC_K_KEVNM, 16, hdr->sta1);
+	sac_set_k(&h, SAC_K_KUSER1, 8, hdr->loc1); sac_set_k(&h, SAC_K_KUSER2, 8, hdr->chn1);
+	h.i[SAC_I_LCALDA] = 1;
+	const int rc = sac_write(name, &h, y);
+	if (rc) printf("\a wrsac: Error writing the %s file\n", name);
+	return rc;
+}
+
+static void put8(char dst[8], const char *src) /* NUL-padded 8-character field, no terminator needed */
+{
+	size_t n = strlen(src);
+	memset(dst, 0, 8);
+	memcpy(dst, src, n < 8 ? n : 8);
+}
+
+/* reference: wrbin, ts_pws1f.c:765-826 (header, then the replica sizes as time_t, then the rows; no lag0 block) */
+static int write_bin(const char *name, float **y, unsigned M, unsigned first, const t_hdr *hdr, const char *kinst, const unsigned *mtr)
+{
+	msacs_header b;
+	memset(&b, 0, sizeof b);
+	b.nlags = (uint32_t)hdr->max; b.nseq = M;
+	b.stlat1 = hdr->evla; b.stlon1 = hdr->evlo; b.stlat2 = hdr->stla; b.stlon2 = hdr->stlo; b.stel2 = hdr->stel;
+	b.lag1 = hdr->beg; b.tlength = hdr->dt * (float)(b.nlags - 1); b.lag2 = b.lag1 + b.tlength;
+	put8(b.method, kinst);
+	put8(b.net1, hdr->net1); put8(b.sta1, hdr->sta1); put8(b.loc1, hdr->loc1); put8(b.chn1, hdr->chn1);
+	put8(b.net2, hdr->net2); put8(b.sta2, hdr->sta2); put8(b.loc2, hdr->loc2); put8(b.chn2, hdr->chn2);
+	FILE *f = fopen(name, "wb");
+	if (!f) { printf("tspws_main: cannot open the %s file\n", name); return -2; }
+	fwrite(&b, sizeof b, 1, f);
+	for (unsigned m = 0; m < M; m++) { time_t t = (time_t)mtr[m]; fwrite(&t, sizeof t, 1, f); }
+	for (unsigned m = 0; m < M; m++) fwrite(y[m] + first, sizeof(float), (size_t)hdr->max, f);
+	fclose(f);
+	return 0;
+}
+
+int main(int argc, char *argv[])
+{
+	/* defaults of the reference, ts_pws1f.c:140-142 */
+	t_tsPWS p;
+	memset(&p, 0, sizeof p);
+	p.type = -1; p.V = 4; p.s0 = 2.; p.b0 = 1.0; p.w0 = PI * sqrt(2 / log(2)); p.wu = 2.; p.cycle = 2.;
+	if (argc == 1) { usage(); return 0; }
+	p.filein = argv[1];
+	if (starts(p.filein, "info")) { usage(); return 0; }
+
+	for (int i = 2; i < argc; i++) {
+		const char *a = argv[i];
+		if (starts(a, "wu=")) rd_double(&p.wu, a + 3);
+		else if (starts(a, "J=")) rd_uint(&p.J, a + 2);
+		else if (starts(a, "Nmax=")) rd_uint(&p.Nmax, a + 5);
+		else if (starts(a, "fmin=")) rd_double(&p.fmin, a + 5);
+		else if (starts(a, "V=")) { rd_uint(&p.V, a + 2); p.lVfix = 1; }
+		else if (starts(a, "s0=")) { rd_double(&p.s0, a + 3); p.ls0fix = 1; }
+		else if (starts(a, "b0=")) { rd_double(&p.b0, a + 3); p.lb0fix = 1; }
+		else if (starts(a, "uni")) p.uni = 1;
+		else if (starts(a, "rm")) p.lrm = 1;
+		else if (starts(a, "bin")) p.bin = 1;
+		else if (starts(a, "verbose")) p.verbose = 1;
+		else if (starts(a, "fold")) p.fold = 1;
+		else if (starts(a, "unbiased")) p.unbiased = 1;
+		else if (starts(a, "MexHat")) p.type = -3;
+		else if (starts(a, "AllSteps")) p.AllSteps = 1;
+		else if (starts(a, "subsmpl_N=")) rd_uint(&p.subsmpl_N, a + 10);
+		else if (starts(a, "subsmpl_prob=")) rd_double(&p.subsmpl_p, a + 13);
+		else if (starts(a, "jackknife_n=")) rd_uint(&p.jackknife_n, a + 12);
+		else if (starts(a, "jackknife_d=")) rd_uint(&p.jackknife_d, a + 12);
+		else if (starts(a, "obin")) p.obin = 1;
+		else if (starts(a, "TwoStage")) { p.Kmax = 10; if (starts(a, "TwoStage=")) rd_uint(&p.Kmax, a + 9); }
+		else if (starts(a, "convergence")) { p.convergence = 1; if (starts(a, "convergence=")) p.fileconv = argv[i] + 12; }
+		else if (starts(a, "Q=")) { rd_double(&p.Q, a + 2); if (p.w0set < 1) p.w0set = 1; }
+		else if (starts(a, "cycles=")) { rd_double(&p.cycle, a + 7); if (p.w0set < 2) p.w0set = 2; }
+		else if (starts(a, "cyc=")) { if (p.w0set < 3) { p.w0set = 3; rd_double(&p.w0, a + 4); p.w0 *= PI; } }
+		else if (starts(a, "w0=")) { rd_double(&p.w0, a + 3); if (p.w0set < 4) p.w0set = 4; }
+		else if (starts(a, "osac=")) { p.fileout = argv[i] + 5; if (!strlen(p.fileout)) p.fileout = NULL; }
+		else if (starts(a, "kinst=")) { p.kinst = argv[i] + 6; p.lkinst = 1; }
+		else if (starts(a, "info")) { usage(); return 0; }
+	}
+
+	t_data in;
+	memset(&in, 0, sizeof in);
+	int er = read_data(&in, p.filein, p.bin, p.verbose);
+	if (er) return er;
+	if (!in.hdr.mtr) return 0;
+
+	t_tsPWS_out out;
+	memset(&out, 0, sizeof out);
+	const size_t max = (size_t)in.hdr.max;
+	out.N = (unsigned)max;
+	out.mtr = p.Nmax ? p.Nmax : in.hdr.mtr;
+	out.ls = (float *)calloc(max, sizeof(float));
+	out.tsPWS = (float *)calloc(max, sizeof(float));
+	if (!out.ls || !out.tsPWS) { printf("main: Out of memory\n"); return 4; }
+	if (p.convergence || p.subsmpl_N) {
+		printf("ts_pws: convergence curves / random subsampling are not on the MI355X path yet; ignored.\n");
+		p.convergence = 0; p.subsmpl_N = 0; p.subsmpl_p = 0; p.fileconv = NULL;
+	}
+	if (p.jackknife_n) { /* :247-252 */
+		if (p.jackknife_d == 0 || p.jackknife_d >= p.jackknife_n) { p.jackknife_d = 0; p.jackknife_n = 0; }
+		else out.M = binomial(p.jackknife_n, p.jackknife_d);
+	}
+	if (p.jackknife_n) {
+		out.mtr_subsmpl = (unsigned *)calloc(out.M, sizeof(unsigned));
+		out.ls_subsmpl = (float **)calloc(out.M, sizeof(float *));
+		out.tsPWS_subsmpl = (float **)calloc(out.M, sizeof(float *));
+		float *a = (float *)calloc((size_t)out.M * max, sizeof(float)), *b = (float *)calloc((size_t)out.M * max, sizeof(float));
+		if (!out.mtr_subsmpl || !out.ls_subsmpl || !out.tsPWS_subsmpl || !a || !b) { printf("main: Out of memory\n"); return 4; }
+		for (unsigned m = 0; m < out.M; m++) { out.ls_subsmpl[m] = a + (size_t)m * max; out.tsPWS_subsmpl[m] = b + (size_t)m * max; }
+	}
+
+	er = tspws_main(&p, &out, &in);
+
+	if (!er) {
+		t_hdr hdr = in.hdr;
+		unsigned first = 0;
+		if (p.fold) { /* :322-328 */
+			if (2 * hdr.beg + (hdr.max - 1) * hdr.dt < 0.5 * hdr.dt) {
+				first = (unsigned)(hdr.max / 2);
+				hdr.max = (hdr.max + 1) / 2;
+				hdr.beg += hdr.dt * first;
+			} else printf("Warning: Folding ignored. B = %f, E = %f\n", hdr.beg, hdr.beg + (hdr.max - 1) * hdr.dt);
+		}
+		char name[1200];
+		const char *tag = p.fileout;
+		if (tag) snprintf(name, sizeof name, "tl_%s.sac", tag); else strcpy(name, "tl.sac");
+		write_sac(name, out.ls + first, &hdr, p.lkinst ? p.kinst : "t-lin", (float)out.mtr);
+		if (p.verbose) printf("Output files:\n  Linear stack: %s\n", name);
+		if (tag) snprintf(name, sizeof name, "ts_pws_%s.sac", tag); else strcpy(name, "ts_pws.sac");
+		write_sac(name, out.tsPWS + first, &hdr, p.lkinst ? p.kinst : "ts_pws", (float)out.mtr);
+		if (p.verbose) printf("  ts-PWS:       %s\n", name);
+		if (p.jackknife_n) {
+			char sub[1100];
+			if (tag) snprintf(sub, sizeof sub, "_%s_subsmpl", tag); else strcpy(sub, "_subsmpl");
+			if (p.obin) {
+				snprintf(name, sizeof name, "tl%s.bin", sub);
+				write_bin(name, out.ls_subsmpl, out.M, first, &hdr, p.lkinst ? p.kinst : "t-lin", out.mtr_subsmpl);
+				snprintf(name, sizeof name, "ts_pws%s.bin", sub);
+				write_bin(name, out.tsPWS_subsmpl, out.M, first, &hdr, p.lkinst ? p.kinst : "ts_pws", out.mtr_subsmpl);
+			} else
+				for (unsigned m = 0; m < out.M; m++) {
+					snprintf(name, sizeof name, "tl%s_%u.sac", sub, m);
+					write_sac(name, out.ls_subsmpl[m] + first, &hdr, p.lkinst ? p.kinst : "t-lin", (float)out.mtr_subsmpl[m]);
+					snprintf(name, sizeof name, "ts_pws%s_%u.sac", sub, m);
+					write_sac(name, out.tsPWS_subsmpl[m] + first, &hdr, p.lkinst ? p.kinst : "ts_pws", (float)out.mtr_subsmpl[m]);
+				}
+		}
+	}
+	if (out.ls_subsmpl) { free(out.ls_subsmpl[0]); free(out.tsPWS_subsmpl[0]); }
+	free(out.ls_subsmpl); free(out.tsPWS_subsmpl); free(out.mtr_subsmpl);
+	free(out.ls); free(out.tsPWS);
+	free(in.sigall); free(in.time); free(in.lag0);
+	return er; /* the reference returns 0 even when tspws_main failed (:430); a non-zero status is more useful */
+}
