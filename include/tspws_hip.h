@@ -134,6 +134,17 @@ int  tspws_hip_reduce_buffer(tspws_hip_plan *plan, const t_tsPWS *p, size_t mtr_
 int  tspws_hip_stack_finish(tspws_hip_plan *plan, const t_tsPWS *p, size_t mtr_global,
                             float *d_ls, float *d_tsPWS, void *stream);
 
+/* Single-GPU convenience: the same call, pipelined.  The two-stage partial stacks are streamed group by group on
+ * `stream` while an internal second stream transforms each finished group (HBM-bound streaming overlaps the
+ * FP64-bound CWTs); falls back to _local + _finish for single-stage requests or with TSPWS_NO_OVERLAP=1.  On
+ * return all work is ordered on `stream`. */
+int  tspws_hip_stack(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_sigall, size_t ld, size_t mtr,
+                     float *d_ls, float *d_tsPWS, void *stream);
+/* Optional timing of the streaming stage inside tspws_hip_stack (HIP events on `stream` around the partial-stack
+ * launches of up to max_calls calls); _end synchronises the device and returns the mean per call. */
+int  tspws_hip_profile_begin(tspws_hip_plan *plan, size_t max_calls);
+int  tspws_hip_profile_end(tspws_hip_plan *plan, double *mean_ms, size_t *ncalls);
+
 /* ---- jackknife (two-stage only, like the reference) ------------------------------------- */
 /* Host: deletion masks sel[C][mtr] (1 = kept) from start times.  JackknifePlans, :385-430.
  * Returns 0, 1 for NULL arguments, -2 when time[0]==0 (no start times). */

@@ -295,6 +295,13 @@ def test_device_path_and_shards(lib, torch, kw):
     torch.cuda.synchronize()
     assert abi.relerr(ls.cpu().numpy(), b["ls"]) < TOL32
     assert abi.relerr(ts.cpu().numpy(), b["tsPWS"]) < TOL32
+    # pipelined single-GPU entry (tspws_hip_stack) gives the same answer, call after call
+    for _ in range(3):
+        ls1, ts1 = pl.stack_single(Xd)
+    torch.cuda.synchronize()
+    assert abi.relerr(ls1.cpu().numpy(), b["ls"]) < TOL32
+    assert abi.relerr(ts1.cpu().numpy(), b["tsPWS"]) < TOL32
+    np.testing.assert_array_equal(ts1.cpu().numpy(), ts.cpu().numpy())  # same kernels, same order
     # emulate 4 ranks on one GPU: shard-local halves, summed reduce buffers, one finish
     total = None
     for r in range(4):

@@ -97,6 +97,9 @@ SYMBOLS = {
     "tspws_hip_stack_local": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "tspws_hip_reduce_buffer": (_i, [_vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz)]),
     "tspws_hip_stack_finish": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "tspws_hip_stack": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    "tspws_hip_profile_begin": (_i, [_vp, _sz]),
+    "tspws_hip_profile_end": (_i, [_vp, C.POINTER(_d), C.POINTER(_sz)]),
     "tspws_jackknife_plan": (_i, [_vp, _vp, _sz, _u, _u, _u]),
     "tspws_hip_jackknife": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _u, _vp, _vp, _vp, _vp]),
     "tspws_hip_synth": (_i, [_vp, _sz, _sz, _sz, C.c_uint64, _sz, _vp]),
@@ -200,6 +203,16 @@ class Plan:
     def stack(self, traces, first=0, mtr_global=None, group=None):
         """ls, tsPWS (float32 cuda tensors) of a shard of HBM-resident traces; see stack_sharded."""
         return stack_sharded(self, traces, first, mtr_global, group)
+
+    def stack_single(self, traces, ls=None, ts=None):
+        """Whole call on ONE GPU through tspws_hip_stack (pipelined streaming + transforms)."""
+        import torch
+        mtr, ld = traces.shape[0], traces.stride(0) if traces.shape[0] > 1 else traces.shape[1]
+        ls = torch.empty(self.N, dtype=torch.float32, device=traces.device) if ls is None else ls
+        ts = torch.empty(self.N, dtype=torch.float32, device=traces.device) if ts is None else ts
+        check(self.lib.tspws_hip_stack(self.h, C.byref(self.params), traces.data_ptr(), ld, mtr, ls.data_ptr(), ts.data_ptr(), self._stream()),
+              "stack")
+        return ls, ts
 
     def close(self):
         if getattr(self, "h", None):

@@ -62,7 +62,10 @@ struct ScaleDesc {
 	unsigned ngw;               // group-blocks (waves) per split
 	unsigned wave_off;          // first wave of this scale in the launch
 	unsigned inv_fast;          // 1: D divides N, handled by the polyphase inverse (inv_poly.h)
-	unsigned acc_off, pad;      // first 256-coefficient block of this scale in k_accumulate_parts
+	unsigned acc_off;           // first 256-coefficient block of this scale in k_accumulate_parts
+	unsigned use_lds;           // 1: forward transform by k_fwd_lds (fwd_lds.h), 0: k_fwd_poly
+	unsigned lds_off, lds_bps;  // first workgroup of this scale in k_fwd_lds, workgroups per split
+	unsigned pad0, pad1;
 	unsigned long long part_off; // offset of this scale's [nsplit][Ns] partial block
 };
 
@@ -84,6 +87,7 @@ struct tspws_hip_plan {
 	size_t npart = 0;          // complex partial coefficients per trace (sum of nsplit*Ns)
 	unsigned fwd_waves = 0;    // waves per trace batch of k_fwd_poly
 	unsigned acc_blocks = 0;   // blocks of k_accumulate_parts
+	unsigned lds_blocks = 0;   // workgroups per trace of k_fwd_lds
 	unsigned inv_waves = 0, inv_noct = 0, inv_ngeneric = 0; // polyphase inverse: waves, octave items, scales left to the generic kernel
 	struct OctDesc *d_oc = nullptr;
 	std::vector<ScaleDesc> sc;
@@ -95,6 +99,13 @@ struct tspws_hip_plan {
 	// lazily grown device scratch
 	void *scr[SCR_N] = {nullptr};
 	size_t scr_bytes[SCR_N] = {0};
+	// pipelined single-GPU call: second stream, per-group events
+	hipStream_t aux = nullptr;
+	std::vector<hipEvent_t> ev_grp;
+	hipEvent_t ev_done = nullptr;
+	// optional timing of the streaming stage inside tspws_hip_stack (bench.py roofline leg)
+	std::vector<hipEvent_t> prof_ev;
+	size_t prof_used = 0;
 	// cached chunk table
 	std::vector<Chunk> chunks;
 	std::vector<unsigned> row_first; // per destination row: first chunk, rows+1 entries
@@ -277,9 +288,12 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 		toff += d.L; coff += d.Ns;
 	}
 	p->ntaps = toff; p->ncoef = coff;
-	{ // polyphase forward decomposition: aim at ~FWD_STEPS tap steps per wave
+	{ // forward decomposition.  Scales with >= 8 output groups and (D >= 64 or D a power of two) run on the
+	  // LDS-staged kernel; the rest (very coarse scales, odd small decimations) on the direct kernel, which
+	  // aims at ~FWD_STEPS tap steps per wave.
 		const unsigned R = 8, FWD_STEPS = 96;
-		unsigned woff = 0;
+		const bool no_lds = getenv("TSPWS_FWD_NOLDS") && *getenv("TSPWS_FWD_NOLDS") == '1';
+		unsigned woff = 0, boff = 0;
 		unsigned long long poff = 0;
 		for (unsigned s = 0; s < S; s++) {
 			ScaleDesc &d = p->sc[s];
@@ -288,20 +302,28 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 			while (dl < d.D && dl < 64) { dl <<= 1; lg++; }
 			d.DL = dl; d.logDL = lg;
 			d.MC = d.D > 64 ? (d.D + 63) / 64 : 1;
-			unsigned cps = std::max(1u, (FWD_STEPS + d.Q / 2) / std::max(1u, d.Q));
+			const unsigned NG = (d.Ns + R - 1) / R, GW = 64 / d.DL;
+			const bool pow2 = (d.D & (d.D - 1)) == 0;
+			d.use_lds = (!no_lds && NG >= 8 && (d.D >= 64 || pow2)) ? 1u : 0u;
+			unsigned cps;
+			if (d.use_lds) {
+				const unsigned qtiles = (d.Q + 15) / 16;
+				cps = std::max(1u, 8u / qtiles);
+			} else cps = std::max(1u, (FWD_STEPS + d.Q / 2) / std::max(1u, d.Q));
 			d.cps = std::min(cps, d.MC);
 			d.nsplit = (d.MC + d.cps - 1) / d.cps;
-			const unsigned NG = (d.Ns + R - 1) / R, GW = 64 / d.DL;
 			d.ngw = (NG + GW - 1) / GW;
-			d.wave_off = woff; d.part_off = poff;
-			woff += d.ngw * d.nsplit;
+			d.wave_off = woff; d.lds_off = boff; d.part_off = poff;
+			d.lds_bps = (NG + 8 * GW - 1) / (8 * GW);
+			if (d.use_lds) boff += d.lds_bps * d.nsplit; else woff += d.ngw * d.nsplit;
 			poff += (unsigned long long)d.nsplit * d.Ns;
+			d.pad0 = d.pad1 = 0;
 		}
-		p->fwd_waves = woff; p->npart = poff;
+		p->fwd_waves = woff; p->lds_blocks = boff; p->npart = poff;
 	}
 	for (unsigned s = 0; s < S; s++) {
 		p->sc[s].inv_fast = (N % p->sc[s].D == 0) ? 1u : 0u;
-		p->sc[s].acc_off = p->acc_blocks; p->sc[s].pad = 0;
+		p->sc[s].acc_off = p->acc_blocks;
 		p->acc_blocks += (p->sc[s].Ns + 255) / 256;
 	}
 
@@ -329,6 +351,10 @@ extern "C" void tspws_hip_plan_destroy(tspws_hip_plan *p)
 	if (!p) return;
 	(void)hipSetDevice(p->device);
 	for (int i = 0; i < SCR_N; i++) if (p->scr[i]) (void)hipFree(p->scr[i]);
+	for (hipEvent_t e : p->ev_grp) (void)hipEventDestroy(e);
+	for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
+	if (p->ev_done) (void)hipEventDestroy(p->ev_done);
+	if (p->aux) (void)hipStreamDestroy(p->aux);
 	if (p->d_oc) (void)hipFree(p->d_oc);
 	if (p->d_sc) (void)hipFree(p->d_sc);
 	if (p->d_w) (void)hipFree(p->d_w);
@@ -581,39 +607,46 @@ static unsigned chunk_len_for(size_t N, size_t mtr)
 	return (unsigned)std::min<size_t>(len, 1u << 20);
 }
 
+// Chunk table of the two-stage streaming pass: every group's run of local traces is cut into equal pieces
+// (group of global trace i: floor(i*Kmax/mtr_global), ts_pws1f_lib.c:876).  Cached in the plan.
+static bool build_group_chunks(tspws_hip_plan *p, size_t mtr_local, size_t first, size_t mtr_global, unsigned Kmax)
+{
+	if (p->ck_valid && p->ck_mtr == mtr_local && p->ck_first == first && p->ck_glob == mtr_global && p->ck_K == Kmax) return false;
+	p->chunks.clear();
+	p->row_first.assign(Kmax + 1, 0);
+	unsigned clen = chunk_len_for(p->N, mtr_local);
+	if (const char *e = getenv("TSPWS_CHUNK_LEN")) clen = std::max(1, atoi(e));
+	std::vector<std::vector<Chunk>> per(Kmax);
+	size_t i = 0;
+	while (i < mtr_local) {
+		const size_t g = (size_t)floor((double)((first + i) * (size_t)Kmax) / (double)mtr_global);
+		size_t j = i + 1;
+		while (j < mtr_local && (size_t)floor((double)((first + j) * (size_t)Kmax) / (double)mtr_global) == g) j++;
+		const size_t n = j - i, pieces = (n + clen - 1) / clen, base = n / pieces, rem = n % pieces;
+		size_t t = i;
+		for (size_t k = 0; k < pieces; k++) {
+			Chunk c; c.t0 = t; c.count = (unsigned)(base + (k < rem ? 1 : 0)); c.row = (unsigned)g;
+			per[std::min<size_t>(g, Kmax - 1)].push_back(c);
+			t += c.count;
+		}
+		i = j;
+	}
+	for (unsigned g = 0; g < Kmax; g++) {
+		p->row_first[g] = (unsigned)p->chunks.size();
+		p->chunks.insert(p->chunks.end(), per[g].begin(), per[g].end());
+	}
+	p->row_first[Kmax] = (unsigned)p->chunks.size();
+	p->ck_mtr = mtr_local; p->ck_first = first; p->ck_glob = mtr_global; p->ck_K = Kmax; p->ck_valid = true;
+	return true;
+}
+
 extern "C" int tspws_hip_partial_stacks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t mtr_local, size_t first,
                                         size_t mtr_global, unsigned Kmax, double *d_P, size_t ldP, void *stream)
 {
 	if (!p || !d_x || !d_P || !Kmax || !mtr_global) return fail(TSPWS_E_ARG, "partial_stacks: bad argument");
 	HIP_TRY(hipSetDevice(p->device));
-	const size_t N = p->N;
-	bool upload = false;
-	if (!p->ck_valid || p->ck_mtr != mtr_local || p->ck_first != first || p->ck_glob != mtr_global || p->ck_K != Kmax) {
-		// group of global trace i: floor(i*Kmax/mtr_global)   (ts_pws1f_lib.c:876)
-		p->chunks.clear();
-		p->row_first.assign(Kmax + 1, 0);
-		const unsigned clen = chunk_len_for(N, mtr_local);
-		std::vector<std::vector<Chunk>> per(Kmax);
-		size_t i = 0;
-		while (i < mtr_local) {
-			const size_t g = (size_t)floor((double)((first + i) * (size_t)Kmax) / (double)mtr_global);
-			size_t j = i + 1;
-			while (j < mtr_local && (size_t)floor((double)((first + j) * (size_t)Kmax) / (double)mtr_global) == g) j++;
-			for (size_t t = i; t < j; t += clen) {
-				Chunk c; c.t0 = t; c.count = (unsigned)std::min<size_t>(clen, j - t); c.row = (unsigned)g;
-				per[std::min<size_t>(g, Kmax - 1)].push_back(c);
-			}
-			i = j;
-		}
-		for (unsigned g = 0; g < Kmax; g++) {
-			p->row_first[g] = (unsigned)p->chunks.size();
-			p->chunks.insert(p->chunks.end(), per[g].begin(), per[g].end());
-		}
-		p->row_first[Kmax] = (unsigned)p->chunks.size();
-		p->ck_mtr = mtr_local; p->ck_first = first; p->ck_glob = mtr_global; p->ck_K = Kmax; p->ck_valid = true;
-		upload = true;
-	}
-	return run_chunks(p, d_x, ld, N, p->chunks, p->row_first, Kmax, d_P, ldP, S_(stream), upload);
+	const bool upload = build_group_chunks(p, mtr_local, first, mtr_global, Kmax);
+	return run_chunks(p, d_x, ld, p->N, p->chunks, p->row_first, Kmax, d_P, ldP, S_(stream), upload);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -690,20 +723,30 @@ static int forward_generic(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t
 }
 
 #include "fwd_poly.h"
+#include "fwd_lds.h"
 
 // Forward transform of ntr traces into the split-partial layout part[ntr][npart].
 template <typename TIn>
 static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double2 *d_part, hipStream_t st)
 {
-	const unsigned nb = (p->fwd_waves + 3) / 4;
-	if (ntr == 1) {
-		hipLaunchKernelGGL((k_fwd_poly<TIn, 1>), dim3(nb, 1), dim3(256), 0, st, d_x, ld, 1u, p->N, p->d_sc, p->S, p->d_w, d_part, p->npart,
-		                   p->fwd_waves);
-	} else {
-		for (size_t t0 = 0; t0 < ntr; t0 += 2 * 32768) {
-			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, 2 * 32768);
-			hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nb, (nt + 1) / 2), dim3(256), 0, st, d_x + t0 * ld, ld, nt, p->N, p->d_sc, p->S,
-			                   p->d_w, d_part + t0 * p->npart, p->npart, p->fwd_waves);
+	if (p->lds_blocks) {
+		for (size_t t0 = 0; t0 < ntr; t0 += 65535) {
+			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, 65535);
+			hipLaunchKernelGGL((k_fwd_lds<TIn>), dim3(p->lds_blocks, nt), dim3(256), FL_LDS_BYTES, st, d_x + t0 * ld, ld, p->N, p->d_sc, p->S,
+			                   p->d_w, d_part + t0 * p->npart, p->npart);
+		}
+	}
+	if (p->fwd_waves) {
+		const unsigned nb = (p->fwd_waves + 3) / 4;
+		if (ntr == 1) {
+			hipLaunchKernelGGL((k_fwd_poly<TIn, 1>), dim3(nb, 1), dim3(256), 0, st, d_x, ld, 1u, p->N, p->d_sc, p->S, p->d_w, d_part,
+			                   p->npart, p->fwd_waves);
+		} else {
+			for (size_t t0 = 0; t0 < ntr; t0 += 2 * 32768) {
+				const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, 2 * 32768);
+				hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nb, (nt + 1) / 2), dim3(256), 0, st, d_x + t0 * ld, ld, nt, p->N, p->d_sc,
+				                   p->S, p->d_w, d_part + t0 * p->npart, p->npart, p->fwd_waves);
+			}
 		}
 	}
 	HIP_TRY(hipGetLastError());
@@ -1103,6 +1146,135 @@ extern "C" int tspws_hip_stack_finish(tspws_hip_plan *pl, const t_tsPWS *p, size
 	double *x2 = (double *)v;
 	if ((rc = tspws_hip_inverse(pl, OUT, 2, x2, s))) return rc; // row 0 = ICWT(OUT), row 1 = ICWT(ST)
 	return tspws_hip_epilogue(d_ls, d_ts, x2 + pl->N, x2, pl->N, (unsigned)mtr_global, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// Whole call on one GPU, pipelined: the partial stacks are streamed group by group on the caller's stream
+// while a second stream transforms each finished group (forward CWT + phase accumulation are FP64-bound, the
+// streaming is HBM-bound, so they overlap), then weight / inverses / epilogue.  Same results as
+// stack_local + stack_finish (same kernels, same summation order).
+// ------------------------------------------------------------------------------------------
+static bool overlap_enabled()
+{
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("TSPWS_NO_OVERLAP"); v = (e && *e == '1') ? 0 : 1; }
+	return v == 1;
+}
+
+extern "C" int tspws_hip_profile_begin(tspws_hip_plan *pl, size_t max_calls)
+{
+	if (!pl) return fail(TSPWS_E_ARG, "profile_begin: NULL");
+	HIP_TRY(hipSetDevice(pl->device));
+	const size_t need = max_calls * 2;
+	while (pl->prof_ev.size() < need) {
+		hipEvent_t e;
+		HIP_TRY(hipEventCreate(&e));
+		pl->prof_ev.push_back(e);
+	}
+	pl->prof_used = 0;
+	return 0;
+}
+
+extern "C" int tspws_hip_profile_end(tspws_hip_plan *pl, double *mean_ms, size_t *ncalls)
+{
+	if (!pl || !mean_ms || !ncalls) return fail(TSPWS_E_ARG, "profile_end: NULL");
+	HIP_TRY(hipSetDevice(pl->device));
+	HIP_TRY(hipDeviceSynchronize());
+	double tot = 0;
+	const size_t n = pl->prof_used / 2;
+	for (size_t i = 0; i < n; i++) {
+		float ms = 0;
+		HIP_TRY(hipEventElapsedTime(&ms, pl->prof_ev[2 * i], pl->prof_ev[2 * i + 1]));
+		tot += ms;
+	}
+	*mean_ms = n ? tot / (double)n : 0.0;
+	*ncalls = n;
+	pl->prof_used = 0;
+	return 0;
+}
+
+extern "C" int tspws_hip_stack(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, float *d_ls, float *d_ts,
+                               void *s)
+{
+	if (!pl || !p || !d_x || !mtr) return fail(TSPWS_E_ARG, "stack: bad argument");
+	HIP_TRY(hipSetDevice(pl->device));
+	int rc;
+	if (!is_two_stage(p, mtr) || !overlap_enabled()) {
+		const bool prof0 = pl->prof_used + 2 <= pl->prof_ev.size();
+		if (prof0) HIP_TRY(hipEventRecord(pl->prof_ev[pl->prof_used], S_(s)));
+		if ((rc = tspws_hip_stack_local(pl, p, d_x, ld, mtr, 0, mtr, s))) return rc;
+		if (prof0) { HIP_TRY(hipEventRecord(pl->prof_ev[pl->prof_used + 1], S_(s))); pl->prof_used += 2; }
+		return tspws_hip_stack_finish(pl, p, mtr, d_ls, d_ts, s);
+	}
+	hipStream_t A = S_(s);
+	const unsigned K = p->Kmax;
+	const size_t N = pl->N, nc = pl->ncoef;
+	// ---- everything that may allocate happens before the first launch ----
+	if (!pl->aux) HIP_TRY(hipStreamCreateWithFlags(&pl->aux, hipStreamNonBlocking));
+	if (!pl->ev_done) HIP_TRY(hipEventCreateWithFlags(&pl->ev_done, hipEventDisableTiming));
+	while (pl->ev_grp.size() < (size_t)K + 1) {
+		hipEvent_t e;
+		HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		pl->ev_grp.push_back(e);
+	}
+	hipStream_t Bq = pl->aux;
+	const bool upload = build_group_chunks(pl, mtr, 0, mtr, K);
+	const size_t nck = pl->chunks.size(), ldpc = (N + 3) & ~(size_t)3;
+	void *v;
+	double *P; size_t nd;
+	if ((rc = tspws_hip_reduce_buffer(pl, p, mtr, &P, &nd))) return rc;
+	if ((rc = scratch(pl, SCR_TAB, nck * sizeof(Chunk) + (K + 1) * sizeof(unsigned), &v))) return rc;
+	Chunk *d_chunks = (Chunk *)v;
+	unsigned *d_rf = (unsigned *)((char *)v + nck * sizeof(Chunk));
+	if ((rc = scratch(pl, SCR_CHUNK, nck * ldpc * sizeof(double), &v))) return rc;
+	double *d_pc = (double *)v;
+	if ((rc = scratch(pl, SCR_PART, (size_t)K * pl->npart * sizeof(double2), &v))) return rc;
+	double2 *part = (double2 *)v;
+	if ((rc = scratch(pl, SCR_OUT, 6 * nc * sizeof(double), &v))) return rc;
+	double *OUT = (double *)v, *ST = OUT + 2 * nc, *PS = ST + 2 * nc;
+	if ((rc = scratch(pl, SCR_X2, 2 * N * sizeof(double), &v))) return rc;
+	double *x2 = (double *)v;
+	if (pl->inv_noct && (rc = scratch(pl, SCR_OBUF, (size_t)(pl->inv_noct + (pl->inv_ngeneric ? 1 : 0)) * 2 * N * sizeof(double), &v))) return rc;
+	if (upload) {
+		HIP_TRY(hipMemcpyAsync(d_chunks, pl->chunks.data(), nck * sizeof(Chunk), hipMemcpyHostToDevice, A));
+		HIP_TRY(hipMemcpyAsync(d_rf, pl->row_first.data(), (K + 1) * sizeof(unsigned), hipMemcpyHostToDevice, A));
+	}
+	// the aux stream must not start before earlier work on the caller's stream (e.g. a previous call's readers)
+	HIP_TRY(hipEventRecord(pl->ev_grp[K], A));
+	HIP_TRY(hipStreamWaitEvent(Bq, pl->ev_grp[K], 0));
+	const bool prof = pl->prof_used + 2 <= pl->prof_ev.size();
+	unsigned pipe_batch = 5;
+	if (const char *e = getenv("TSPWS_PIPE_BATCH")) pipe_batch = (unsigned)std::max(1, atoi(e));
+	const unsigned bx = (unsigned)((N + 1023) / 1024);
+	const bool vec = (N % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x & 15) == 0);
+	if (prof) HIP_TRY(hipEventRecord(pl->prof_ev[pl->prof_used], A));
+	for (unsigned g = 0; g < K; g++) {
+		const unsigned c0 = pl->row_first[g], c1 = pl->row_first[g + 1];
+		if (c1 > c0) {
+			if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, c1 - c0), dim3(256), 0, A, d_x, ld, N, d_chunks + c0, d_pc + (size_t)c0 * ldpc, ldpc);
+			else hipLaunchKernelGGL(k_partial<false>, dim3(bx, c1 - c0), dim3(256), 0, A, d_x, ld, N, d_chunks + c0, d_pc + (size_t)c0 * ldpc, ldpc);
+		}
+		hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((N + 255) / 256), 1), dim3(256), 0, A, (const double *)d_pc, ldpc, d_rf + g,
+		                   P + (size_t)g * N, N, N);
+		// hand finished groups to the transform stream in batches (a batch of traces shares the tap reads and
+		// fills the GPU better than single-trace launches)
+		if ((g + 1) % pipe_batch == 0 || g + 1 == K) {
+			const unsigned gb = (g / pipe_batch) * pipe_batch, nb = g + 1 - gb;
+			HIP_TRY(hipEventRecord(pl->ev_grp[g], A));
+			HIP_TRY(hipStreamWaitEvent(Bq, pl->ev_grp[g], 0));
+			if ((rc = forward_parts<double>(pl, P + (size_t)gb * N, nb, N, part + (size_t)gb * pl->npart, Bq))) return rc;
+			hipLaunchKernelGGL(k_accumulate_parts, dim3(pl->acc_blocks), dim3(256), 0, Bq, (const double2 *)(part + (size_t)gb * pl->npart),
+			                   pl->npart, pl->d_sc, pl->S, nb, (double2 *)ST, (double2 *)PS, gb == 0 ? 1 : 0);
+		}
+	}
+	if (prof) { HIP_TRY(hipEventRecord(pl->prof_ev[pl->prof_used + 1], A)); pl->prof_used += 2; }
+	if ((rc = tspws_hip_weight(pl, OUT, ST, PS, K, (unsigned)mtr, p->wu, p->unbiased, Bq))) return rc;
+	if ((rc = tspws_hip_inverse(pl, OUT, 2, x2, Bq))) return rc;
+	if ((rc = tspws_hip_epilogue(d_ls, d_ts, x2 + N, x2, N, (unsigned)mtr, Bq))) return rc;
+	HIP_TRY(hipEventRecord(pl->ev_done, Bq));
+	HIP_TRY(hipStreamWaitEvent(A, pl->ev_done, 0));
+	HIP_TRY(hipGetLastError());
+	return 0;
 }
 
 // ------------------------------------------------------------------------------------------
