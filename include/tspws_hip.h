@@ -155,6 +155,24 @@ int  tspws_hip_jackknife(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_
                          size_t mtr, const char *h_sel, unsigned C,
                          float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *stream);
 
+/* ---- random subsampling ---------------------------------------------------------------------- */
+/* Host: keep K of J traces at random with libc rand(), flipping whichever symbol is rarer.
+ * SubsamplingPlan, ts_pws1f_lib.c:355-383 (same rand() call order, so the same masks from the same state). */
+int  tspws_subsampling_plan(char *sel, size_t J, size_t K);
+/* M random subsamples of K = ceil(mtr * p->subsmpl_p) traces; d_ls_out / d_ts_out are [M][max] floats.
+ * Single-stage: tspws_subsmpl_float (:501-610); two-stage: TwoStage_subsmpl_float (:612-709). */
+int  tspws_hip_subsample(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_sigall, size_t ld, size_t mtr, unsigned M,
+                         float *d_ls_out, float *d_ts_out, void *stream);
+
+/* ---- convergence curves ------------------------------------------------------------------------ */
+/* Similarity / misfit of the stack of the first i+1 traces against a reference, for i = 0..mtr-1
+ * (ts_pws1f_lib.c:247-314, similarity :433-449, misfit :452-462).  d_ref_ts / d_ref_ls are [max] floats on the
+ * device (the caller passes in->reference for both, or the final tsPWS / ls); the four h_ arrays receive mtr doubles;
+ * d_*_steps, when not NULL, receive the [mtr][max] float stacks of every step. */
+int  tspws_hip_convergence(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_sigall, size_t ld, size_t mtr,
+                           const float *d_ref_ts, const float *d_ref_ls, double *h_ts_sim, double *h_ts_misfit,
+                           double *h_ls_sim, double *h_ls_misfit, float *d_ts_steps, float *d_ls_steps, void *stream);
+
 /* ---- synthetic ensembles for bench / tests ------------------------------------ */
 /* trace i = first+local, sample n: 0.2 sin(2pi(n-N/2)/200) exp(-((n-N/2)/(0.05N))^2/2) + U(-.5,.5) */
 int  tspws_hip_synth(float *d_sigall, size_t mtr, size_t N, size_t ld, uint64_t seed, size_t first, void *stream);

@@ -412,8 +412,78 @@ int orc_jackknife_plan(char *sel, const time_t *tm, size_t mtr, unsigned d, unsi
 	return 0;
 }
 
-/* Whole call.  ts_pws1f_lib.c:48-352 (main path, two-stage, unbiased,
- * jackknife; convergence / random subsampling are not on the hot path). */
+
+/* Convergence metrics.  similarity = normalised cross-correlation at lag 0, misfit = sum of squared
+ * differences.  ts_pws1f_lib.c:433-462 */
+static double similarity_of(const double *a, const float *b, size_t N)
+{
+	double y = 0, s = 0;
+	for (size_t n = 0; n < N; n++) y += a[n] * b[n];
+	for (size_t n = 0; n < N; n++) s += a[n] * a[n];
+	y /= sqrt(s);
+	s = 0;
+	for (size_t n = 0; n < N; n++) s += b[n] * b[n];
+	return y / sqrt(s);
+}
+
+static double misfit_of(const double *a, const float *b, size_t N)
+{
+	double y = 0;
+	for (size_t n = 0; n < N; n++) { const double e = a[n] - (double)b[n]; y += e * e; }
+	return y;
+}
+
+/* Random K-of-J selection with libc rand(), flipping the rarer symbol.  ts_pws1f_lib.c:355-383 */
+int orc_subsampling_plan(char *sel, size_t J, size_t K)
+{
+	if (!sel) return 1;
+	if (K > J) return 2;
+	size_t k = 0;
+	if (2 * K < J) {
+		memset(sel, 0, J);
+		while (k < K) { const size_t j = (size_t)rand() % J; if (!sel[j]) { k++; sel[j] = 1; } }
+	} else {
+		memset(sel, 1, J);
+		K = J - K;
+		while (k < K) { const size_t j = (size_t)rand() % J; if (sel[j]) { k++; sel[j] = 0; } }
+	}
+	return 0;
+}
+
+/* One masked two-stage replica: partial stacks of the selected traces (group by rank among the selected),
+ * stacks, weight(Kmax, K), inverse; time-domain linear stack.  Shared by the jackknife (:758-811) and the
+ * two-stage random subsampling (:642-691). */
+static size_t masked_two_stage(const orc_frame *f, const t_tsPWS *p, const float *sigall, size_t max, size_t mtr, const char *row,
+                               float *ts_out, float *ls_out)
+{
+	const size_t nc = orc_frame_ncoef(f);
+	const unsigned KM = p->Kmax;
+	cplx *y = malloc(nc * sizeof(cplx)), *st = malloc(nc * sizeof(cplx)), *ps = malloc(nc * sizeof(cplx)), *o = malloc(nc * sizeof(cplx));
+	double *P = calloc((size_t)KM * max, sizeof(double)), *xr = malloc(max * sizeof(double));
+	size_t K = 0, k = 0;
+	for (size_t i = 0; i < mtr; i++) if (row[i] == 1) K++;
+	for (size_t i = 0; i < mtr; i++) {
+		if (row[i] != 1) continue;
+		const size_t g = (size_t)floor((double)(k * KM) / (double)K);
+		double *pg = P + g * max;
+		const float *x = sigall + i * max;
+		for (size_t n = 0; n < max; n++) pg[n] += (double)x[n];
+		k++;
+	}
+	stacks_of_doubles(f, st, ps, y, P, max, KM);
+	weight(o, st, ps, nc, KM, (unsigned)K, p->wu, p->unbiased);
+	orc_inverse(f, (double *)o, xr);
+	for (size_t n = 0; n < max; n++) ts_out[n] = (float)(1. * xr[n]);
+	memcpy(xr, P, max * sizeof(double));
+	for (unsigned g = 1; g < KM; g++) for (size_t n = 0; n < max; n++) xr[n] += P[(size_t)g * max + n];
+	const double sc = 1. / K;
+	for (size_t n = 0; n < max; n++) ls_out[n] = (float)(xr[n] * sc);
+	free(y); free(st); free(ps); free(o); free(P); free(xr);
+	return K;
+}
+
+/* Whole call.  ts_pws1f_lib.c:48-352 (main path, two-stage, unbiased, convergence, random subsampling,
+ * jackknife). */
 int orc_tspws_main(t_tsPWS *p, t_tsPWS_out *out, t_data *in)
 {
 	if (!p || !out || !in) { printf("tspws_main: NULL input\n"); return -1; }
@@ -486,6 +556,89 @@ int orc_tspws_main(t_tsPWS *p, t_tsPWS_out *out, t_data *in)
 	/* epilogue :233-241 -- ls is a FLOAT division by the converted count */
 	for (size_t n = 0; n < nsamp; n++) out->ls[n] = (float)xb[n] / (unsigned)mtr;
 	for (size_t n = 0; n < nsamp; n++) out->tsPWS[n] = (float)xa[n];
+
+	/* convergence curves, :247-314 */
+	if (p->convergence) {
+		const float *ref_ts = in->reference ? in->reference : out->tsPWS;
+		const float *ref_ls = in->reference ? in->reference : out->ls;
+		double *xr = malloc((size_t)max * sizeof(double)), *P = malloc((size_t)(p->Kmax ? p->Kmax : 1) * max * sizeof(double));
+		memset(ST, 0, nc * sizeof(cplx));
+		memset(PS, 0, nc * sizeof(cplx));
+		float *steps = out->tsPWS_steps;
+		for (size_t i = 0; i < mtr; i++) {
+			const size_t Tr = i + 1;
+			unsigned K;
+			if (!p->Kmax || p->Kmax >= Tr) { /* incremental single-stage step, :835-863 */
+				K = (unsigned)Tr;
+				const float *x = sigall + i * (size_t)max;
+				for (size_t n = 0; n < nsamp; n++) xr[n] = (double)x[n];
+				orc_forward(f, xr, (double *)Y);
+				accumulate(ST, PS, Y, nc);
+			} else {
+				K = p->Kmax;
+				orc_partial_stacks(P, sigall, (size_t)max, Tr, K);
+				stacks_of_doubles(f, ST, PS, Y, P, (size_t)max, K);
+			}
+			weight(OUT, ST, PS, nc, K, (unsigned)Tr, p->wu, p->unbiased);
+			orc_inverse(f, (double *)OUT, xr);
+			out->tsPWS_sim[i] = similarity_of(xr, ref_ts, nsamp);
+			out->tsPWS_misfit[i] = misfit_of(xr, ref_ts, nsamp);
+			if (steps) { for (size_t n = 0; n < nsamp; n++) steps[n] = (float)xr[n]; steps += max; }
+		}
+		/* linear stack: running sum scaled by a FLOAT reciprocal and scaled back, :288-308 */
+		steps = out->ls_steps;
+		for (size_t n = 0; n < nsamp; n++) xr[n] = 0;
+		for (size_t i = 0; i < mtr; i++) {
+			const float *x = sigall + i * (size_t)max;
+			for (size_t n = 0; n < nsamp; n++) xr[n] += x[n];
+			const float inv = 1.0 / (i + 1);
+			for (size_t n = 0; n < nsamp; n++) xr[n] *= inv;
+			out->ls_sim[i] = similarity_of(xr, ref_ls, nsamp);
+			out->ls_misfit[i] = misfit_of(xr, ref_ls, nsamp);
+			if (steps) { for (size_t n = 0; n < nsamp; n++) steps[n] = (float)xr[n]; steps += max; }
+			for (size_t n = 0; n < nsamp; n++) xr[n] *= (i + 1);
+		}
+		free(xr); free(P);
+	}
+
+	/* random subsampling, :324-333 */
+	if (p->subsmpl_N > 0 && p->subsmpl_p > 0) {
+		const size_t K = (size_t)ceil((double)mtr * p->subsmpl_p);
+		const unsigned M = p->subsmpl_N;
+		char *sel = malloc((size_t)M * mtr);
+		if (!two_stage) { /* :501-610 */
+			for (unsigned m = 0; m < M; m++) orc_subsampling_plan(sel + (size_t)m * mtr, mtr, K);
+			cplx *st = calloc((size_t)M * nc, sizeof(cplx)), *ps = calloc((size_t)M * nc, sizeof(cplx));
+			double *xr = malloc((size_t)max * sizeof(double));
+			for (unsigned m = 0; m < M; m++) { memset(out->ls_subsmpl[m], 0, (size_t)max * sizeof(float)); memset(out->tsPWS_subsmpl[m], 0, (size_t)max * sizeof(float)); }
+			for (size_t i = 0; i < mtr; i++) {
+				const float *x = sigall + i * (size_t)max;
+				for (size_t n = 0; n < nsamp; n++) xr[n] = (double)x[n];
+				orc_forward(f, xr, (double *)Y);
+				for (unsigned m = 0; m < M; m++) {
+					if (sel[(size_t)m * mtr + i] != 1) continue;
+					float *l = out->ls_subsmpl[m];
+					for (size_t n = 0; n < nsamp; n++) l[n] += 1. * xr[n];   /* float accumulator */
+					accumulate(st + (size_t)m * nc, ps + (size_t)m * nc, Y, nc);
+				}
+			}
+			for (unsigned m = 0; m < M; m++) {
+				const float sc = 1. / K;
+				float *l = out->ls_subsmpl[m];
+				for (size_t n = 0; n < (size_t)max; n++) l[n] *= sc;
+				weight(OUT, st + (size_t)m * nc, ps + (size_t)m * nc, nc, (unsigned)K, (unsigned)K, p->wu, p->unbiased);
+				orc_inverse(f, (double *)OUT, xr);
+				for (size_t n = 0; n < nsamp; n++) out->tsPWS_subsmpl[m][n] = (float)(1. * xr[n]);
+			}
+			free(st); free(ps); free(xr);
+		} else { /* :612-709 (sequential here: the reference draws the masks inside an OpenMP loop) */
+			for (unsigned m = 0; m < M; m++) {
+				orc_subsampling_plan(sel, mtr, K);
+				masked_two_stage(f, p, sigall, (size_t)max, mtr, sel, out->tsPWS_subsmpl[m], out->ls_subsmpl[m]);
+			}
+		}
+		free(sel);
+	}
 
 	/* jackknife, :335-345 -> :719-831 (two-stage only; the single-stage variant
 	 * is an empty stub at :711-716) */

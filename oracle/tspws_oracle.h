@@ -31,6 +31,7 @@ void orc_accumulate(double *ST, double *PS, const double *Y, size_t ncoef);
 void orc_weight(double *OUT, const double *ST, const double *PS, size_t ncoef, unsigned K, unsigned M, double wu, int unbiased);
 void orc_partial_stacks(double *P, const float *sigall, size_t max, size_t mtr, unsigned Kmax);
 void orc_resolve(t_tsPWS *p, unsigned nsamp, float dt);
+int  orc_subsampling_plan(char *sel, size_t J, size_t K);
 int  orc_jackknife_plan(char *sel, const time_t *tm, size_t mtr, unsigned d, unsigned n, unsigned C);
 int  orc_tspws_main(t_tsPWS *p, t_tsPWS_out *out, t_data *in);
 

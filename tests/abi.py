@@ -93,39 +93,66 @@ def binomial(n, d):
     return math.comb(n, d)
 
 
-def run_main(lib_fn, params, traces, dt=1.0, beg=0.0, times=None):
+def srand(seed=1):
+    """Reset libc's rand(): the random-subsampling masks of the reference (and of this engine's host
+    side) come from rand(), so runs are comparable only from the same generator state."""
+    C.CDLL(None).srand(seed)
+
+
+def run_main(lib_fn, params, traces, dt=1.0, beg=0.0, times=None, reference=None):
     """Call a tspws_main-shaped entry point on a copy of `traces` (float32 [mtr][max]).
-    Returns dict(rc, ls, tsPWS, sigall, params, [jk_ls, jk_ts, jk_mtr])."""
+    Returns dict(rc, ls, tsPWS, sigall, params, [jk_ls, jk_ts, jk_mtr | sub_ls, sub_ts], [conv_*])."""
     x = np.ascontiguousarray(traces, dtype=np.float32).copy()
     mtr, mx = x.shape
     p = t_tsPWS.from_buffer_copy(params)
     out = t_tsPWS_out()
     ls = np.zeros(mx, np.float32)
     ts = np.zeros(mx, np.float32)
-    out.ls = ls.ctypes.data_as(C.POINTER(C.c_float))
-    out.tsPWS = ts.ctypes.data_as(C.POINTER(C.c_float))
+    fp = C.POINTER(C.c_float)
+    out.ls = ls.ctypes.data_as(fp)
+    out.tsPWS = ts.ctypes.data_as(fp)
     out.N, out.mtr = mx, (p.Nmax or mtr)
     keep = []
     res = {}
+    M = 0
     if p.jackknife_n and 0 < p.jackknife_d < p.jackknife_n:
-        M = binomial(p.jackknife_n, p.jackknife_d)
+        M, key = binomial(p.jackknife_n, p.jackknife_d), "jk"
+    elif p.subsmpl_N and 0 <= p.subsmpl_p <= 1:
+        M, key = p.subsmpl_N, "sub"
+    if M:
         out.M = M
         jl = np.zeros((M, mx), np.float32)
         jt = np.zeros((M, mx), np.float32)
         jm = np.zeros(M, np.uint32)
-        rows_l = (C.POINTER(C.c_float) * M)(*[jl[i].ctypes.data_as(C.POINTER(C.c_float)) for i in range(M)])
-        rows_t = (C.POINTER(C.c_float) * M)(*[jt[i].ctypes.data_as(C.POINTER(C.c_float)) for i in range(M)])
-        out.ls_subsmpl = C.cast(rows_l, C.POINTER(C.POINTER(C.c_float)))
-        out.tsPWS_subsmpl = C.cast(rows_t, C.POINTER(C.POINTER(C.c_float)))
+        rows_l = (fp * M)(*[jl[i].ctypes.data_as(fp) for i in range(M)])
+        rows_t = (fp * M)(*[jt[i].ctypes.data_as(fp) for i in range(M)])
+        out.ls_subsmpl = C.cast(rows_l, C.POINTER(fp))
+        out.tsPWS_subsmpl = C.cast(rows_t, C.POINTER(fp))
         out.mtr_subsmpl = jm.ctypes.data_as(C.POINTER(C.c_uint))
         keep += [rows_l, rows_t]
-        res.update(jk_ls=jl, jk_ts=jt, jk_mtr=jm)
+        res.update({key + "_ls": jl, key + "_ts": jt, key + "_mtr": jm})
+    if p.convergence:
+        n = out.mtr
+        conv = {k: np.zeros(n) for k in ("ls_sim", "tsPWS_sim", "ls_misfit", "tsPWS_misfit")}
+        dp = C.POINTER(C.c_double)
+        out.ls_sim, out.tsPWS_sim = conv["ls_sim"].ctypes.data_as(dp), conv["tsPWS_sim"].ctypes.data_as(dp)
+        out.ls_misfit, out.tsPWS_misfit = conv["ls_misfit"].ctypes.data_as(dp), conv["tsPWS_misfit"].ctypes.data_as(dp)
+        res.update({"conv_" + k: v for k, v in conv.items()})
+        if p.AllSteps:
+            sl = np.zeros((n, mx), np.float32)
+            st = np.zeros((n, mx), np.float32)
+            out.ls_steps, out.tsPWS_steps = sl.ctypes.data_as(fp), st.ctypes.data_as(fp)
+            res.update(conv_ls_steps=sl, conv_ts_steps=st)
     d = t_data()
-    d.sigall = x.ctypes.data_as(C.POINTER(C.c_float))
+    d.sigall = x.ctypes.data_as(fp)
     if times is not None:
         tarr = np.ascontiguousarray(times, dtype=np.int64)
         d.time = tarr.ctypes.data_as(C.POINTER(time_t))
         keep.append(tarr)
+    if reference is not None:
+        rarr = np.ascontiguousarray(reference, dtype=np.float32)
+        d.reference = rarr.ctypes.data_as(fp)
+        keep.append(rarr)
     d.hdr.max, d.hdr.mtr, d.hdr.dt, d.hdr.beg = mx, mtr, dt, beg
     rc = lib_fn(C.byref(p), C.byref(out), C.byref(d))
     res.update(rc=rc, ls=ls, tsPWS=ts, sigall=x, params=p)
@@ -168,6 +195,8 @@ def oracle():
         lib.orc_weight.argtypes = [vp, vp, vp, sz, u, u, d, i]
         lib.orc_partial_stacks.argtypes = [vp, vp, sz, sz, u]
         lib.orc_resolve.argtypes = [vp, u, C.c_float]
+        lib.orc_subsampling_plan.restype = i
+        lib.orc_subsampling_plan.argtypes = [vp, sz, sz]
         lib.orc_jackknife_plan.restype = i
         lib.orc_jackknife_plan.argtypes = [vp, vp, sz, u, u, u]
         lib.orc_tspws_main.restype = i

@@ -16,6 +16,8 @@ import glob
 import os
 import sys
 
+os.environ["OMP_NUM_THREADS"] = "1"  # the reference draws random-subsampling masks inside an OpenMP loop: keep the order fixed
+
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -112,21 +114,27 @@ def cwt_case(lib, name, params, x):
 
 
 PARAM_KEYS = ["type", "uni", "J", "V", "s0", "b0", "w0", "wu", "fmin", "Q", "cycle", "w0set", "lrm", "lVfix", "ls0fix",
-              "lb0fix", "fold", "unbiased", "jackknife_n", "jackknife_d", "Nmax", "Kmax"]
+              "lb0fix", "fold", "unbiased", "jackknife_n", "jackknife_d", "Nmax", "Kmax", "convergence", "AllSteps",
+              "subsmpl_N", "subsmpl_p"]
 
 
 def params_to_arrays(prefix, p):
     return {f"{prefix}/{k}": getattr(p, k) for k in PARAM_KEYS}
 
 
-def main_case(lib, name, params, traces, dt=1.0, beg=0.0, times=None):
-    r = abi.run_main(lib.tspws_main, params, traces, dt=dt, beg=beg, times=times)
+def main_case(lib, name, params, traces, dt=1.0, beg=0.0, times=None, reference=None):
+    abi.srand(1)
+    r = abi.run_main(lib.tspws_main, params, traces, dt=dt, beg=beg, times=times, reference=reference)
     assert r["rc"] == 0, (name, r["rc"])
     d = {f"{name}/ls": r["ls"], f"{name}/tsPWS": r["tsPWS"], f"{name}/dt": dt, f"{name}/beg": beg}
     d.update(params_to_arrays(f"{name}/in", params))
     d.update(params_to_arrays(f"{name}/out", r["params"]))
     if params.lrm or params.fold:
         d[f"{name}/sigall_after"] = r["sigall"]
+    for k in [k for k in r if k.startswith("conv_") or k.startswith("sub_")]:
+        d[f"{name}/{k}"] = r[k]
+    if reference is not None:
+        d[f"{name}/reference"] = np.asarray(reference, np.float32)
     if "jk_ls" in r:
         d.update({f"{name}/jk_ls": r["jk_ls"], f"{name}/jk_ts": r["jk_ts"], f"{name}/jk_mtr": r["jk_mtr"],
                   f"{name}/times": np.asarray(times, np.int64)})
@@ -202,6 +210,12 @@ def main():
         "jk_n4_d1": (P(Kmax=4, jackknife_n=4, jackknife_d=1), X, dict(times=times)),
         "jk_n5_d2": (P(Kmax=4, unbiased=1, jackknife_n=5, jackknife_d=2), X, dict(times=times)),
         "jk_mexhat": (P(type=-3, Kmax=2, jackknife_n=3, jackknife_d=1), X, dict(times=times)),
+        "conv_single_steps": (P(convergence=1, AllSteps=1), X, {}),
+        "conv_two_K4": (P(convergence=1, Kmax=4, unbiased=1), X, {}),
+        "conv_reference": (P(convergence=1, wu=1.0), X, dict(reference=X[3])),
+        "sub_single": (P(subsmpl_N=3, subsmpl_p=0.5), X, {}),
+        "sub_single_dense": (P(subsmpl_N=2, subsmpl_p=0.8, unbiased=1), X, {}),
+        "sub_two_K4": (P(subsmpl_N=3, subsmpl_p=0.6, Kmax=4, unbiased=1), X, {}),
     }
     mains = {"X": X, "Xodd": Xodd}
     inputs = {}

@@ -84,3 +84,15 @@ def test_example3_bin_twostage_and_jackknife(sac_list, golden):
     run_cli(sac_list, "list.txt", "osac=jk2", "TwoStage=4", "jackknife_n=4", "jackknife_d=1")
     r0 = abi.read_sac(sac_list / "ts_pws_jk2_subsmpl_0.sac")
     assert abi.relerr(r0["data"], want["jk_ts"][0]) < 2e-6 and r0["f"][40] == float(want["jk_mtr"][0])
+
+
+def test_convergence_and_subsampling_outputs(sac_list, golden):
+    g = golden["example32"]
+    run_cli(sac_list, "list.txt", "osac=cv", "convergence", "AllSteps", "subsmpl_N=2", "subsmpl_prob=0.5")
+    sim = np.fromfile(sac_list / "ts_pws_cv_convergence", "<f8")
+    mis = np.fromfile(sac_list / "ts_pws_cv_misfit", "<f8")
+    steps = np.fromfile(sac_list / "ts_pws_cv_steps", "<f4").reshape(32, 16501)
+    assert sim.shape == (32,) and abs(sim[-1] - 1.0) < 1e-6 and mis.shape == (32,) and mis[-1] < 1e-6 * mis[0]
+    assert abi.relerr(steps[-1], g["ex1/tsPWS"]) < 2e-6
+    s0 = abi.read_sac(sac_list / "ts_pws_cv_subsmpl_0.sac")
+    assert s0["i"][9] == 16501 and np.isfinite(s0["data"]).all() and s0["data"].any()

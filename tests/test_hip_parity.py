@@ -340,3 +340,41 @@ def test_full_size_properties(lib, torch):
     ls, ts = pl.stack(Xc)
     torch.cuda.synchronize()
     assert abi.relerr(ts.cpu().numpy(), ls.cpu().numpy()) < 1e-6
+
+
+# --------------------------------------------------------- convergence / random subsampling
+@pytest.mark.parametrize("kw", [dict(convergence=1, AllSteps=1), dict(convergence=1, Kmax=6, unbiased=1), dict(convergence=1, type=-3, wu=1.0)])
+def test_convergence_vs_oracle(lib, kw):
+    X = abi.synth_traces(40, 4096, seed=12)
+    p = abi.default_params(**kw)
+    a = abi.run_main(lib.tspws_main, p, X)
+    b = abi.run_main(abi.oracle().orc_tspws_main, p, X)
+    assert a["rc"] == 0
+    for k in ("conv_ls_sim", "conv_tsPWS_sim"):
+        assert np.max(np.abs(a[k] - b[k])) < 1e-9, k
+    # the last ts-PWS step is the full stack: similarity with its own float-rounded copy ~ 1 (the linear curve compares
+    # the time-domain mean with the frame-filtered ls, so it does not reach 1)
+    assert abs(a["conv_tsPWS_sim"][-1] - 1.0) < 1e-6
+    for k in ("conv_ls_misfit", "conv_tsPWS_misfit"):
+        assert np.max(np.abs(a[k] - b[k])) <= 1e-7 * np.max(np.abs(b[k])) + 1e-18, k
+    if "conv_ts_steps" in a:
+        assert abi.relerr(a["conv_ts_steps"], b["conv_ts_steps"]) < TOL32
+        assert abi.relerr(a["conv_ls_steps"], b["conv_ls_steps"]) < TOL32
+        np.testing.assert_array_equal(a["conv_ts_steps"][-1], a["tsPWS"])
+
+
+@pytest.mark.parametrize("kw", [dict(subsmpl_N=4, subsmpl_p=0.3), dict(subsmpl_N=3, subsmpl_p=0.7, Kmax=5, unbiased=1),
+                                dict(subsmpl_N=2, subsmpl_p=1.0, type=-3)])
+def test_random_subsampling_vs_oracle(lib, kw):
+    X = abi.synth_traces(50, 4096, seed=13)
+    p = abi.default_params(**kw)
+    abi.srand(7)
+    a = abi.run_main(lib.tspws_main, p, X)
+    abi.srand(7)
+    b = abi.run_main(abi.oracle().orc_tspws_main, p, X)
+    assert a["rc"] == 0
+    for m in range(kw["subsmpl_N"]):
+        assert abi.relerr(a["sub_ls"][m], b["sub_ls"][m]) < TOL32, m
+        assert abi.relerr(a["sub_ts"][m], b["sub_ts"][m]) < TOL32, m
+    if kw["subsmpl_p"] == 1.0 and not kw.get("Kmax"):  # every trace kept: each subsample is the full single-stage stack
+        assert abi.relerr(a["sub_ts"][0], a["tsPWS"]) < TOL32

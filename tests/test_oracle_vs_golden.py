@@ -93,6 +93,9 @@ def check_main(fn, g, name, tol):
     kw = dict(dt=float(g[f"{name}/dt"]), beg=float(g[f"{name}/beg"]))
     if f"{name}/times" in g.files:
         kw["times"] = g[f"{name}/times"]
+    if f"{name}/reference" in g.files:
+        kw["reference"] = g[f"{name}/reference"]
+    abi.srand(1)  # random-subsampling masks come from libc rand()
     r = abi.run_main(fn, p, _case_input(g, name), **kw)
     assert r["rc"] == 0, name
     assert abi.relerr(r["ls"], g[f"{name}/ls"]) < tol, name
@@ -106,6 +109,20 @@ def check_main(fn, g, name, tol):
         for c in range(len(r["jk_mtr"])):
             assert abi.relerr(r["jk_ls"][c], g[f"{name}/jk_ls"][c]) < tol, (name, c)
             assert abi.relerr(r["jk_ts"][c], g[f"{name}/jk_ts"][c]) < tol, (name, c)
+    if f"{name}/sub_ls" in g.files:
+        for c in range(g[f"{name}/sub_ls"].shape[0]):
+            assert abi.relerr(r["sub_ls"][c], g[f"{name}/sub_ls"][c]) < tol, (name, c)
+            assert abi.relerr(r["sub_ts"][c], g[f"{name}/sub_ts"][c]) < tol, (name, c)
+    if f"{name}/conv_ls_sim" in g.files:
+        # similarity curves are O(1); misfits are sums of squares of float-rounded references: compare relatively
+        for k in ("ls_sim", "tsPWS_sim"):
+            assert np.max(np.abs(r["conv_" + k] - g[f"{name}/conv_{k}"])) < 1e-9, (name, k)
+        for k in ("ls_misfit", "tsPWS_misfit"):
+            want = g[f"{name}/conv_{k}"]
+            assert np.max(np.abs(r["conv_" + k] - want)) <= 1e-7 * np.max(np.abs(want)) + 1e-18, (name, k)
+        if f"{name}/conv_ts_steps" in g.files:
+            assert abi.relerr(r["conv_ts_steps"], g[f"{name}/conv_ts_steps"]) < tol, name
+            assert abi.relerr(r["conv_ls_steps"], g[f"{name}/conv_ls_steps"]) < tol, name
     return r
 
 

@@ -62,7 +62,7 @@ static void usage(void)
 	     "  rm  fold  uni  verbose  unbiased                 TwoStage[=10]   two-stage stack\n"
 	     "  jackknife_n= jackknife_d=   (TwoStage only)      obin   replicas to one msacs file\n"
 	     "  Nmax=              use the first Nmax traces     osac=X kinst=S  output naming / header\n"
-	     "  convergence[=ref.sac] AllSteps subsmpl_N= subsmpl_prob=   accepted; not on the HIP path yet\n"
+	     "  convergence[=ref.sac] AllSteps   convergence curves   subsmpl_N= subsmpl_prob=   random subsampling\n"
 	     "OUTPUT: tl[_X].sac (linear stack), ts_pws[_X].sac (ts-PWS), *_subsmpl_<m>.sac replicas.\n"
 	     "Device: environment variable TSPWS_DEVICE (default 0).\n");
 }
@@ -289,15 +289,35 @@ int main(int argc, char *argv[])
 	out.ls = (float *)calloc(max, sizeof(float));
 	out.tsPWS = (float *)calloc(max, sizeof(float));
 	if (!out.ls || !out.tsPWS) { printf("main: Out of memory\n"); return 4; }
-	if (p.convergence || p.subsmpl_N) {
-		printf("ts_pws: convergence curves / random subsampling are not on the MI355X path yet; ignored.\n");
-		p.convergence = 0; p.subsmpl_N = 0; p.subsmpl_p = 0; p.fileconv = NULL;
+	if (p.convergence && p.fileconv) { /* alternative reference trace, :287-305 */
+		sac_header rh;
+		int rn = 0;
+		in.reference = (float *)calloc(max, sizeof(float));
+		if (!in.reference || sac_read(p.fileconv, &rh, in.reference, (int)max, &rn) || rn != (int)max) {
+			if (in.reference && rn != (int)max) printf("The reference for convergence has a different length (%d:%d)\n", (int)max, rn);
+			free(in.reference); in.reference = NULL; p.fileconv = NULL;
+		}
+	}
+	if (p.convergence) { /* :233-243 */
+		out.ls_sim = (double *)malloc(in.hdr.mtr * sizeof(double)); out.tsPWS_sim = (double *)malloc(in.hdr.mtr * sizeof(double));
+		out.ls_misfit = (double *)malloc(in.hdr.mtr * sizeof(double)); out.tsPWS_misfit = (double *)malloc(in.hdr.mtr * sizeof(double));
+		if (!out.ls_sim || !out.tsPWS_sim || !out.ls_misfit || !out.tsPWS_misfit) { printf("main: Out of memory\n"); return 4; }
+		if (p.AllSteps) {
+			out.ls_steps = (float *)malloc((size_t)in.hdr.mtr * max * sizeof(float));
+			out.tsPWS_steps = (float *)malloc((size_t)in.hdr.mtr * max * sizeof(float));
+			if (!out.ls_steps || !out.tsPWS_steps) { printf("main: Out of memory\n"); return 4; }
+		}
 	}
 	if (p.jackknife_n) { /* :247-252 */
+		p.subsmpl_N = 0; p.subsmpl_p = 0;
 		if (p.jackknife_d == 0 || p.jackknife_d >= p.jackknife_n) { p.jackknife_d = 0; p.jackknife_n = 0; }
 		else out.M = binomial(p.jackknife_n, p.jackknife_d);
 	}
-	if (p.jackknife_n) {
+	if (p.subsmpl_N) { /* :254-258 */
+		if (p.subsmpl_p < 0 || p.subsmpl_p > 1) { p.subsmpl_N = 0; p.subsmpl_p = 0; }
+		else out.M = p.subsmpl_N;
+	}
+	if (p.jackknife_n || p.subsmpl_N) {
 		out.mtr_subsmpl = (unsigned *)calloc(out.M, sizeof(unsigned));
 		out.ls_subsmpl = (float **)calloc(out.M, sizeof(float *));
 		out.tsPWS_subsmpl = (float **)calloc(out.M, sizeof(float *));
@@ -305,6 +325,8 @@ int main(int argc, char *argv[])
 		if (!out.mtr_subsmpl || !out.ls_subsmpl || !out.tsPWS_subsmpl || !a || !b) { printf("main: Out of memory\n"); return 4; }
 		for (unsigned m = 0; m < out.M; m++) { out.ls_subsmpl[m] = a + (size_t)m * max; out.tsPWS_subsmpl[m] = b + (size_t)m * max; }
 	}
+
+	if (p.subsmpl_N) for (unsigned i = 1; i < out.M; i++) out.mtr_subsmpl[i] = (unsigned)(out.mtr * p.subsmpl_p); /* :277 (entry 0 stays 0) */
 
 	er = tspws_main(&p, &out, &in);
 
@@ -326,7 +348,21 @@ int main(int argc, char *argv[])
 		if (tag) snprintf(name, sizeof name, "ts_pws_%s.sac", tag); else strcpy(name, "ts_pws.sac");
 		write_sac(name, out.tsPWS + first, &hdr, p.lkinst ? p.kinst : "ts_pws", (float)out.mtr);
 		if (p.verbose) printf("  ts-PWS:       %s\n", name);
-		if (p.jackknife_n) {
+		if (p.convergence) { /* raw double / float dumps, :354-396 */
+			const char *t = tag ? tag : "";
+			const struct { const char *pre, *suf; const void *buf; size_t bytes; } dumps[] = {
+				{"ts_pws_", "_convergence", out.tsPWS_sim, out.mtr * sizeof(double)}, {"tl_", "_convergence", out.ls_sim, out.mtr * sizeof(double)},
+				{"ts_pws_", "_misfit", out.tsPWS_misfit, out.mtr * sizeof(double)}, {"tl_", "_misfit", out.ls_misfit, out.mtr * sizeof(double)},
+				{"ts_pws_", "_steps", out.tsPWS_steps, (size_t)out.mtr * out.N * sizeof(float)}, {"tl_", "_steps", out.ls_steps, (size_t)out.mtr * out.N * sizeof(float)},
+			};
+			for (size_t j = 0; j < sizeof dumps / sizeof dumps[0]; j++) {
+				if (!dumps[j].buf) continue;
+				snprintf(name, sizeof name, "%s%s%s", dumps[j].pre, t, dumps[j].suf);
+				FILE *f = fopen(name, "wb");
+				if (f) { fwrite(dumps[j].buf, 1, dumps[j].bytes, f); fclose(f); }
+			}
+		}
+		if (p.jackknife_n || p.subsmpl_N) {
 			char sub[1100];
 			if (tag) snprintf(sub, sizeof sub, "_%s_subsmpl", tag); else strcpy(sub, "_subsmpl");
 			if (p.obin) {
@@ -346,6 +382,7 @@ int main(int argc, char *argv[])
 	if (out.ls_subsmpl) { free(out.ls_subsmpl[0]); free(out.tsPWS_subsmpl[0]); }
 	free(out.ls_subsmpl); free(out.tsPWS_subsmpl); free(out.mtr_subsmpl);
 	free(out.ls); free(out.tsPWS);
-	free(in.sigall); free(in.time); free(in.lag0);
+	free(out.ls_sim); free(out.tsPWS_sim); free(out.ls_misfit); free(out.tsPWS_misfit); free(out.ls_steps); free(out.tsPWS_steps);
+	free(in.sigall); free(in.time); free(in.lag0); free(in.reference);
 	return er; /* the reference returns 0 even when tspws_main failed (:430); a non-zero status is more useful */
 }

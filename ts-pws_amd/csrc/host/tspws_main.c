@@ -9,10 +9,8 @@
  *
  * Covered: fold (:71-88), parameter resolution (:91-124), mean removal
  * (:159-169), single- and two-stage stacks (:194-242), biased / unbiased
- * weighting (:226-228), two-stage jackknife (:335-345).
- * Not yet on the device path ("next" rows): convergence curves
- * (:247-314) and random subsampling (:324-333); requesting them prints a notice
- * and leaves their outputs untouched.
+ * weighting (:226-228), convergence curves (:247-314), random subsampling
+ * (:324-333), two-stage jackknife (:335-345).
  */
 #include <math.h>
 #include <stdio.h>
@@ -71,7 +69,7 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 	}
 
 	tspws_hip_plan *plan = NULL;
-	float *d_sig = NULL, *d_out = NULL, *d_jk = NULL;
+	float *d_sig = NULL, *d_out = NULL, *d_jk = NULL, *d_ref = NULL, *d_steps_ts = NULL, *d_steps_ls = NULL;
 	char *sel = NULL;
 	float *stage = NULL;
 	const size_t ld = (size_t)max;
@@ -100,10 +98,37 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 	TRY(tspws_hip_download(out->ls, d_out, ld * sizeof(float), NULL));
 	TRY(tspws_hip_download(out->tsPWS, d_out + ld, ld * sizeof(float), NULL));
 
-	if (tspws->convergence)
-		printf("tspws_main: convergence curves are not on the HIP path yet; outputs left untouched.\n");
-	if (tspws->subsmpl_N > 0 && tspws->subsmpl_p > 0)
-		printf("tspws_main: random subsampling is not on the HIP path yet; outputs left untouched.\n");
+	/* convergence curves, :247-314 */
+	if (tspws->convergence && out->ls_sim && out->tsPWS_sim && out->ls_misfit && out->tsPWS_misfit) {
+		const float *d_ref_ts = d_out + ld, *d_ref_ls = d_out;
+		if (in->reference) { /* alternative reference trace for both curves (:277, :298) */
+			TRY(tspws_hip_alloc((void **)&d_ref, ld * sizeof(float), dev));
+			TRY(tspws_hip_upload(d_ref, in->reference, ld * sizeof(float), NULL));
+			d_ref_ts = d_ref_ls = d_ref;
+		}
+		if (out->tsPWS_steps) TRY(tspws_hip_alloc((void **)&d_steps_ts, mtr * ld * sizeof(float), dev));
+		if (out->ls_steps) TRY(tspws_hip_alloc((void **)&d_steps_ls, mtr * ld * sizeof(float), dev));
+		TRY(tspws_hip_convergence(plan, tspws, d_sig, ld, mtr, d_ref_ts, d_ref_ls, out->tsPWS_sim, out->tsPWS_misfit, out->ls_sim,
+		                          out->ls_misfit, d_steps_ts, d_steps_ls, NULL));
+		if (d_steps_ts) TRY(tspws_hip_download(out->tsPWS_steps, d_steps_ts, mtr * ld * sizeof(float), NULL));
+		if (d_steps_ls) TRY(tspws_hip_download(out->ls_steps, d_steps_ls, mtr * ld * sizeof(float), NULL));
+	}
+
+	/* random subsampling, :324-333 */
+	if (tspws->subsmpl_N > 0 && tspws->subsmpl_p > 0 && out->ls_subsmpl && out->tsPWS_subsmpl) {
+		const unsigned M = tspws->subsmpl_N;
+		TRY(tspws_hip_alloc((void **)&d_jk, 2 * (size_t)M * ld * sizeof(float), dev));
+		TRY(tspws_hip_subsample(plan, tspws, d_sig, ld, mtr, M, d_jk, d_jk + (size_t)M * ld, NULL));
+		stage = (float *)malloc(2 * (size_t)M * ld * sizeof(float));
+		if (!stage) { rc = TSPWS_E_NOMEM; goto done; }
+		TRY(tspws_hip_download(stage, d_jk, 2 * (size_t)M * ld * sizeof(float), NULL));
+		for (unsigned m = 0; m < M; m++) {
+			memcpy(out->ls_subsmpl[m], stage + (size_t)m * ld, ld * sizeof(float));
+			memcpy(out->tsPWS_subsmpl[m], stage + ((size_t)M + m) * ld, ld * sizeof(float));
+		}
+		free(stage); stage = NULL;
+		tspws_hip_free(d_jk); d_jk = NULL;
+	}
 
 	if (tspws->jackknife_n > 0 && tspws->jackknife_d > 0 && tspws->Kmax && tspws->Kmax <= mtr) {
 		const unsigned C = out->M;
@@ -130,6 +155,9 @@ done:
 	if (rc) printf("tspws_main: HIP path failed (%d: %s)\n", rc, tspws_hip_last_error());
 	free(stage);
 	free(sel);
+	tspws_hip_free(d_steps_ls);
+	tspws_hip_free(d_steps_ts);
+	tspws_hip_free(d_ref);
 	tspws_hip_free(d_jk);
 	tspws_hip_free(d_out);
 	tspws_hip_free(d_sig);

@@ -77,7 +77,7 @@ struct Chunk { // one streaming work item of the partial-stack kernel
 	unsigned row;          // destination row (group / class)
 };
 
-enum { SCR_Y = 0, SCR_PART, SCR_OBUF, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_N };
+enum { SCR_Y = 0, SCR_PART, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_N };
 
 struct tspws_hip_plan {
 	int device = 0, type = -1;
@@ -1331,11 +1331,22 @@ __global__ void __launch_bounds__(256) k_jk_linear(const double *__restrict__ P,
 	out[n] = (float)(acc * invK);
 }
 
+static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, const char *h_sel, unsigned C,
+                            float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s);
+
 extern "C" int tspws_hip_jackknife(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, const char *h_sel,
                                    unsigned C, float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s)
 {
 	if (!pl || !p || !d_x || !h_sel || !d_ls_out || !d_ts_out || !h_mtr_out) return fail(TSPWS_E_ARG, "jackknife: NULL");
 	if (!is_two_stage(p, mtr) || !C) return 0; // single-stage variant is an empty stub in the reference (:711-716)
+	return masked_two_stage(pl, p, d_x, ld, mtr, h_sel, C, d_ls_out, d_ts_out, h_mtr_out, s);
+}
+
+// All C masked two-stage replicas from ONE pass over the traces (shared by the jackknife and the two-stage
+// random subsampling, whose per-replica bodies are identical in the reference: :758-811 and :642-691).
+static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, const char *h_sel, unsigned C,
+                            float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s)
+{
 	HIP_TRY(hipSetDevice(pl->device));
 	hipStream_t st = S_(s);
 	const unsigned KM = p->Kmax;
@@ -1420,6 +1431,242 @@ extern "C" int tspws_hip_jackknife(tspws_hip_plan *pl, const t_tsPWS *p, const f
 	}
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st)); // host tables above go out of scope
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// random subsampling (SubsamplingPlan :355-383, tspws_subsmpl_float :501-610, TwoStage_subsmpl_float :612-709)
+// ------------------------------------------------------------------------------------------
+extern "C" int tspws_subsampling_plan(char *sel, size_t J, size_t K)
+{
+	if (!sel) return 1;
+	if (K > J) return 2;
+	size_t k = 0;
+	if (2 * K < J) { // fewer ones than zeros: switch ones on
+		memset(sel, 0, J);
+		while (k < K) { const size_t j = (size_t)rand() % J; if (!sel[j]) { k++; sel[j] = 1; } }
+	} else {         // otherwise switch zeros on
+		memset(sel, 1, J);
+		K = J - K;
+		while (k < K) { const size_t j = (size_t)rand() % J; if (sel[j]) { k++; sel[j] = 0; } }
+	}
+	return 0;
+}
+
+// ST_m += Y_b, PS_m += Y_b/|Y_b| for every mask m that contains trace b; one thread per coefficient, the
+// (<= 8) traces of the batch are normalised once and reused for all masks.
+__global__ void __launch_bounds__(256) k_accumulate_masked(const double2 *__restrict__ part, size_t npart, const ScaleDesc *__restrict__ sc,
+                                                           unsigned S, size_t ncoef, unsigned ntr, const char *__restrict__ sel, size_t mtr,
+                                                           size_t t0, unsigned M, double2 *__restrict__ ST, double2 *__restrict__ PS)
+{
+	unsigned lo = 0, hi = S;
+	while (hi - lo > 1) {
+		const unsigned mid = (lo + hi) >> 1;
+		if (sc[mid].acc_off <= blockIdx.x) lo = mid; else hi = mid;
+	}
+	const unsigned Ns = sc[lo].Ns, nsplit = sc[lo].nsplit;
+	const unsigned k = (blockIdx.x - sc[lo].acc_off) * 256 + threadIdx.x;
+	if (k >= Ns) return;
+	const size_t i = sc[lo].coef_off + k;
+	const double2 *p0 = part + sc[lo].part_off + k;
+	double2 v[8], u[8];
+#pragma unroll
+	for (int b = 0; b < 8; b++) {
+		v[b] = make_double2(0, 0); u[b] = make_double2(0, 0);
+		if ((unsigned)b < ntr) {
+			const double2 *p = p0 + (size_t)b * npart;
+			double2 a = p[0];
+			for (unsigned sp = 1; sp < nsplit; sp++) { const double2 t = p[(size_t)sp * Ns]; a.x += t.x; a.y += t.y; }
+			v[b] = a;
+			add_unit_phasor(u[b], a);
+		}
+	}
+	for (unsigned m = 0; m < M; m++) {
+		const char *row = sel + (size_t)m * mtr + t0;
+		double2 st = ST[(size_t)m * ncoef + i], ps = PS[(size_t)m * ncoef + i];
+		bool any = false;
+#pragma unroll
+		for (int b = 0; b < 8; b++)
+			if ((unsigned)b < ntr && row[b] == 1) { st.x += v[b].x; st.y += v[b].y; ps.x += u[b].x; ps.y += u[b].y; any = true; }
+		if (any) { ST[(size_t)m * ncoef + i] = st; PS[(size_t)m * ncoef + i] = ps; }
+	}
+}
+
+// time-domain linear stacks of the subsamples with the reference's FLOAT accumulator, traces in order
+// (ts_pws1f_lib.c:538-542), then the float scale W/K (:579-583).  grid.y = mask
+__global__ void __launch_bounds__(256) k_sub_linear(const float *__restrict__ x, size_t ld, size_t N, size_t mtr, const char *__restrict__ sel,
+                                                    float scale, float *__restrict__ out)
+{
+	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (n >= N) return;
+	const char *row = sel + (size_t)blockIdx.y * mtr;
+	float acc = 0.f;
+	for (size_t i = 0; i < mtr; i++)
+		if (row[i] == 1) acc = (float)((double)acc + (double)x[i * ld + n]);
+	out[(size_t)blockIdx.y * N + n] = acc * scale;
+}
+
+extern "C" int tspws_hip_subsample(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, unsigned M,
+                                   float *d_ls_out, float *d_ts_out, void *s)
+{
+	if (!pl || !p || !d_x || !d_ls_out || !d_ts_out) return fail(TSPWS_E_ARG, "subsample: NULL");
+	if (!M || !mtr) return 0;
+	HIP_TRY(hipSetDevice(pl->device));
+	hipStream_t st = S_(s);
+	const size_t K = (size_t)ceil((double)mtr * p->subsmpl_p);
+	std::vector<char> sel((size_t)M * mtr);
+	for (unsigned m = 0; m < M; m++) tspws_subsampling_plan(sel.data() + (size_t)m * mtr, mtr, K); // same rand() order as the reference
+	if (is_two_stage(p, mtr)) {
+		std::vector<unsigned> cnt(M);
+		return masked_two_stage(pl, p, d_x, ld, mtr, sel.data(), M, d_ls_out, d_ts_out, cnt.data(), s);
+	}
+	const size_t N = pl->N, nc = pl->ncoef;
+	int rc;
+	void *v;
+	if ((rc = scratch(pl, SCR_SEL, (size_t)M * mtr, &v))) return rc;
+	char *d_sel = (char *)v;
+	HIP_TRY(hipMemcpyAsync(d_sel, sel.data(), (size_t)M * mtr, hipMemcpyHostToDevice, st));
+	if ((rc = scratch(pl, SCR_SUBST, (size_t)M * nc * 2 * sizeof(double2), &v))) return rc;
+	double2 *STm = (double2 *)v, *PSm = STm + (size_t)M * nc;
+	HIP_TRY(hipMemsetAsync(STm, 0, (size_t)M * nc * 2 * sizeof(double2), st));
+	if ((rc = scratch(pl, SCR_PART, 8 * pl->npart * sizeof(double2), &v))) return rc;
+	double2 *part = (double2 *)v;
+	for (size_t t0 = 0; t0 < mtr; t0 += 8) {
+		const unsigned nb = (unsigned)std::min<size_t>(8, mtr - t0);
+		if ((rc = forward_parts<float>(pl, d_x + t0 * ld, nb, ld, part, st))) return rc;
+		hipLaunchKernelGGL(k_accumulate_masked, dim3(pl->acc_blocks), dim3(256), 0, st, (const double2 *)part, pl->npart, pl->d_sc, pl->S, nc,
+		                   nb, d_sel, mtr, t0, M, STm, PSm);
+	}
+	const float scale = (float)(1. / (double)K); // fa1 = W[m]/K with W = 1 (:580)
+	hipLaunchKernelGGL(k_sub_linear, dim3((unsigned)((N + 255) / 256), M), dim3(256), 0, st, d_x, ld, N, mtr, d_sel, scale, d_ls_out);
+	if ((rc = scratch(pl, SCR_JKOUT, (2 * nc + N) * sizeof(double), &v))) return rc;
+	double *OUT = (double *)v, *xr = OUT + 2 * nc;
+	for (unsigned m = 0; m < M; m++) {
+		if ((rc = tspws_hip_weight(pl, OUT, (double *)(STm + (size_t)m * nc), (double *)(PSm + (size_t)m * nc), (unsigned)K, (unsigned)K, p->wu,
+		                           p->unbiased, s))) return rc;
+		if ((rc = tspws_hip_inverse(pl, OUT, 1, xr, s))) return rc;
+		if ((rc = tspws_hip_epilogue(nullptr, d_ts_out + (size_t)m * N, nullptr, xr, N, 1, s))) return rc;
+	}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(st)); // `sel` goes out of scope
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// convergence curves (ts_pws1f_lib.c:247-314, similarity :433-449, misfit :452-462)
+// ------------------------------------------------------------------------------------------
+// out[0] = sum d*r, out[1] = sum d*d, out[2] = sum (d-r)^2, out[3] = sum r*r ; one workgroup, fixed order
+__global__ void __launch_bounds__(1024) k_dot4(const double *__restrict__ d, const float *__restrict__ r, size_t N, double *__restrict__ out)
+{
+	__shared__ double red[16][4];
+	double a = 0, b = 0, c = 0, e = 0;
+	for (size_t n = threadIdx.x; n < N; n += 1024) {
+		const double dv = d[n], rv = (double)r[n], df = dv - rv;
+		a = fma(dv, rv, a); b = fma(dv, dv, b); c = fma(df, df, c); e = fma(rv, rv, e);
+	}
+	a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); e = wave_sum(e);
+	if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a; red[threadIdx.x >> 6][1] = b; red[threadIdx.x >> 6][2] = c; red[threadIdx.x >> 6][3] = e; }
+	__syncthreads();
+	if (threadIdx.x < 4) {
+		double t = 0;
+		for (int w = 0; w < 16; w++) t += red[w][threadIdx.x];
+		out[threadIdx.x] = t;
+	}
+}
+
+// running linear stack: d += x_i; d *= (float)(1/(i+1)); metrics; d *= (i+1)   (:288-308, literal FLOAT reciprocal)
+// every workgroup writes its partial sums of the three metrics per step; k_conv_lin_reduce adds them in order
+__global__ void __launch_bounds__(256) k_conv_linear(const float *__restrict__ x, size_t ld, size_t N, size_t mtr, const float *__restrict__ ref,
+                                                     double *__restrict__ partial, float *__restrict__ steps)
+{
+	__shared__ double red[4][3];
+	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+	const bool live = n < N;
+	const double rv = live ? (double)ref[n] : 0.0;
+	double d = 0;
+	for (size_t i = 0; i < mtr; i++) {
+		if (live) d += (double)x[i * ld + n];
+		const float inv = (float)(1.0 / (double)(i + 1));
+		d *= (double)inv;
+		const double df = d - rv;
+		double a = live ? d * rv : 0.0, b = live ? d * d : 0.0, c = live ? df * df : 0.0;
+		a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+		if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a; red[threadIdx.x >> 6][1] = b; red[threadIdx.x >> 6][2] = c; }
+		__syncthreads();
+		if (threadIdx.x < 3)
+			partial[((size_t)blockIdx.x * mtr + i) * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+		__syncthreads();
+		if (steps && live) steps[i * N + n] = (float)d;
+		d *= (double)(i + 1);
+	}
+}
+
+__global__ void __launch_bounds__(256) k_conv_lin_reduce(const double *__restrict__ partial, unsigned nblocks, size_t mtr, double *__restrict__ out)
+{
+	const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; // index into [mtr][3]
+	if (j >= mtr * 3) return;
+	double t = 0;
+	for (unsigned b = 0; b < nblocks; b++) t += partial[(size_t)b * mtr * 3 + j];
+	out[j] = t;
+}
+
+extern "C" int tspws_hip_convergence(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, const float *d_ref_ts,
+                                     const float *d_ref_ls, double *h_ts_sim, double *h_ts_misfit, double *h_ls_sim, double *h_ls_misfit,
+                                     float *d_ts_steps, float *d_ls_steps, void *s)
+{
+	if (!pl || !p || !d_x || !d_ref_ts || !d_ref_ls || !h_ts_sim || !h_ts_misfit || !h_ls_sim || !h_ls_misfit)
+		return fail(TSPWS_E_ARG, "convergence: NULL");
+	if (!mtr) return 0;
+	HIP_TRY(hipSetDevice(pl->device));
+	hipStream_t st = S_(s);
+	const size_t N = pl->N, nc = pl->ncoef;
+	int rc;
+	void *v;
+	if ((rc = scratch(pl, SCR_OUT, 6 * nc * sizeof(double), &v))) return rc;
+	double *OUT = (double *)v, *ST = OUT + 2 * nc, *PS = ST + 2 * nc;
+	if ((rc = scratch(pl, SCR_X2, 2 * N * sizeof(double), &v))) return rc;
+	double *xr = (double *)v;
+	const unsigned nblk = (unsigned)((N + 255) / 256);
+	if ((rc = scratch(pl, SCR_CONV, ((size_t)mtr * 4 + (size_t)nblk * mtr * 3 + mtr * 3) * sizeof(double), &v))) return rc;
+	double *d_ts = (double *)v, *d_lpart = d_ts + mtr * 4, *d_lin = d_lpart + (size_t)nblk * mtr * 3;
+	if ((rc = scratch(pl, SCR_PART, 2 * pl->npart * sizeof(double2), &v))) return rc;
+	double2 *part = (double2 *)v;
+	double *P = nullptr;
+	if (p->Kmax) { if ((rc = scratch(pl, SCR_P, (size_t)p->Kmax * N * sizeof(double), &v))) return rc; P = (double *)v; }
+	for (size_t i = 0; i < mtr; i++) {
+		const size_t Tr = i + 1;
+		unsigned K;
+		if (!p->Kmax || p->Kmax >= Tr) { // incremental single-stage step (tspws_stacks_float_1step, :835-863)
+			K = (unsigned)Tr;
+			if ((rc = forward_parts<float>(pl, d_x + i * ld, 1, ld, part, st))) return rc;
+			hipLaunchKernelGGL(k_accumulate_parts, dim3(pl->acc_blocks), dim3(256), 0, st, (const double2 *)part, pl->npart, pl->d_sc, pl->S, 1u,
+			                   (double2 *)ST, (double2 *)PS, i == 0 ? 1 : 0);
+		} else { // two-stage over the first Tr traces, recomputed from scratch like the reference (:266-268)
+			K = p->Kmax;
+			if ((rc = tspws_hip_partial_stacks(pl, d_x, ld, Tr, 0, Tr, K, P, N, s))) return rc;
+			if ((rc = tspws_hip_stacks_double(pl, P, K, N, ST, PS, s))) return rc;
+		}
+		if ((rc = tspws_hip_weight(pl, OUT, ST, PS, K, (unsigned)Tr, p->wu, p->unbiased, s))) return rc;
+		if ((rc = tspws_hip_inverse(pl, OUT, 1, xr, s))) return rc;
+		hipLaunchKernelGGL(k_dot4, dim3(1), dim3(1024), 0, st, (const double *)xr, d_ref_ts, N, d_ts + i * 4);
+		if (d_ts_steps && (rc = tspws_hip_epilogue(nullptr, d_ts_steps + i * N, nullptr, xr, N, 1, s))) return rc;
+	}
+	hipLaunchKernelGGL(k_conv_linear, dim3(nblk), dim3(256), 0, st, d_x, ld, N, mtr, d_ref_ls, d_lpart, d_ls_steps);
+	hipLaunchKernelGGL(k_conv_lin_reduce, dim3((unsigned)((mtr * 3 + 255) / 256)), dim3(256), 0, st, (const double *)d_lpart, nblk, mtr, d_lin);
+	hipLaunchKernelGGL(k_dot4, dim3(1), dim3(1024), 0, st, (const double *)xr, d_ref_ls, N, d_lpart); // only out[3] = sum ref_ls^2 is used
+	HIP_TRY(hipGetLastError());
+	std::vector<double> hts(mtr * 4), hl(mtr * 3);
+	double lsq[4];
+	HIP_TRY(hipMemcpyAsync(hts.data(), d_ts, mtr * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(hl.data(), d_lin, mtr * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(lsq, d_lpart, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	for (size_t i = 0; i < mtr; i++) {
+		h_ts_sim[i] = hts[i * 4] / sqrt(hts[i * 4 + 1]) / sqrt(hts[i * 4 + 3]);
+		h_ts_misfit[i] = hts[i * 4 + 2];
+		h_ls_sim[i] = hl[i * 3] / sqrt(hl[i * 3 + 1]) / sqrt(lsq[3]);
+		h_ls_misfit[i] = hl[i * 3 + 2];
+	}
 	return 0;
 }
 
