@@ -114,6 +114,8 @@ def test_forward_inverse_golden(lib, torch, golden):
     (dict(), 4096, 3), (dict(), 16501, 2), (dict(type=-3), 8192, 2), (dict(w0=2 * np.pi), 32768, 1),
     (dict(s0=3.7, J=5), 3001, 2), (dict(uni=1, J=4), 1024, 2), (dict(), 131072, 1), (dict(type=-3), 131072, 1),
     (dict(J=2), 64, 3), (dict(s0=7.890778, J=3), 16501, 1),
+    (dict(b0=0.25), 32768, 2),   # 40-67 taps per phase: the LDS kernel's tiled (non-resident) path at D >= 64
+    (dict(b0=0.25, type=-3, V=3), 8192, 3), (dict(b0=4.0), 65536, 2),
 ])
 def test_forward_inverse_vs_oracle(lib, torch, kw, N, ntr):
     p = abi.resolve(abi.default_params(**kw), N)

@@ -2,8 +2,9 @@
 //
 // Same decomposition as fwd_poly.h (thread = 8 consecutive outputs of one phase, sliding register window),
 // but the operands come from LDS: a 256-thread workgroup owns 8 "group slots" (4 waves x 2 passes) of ONE
-// scale and ONE trace, stages the x window and the taps all of its slots need with one burst of independent
-// coalesced loads, and then runs the FMA loop out of LDS with compile-time LDS offsets.
+// scale (and one 64-phase chunk when D >= 64), keeps that scale's taps RESIDENT in LDS and walks a slice of
+// traces: the x window of trace t+1 is fetched into registers while trace t is computed out of LDS, so the
+// global-memory latency hides behind the FMAs and the tap staging / scale set-up is paid once per workgroup.
 //
 // Why it is written the way it is (PMC, round 1): on gfx950 a wave64 v_fma_f64 costs 4 cycles and an integer
 // VALU op 2, so address arithmetic, predicates and 64-bit pointer math -- not the FP64 pipe -- were >75 % of the
@@ -14,131 +15,164 @@
 // value) instead of 5-instruction shuffle stages.
 //
 //   LOGD = 6 (D >= 64, any D): slot = output group g0+slot, lanes = 64 consecutive phases of the chunk;
-//             LDS x image  xL[row][64]   row j <-> sample (g0*8 + qa + j) D + m0 + lane - c   (80 rows)
-//             LDS taps     tL[q][64]     q <-> tap (qa + q) D + m0 + lane
+//             LDS x image  xL[row][64]   row j <-> sample (g0*8 + qa + j) D + m0 + lane - c   (88 rows)
+//             LDS taps     tL[q][64]     q <-> tap (qa + q) D + m0 + lane                      (24 rows)
 //   LOGD < 6 (D = 2^LOGD):     lanes = (group, phase); a slot is 64/D groups; the x window of the workgroup is one
 //             contiguous sample range stored with D doubles of padding per 8 D samples, so the 64/D groups of
 //             a wave fall on distinct banks (group stride 9 D doubles).
-//   stages  = (64-phase chunk) x (balanced tile of <= 16 taps-per-phase); accumulators live across stages.
+//   Q <= 24 taps per phase: taps resident, one stage per trace.  Q > 24: balanced tiles of <= 24, taps re-staged.
 //
 // Used for scales with at least 8 output groups (N_s >= 64) and D >= 64 or a power of two; everything else
 // (very coarse scales whose parallelism is only in the taps, odd small decimations) stays on k_fwd_poly.
 #pragma once
 
 #define FL_R 8
-#define FL_QT 16
-#define FL_TAPS_BYTES (FL_QT * 64 * 16)         /* 16 KiB */
-#define FL_X_DOUBLES 5760                       /* >= 80*64, >= 4608*9/8 and the 4 x 1056 reduction scratch */
-#define FL_LDS_BYTES (FL_TAPS_BYTES + FL_X_DOUBLES * 8)
+#ifndef FL_QT
+#define FL_QT 24
+#endif
+#ifndef FL_PASSES
+#define FL_PASSES 2                             /* group slots per wave (workgroup = 4 waves x FL_PASSES slots) */
+#endif
+#define FL_SLOTS (4 * FL_PASSES)
+#if FL_QT % FL_R != 0
+#error FL_QT must be a multiple of FL_R
+#endif
+#define FL_TAPS_BYTES (FL_QT * 64 * 16)         /* 24 KiB */
+#define FL_TPW (FL_QT / 4)                      /* tap rows staged per wave (D >= 64) */
+#define FL_TSMALL (FL_QT * 32 / 256)            /* tap values staged per thread (D < 64: <= FL_QT * 32 taps) */
+#define FL_XROWS (FL_SLOTS * FL_R + FL_QT)      /* rows staged when D >= 64 (FL_SLOTS*R + FL_QT - 1 needed); multiple of 4 */
+#define FL_XSMALL ((FL_SLOTS * 512 + 23 * 32 + 255) / 256) /* D < 64: 256-sample columns staged (window <= FL_SLOTS*512 + 23 D) */
+#define FL_X_ALLOC (((FL_XROWS * 64 > FL_XSMALL * 288 ? FL_XROWS * 64 : FL_XSMALL * 288) > 4224 ? (FL_XROWS * 64 > FL_XSMALL * 288 ? FL_XROWS * 64 : FL_XSMALL * 288) : 4224) + 64)
+#define FL_LDS_BYTES (FL_TAPS_BYTES + FL_X_ALLOC * 8)
 
 template <typename TIn, int LOGD>
-__device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ xt, const unsigned N, const ScaleDesc &d, const double2 *__restrict__ ws,
-                                             double *__restrict__ pout, const unsigned split, const unsigned bb, double2 *tL, double *xL)
+__device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const size_t ld, const unsigned ntr, const unsigned N, const ScaleDesc &d,
+                                             const double2 *__restrict__ ws, double *__restrict__ pout0, const size_t npart,
+                                             const unsigned chunk, const unsigned bb, double2 *tL, double *xL)
 {
 	constexpr int R = FL_R;
 	constexpr bool SMALL = LOGD < 6;
+	constexpr int LG = SMALL ? LOGD : 0;
 	constexpr unsigned DC = 1u << (SMALL ? LOGD : 6);     // D when SMALL
-	constexpr unsigned GW = SMALL ? (64u >> LOGD) : 1u;   // groups per wave-slot
+	constexpr unsigned GW = SMALL ? (64u >> LG) : 1u;     // groups per wave-slot
+	constexpr int NXV = SMALL ? FL_XSMALL : FL_XROWS / 4; // x values staged per thread
 	const unsigned D = SMALL ? DC : d.D;
 	const unsigned tid = threadIdx.x, lane = tid & 63;
 	const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const unsigned g0 = bb * 8u * GW;                     // first output group of this workgroup
+	const unsigned g0 = bb * (unsigned)FL_SLOTS * GW;      // first output group of this workgroup
 	const unsigned lane_m = SMALL ? (lane & (DC - 1)) : lane;
-	const unsigned lane_g = SMALL ? (lane >> (SMALL ? LOGD : 0)) : 0;
+	const unsigned lane_g = SMALL ? (lane >> LG) : 0;
+	const unsigned m0 = SMALL ? 0u : chunk * 64u;
+	const unsigned m = m0 + lane;
 
-	double ar[2][R], ai[2][R];
-#pragma unroll
-	for (int p = 0; p < 2; p++)
-#pragma unroll
-		for (int r = 0; r < R; r++) { ar[p][r] = 0; ai[p][r] = 0; }
+	const unsigned ntile = (d.Q + FL_QT - 1) / FL_QT, qt = (d.Q + ntile - 1) / ntile; // balanced tiles
+	const bool resident = ntile == 1;
 
-	// taps-per-phase are cut into equal tiles of at most FL_QT (Q = 17 -> 9 + 8, not 16 + 1)
-	const unsigned ntile = (d.Q + FL_QT - 1) / FL_QT, qt = (d.Q + ntile - 1) / ntile;
-	const unsigned nchunks = SMALL ? 1u : d.cps;
-	for (unsigned ci = 0; ci < nchunks; ci++) {
-		const unsigned chunk = split * d.cps + ci;
-		if (!SMALL && chunk >= d.MC) break;
-		const unsigned m0 = SMALL ? 0u : chunk * 64u;
+	// ---- trace-independent staging geometry -------------------------------------------------
+	// SMALL: contiguous window of NXV*256 samples starting at base(qa); LARGE: FL_XROWS rows of 64 lanes
+	auto x_base = [&](unsigned qa) -> long long {
+		return SMALL ? ((long long)g0 * R + qa) * DC - d.c : ((long long)g0 * R + qa) * D + m0 - d.c;
+	};
+	const bool full = SMALL ? true : (m0 + 63 < D);
+	auto load_x = [&](double (&xv)[NXV], const TIn *__restrict__ xt, unsigned qa) {
+		const long long base = x_base(qa);
+		if (SMALL) {
+			if (base >= 0 && base + NXV * 256 <= (long long)N) { // fast path: no circular wrap
+				const TIn *src = xt + (unsigned)base + tid;
+#pragma unroll
+				for (int i = 0; i < NXV; i++) xv[i] = (double)src[256 * i];
+			} else {
+				unsigned idx = wrap_index(base + tid, N);
+				const unsigned step = 256u % N;
+#pragma unroll
+				for (int i = 0; i < NXV; i++) {
+					xv[i] = (double)xt[idx];
+					idx += step; if (idx >= N) idx -= N;
+				}
+			}
+		} else {
+			const long long s_last = base + (long long)(FL_XROWS - 1) * D + 63;
+			if (full && base >= 0 && s_last < (long long)N) { // fast path
+				const TIn *src = xt + (unsigned)(base + (long long)wv * D) + lane;
+				const unsigned stride = 4u * D;
+#pragma unroll
+				for (int i = 0; i < NXV; i++) xv[i] = (double)src[(size_t)stride * i];
+			} else {
+				const bool mok = m < D;
+				unsigned idx = wrap_index(base + (long long)wv * D + (mok ? lane : 0), N);
+				const unsigned step = (unsigned)((4ull * D) % N);
+#pragma unroll
+				for (int i = 0; i < NXV; i++) {
+					xv[i] = mok ? (double)xt[idx] : 0.0;
+					idx += step; if (idx >= N) idx -= N;
+				}
+			}
+		}
+	};
+	auto store_x = [&](const double (&xv)[NXV]) {
+		if (SMALL) {
+			const unsigned pt = tid + ((tid >> (3 + LG)) << LG); // padded index of element tid; +288 per 256 elements
+#pragma unroll
+			for (int i = 0; i < NXV; i++) xL[pt + 288 * i] = xv[i];
+		} else {
+			double *xdst = xL + wv * 64 + lane;
+#pragma unroll
+			for (int i = 0; i < NXV; i++) xdst[256 * i] = xv[i];
+		}
+	};
+	auto stage_taps = [&](unsigned qa, unsigned qn) {
+		if (SMALL) { // qn * D <= FL_QT * 32 values, natural order
+			double2 tv[FL_TSMALL];
+#pragma unroll
+			for (int i = 0; i < FL_TSMALL; i++) {
+				const unsigned e = tid + 256u * (unsigned)i, l = qa * DC + e;
+				tv[i] = (e < qn * DC && l < d.L) ? ws[l] : make_double2(0.0, 0.0);
+			}
+#pragma unroll
+			for (int i = 0; i < FL_TSMALL; i++) tL[tid + 256 * i] = tv[i];
+		} else {     // rows wv, wv+4, ... of the FL_QT-row tile
+			double2 tv[FL_TPW];
+			const unsigned l0 = (qa + wv) * D + m;
+			if (full && (qa + FL_QT - 1u) * D + m0 + 63 < d.L) { // every tap of the tile exists
+#pragma unroll
+				for (int i = 0; i < FL_TPW; i++) tv[i] = ws[l0 + 4u * D * (unsigned)i];
+			} else {
+#pragma unroll
+				for (int i = 0; i < FL_TPW; i++) {
+					const unsigned q = wv + 4u * (unsigned)i, l = l0 + 4u * D * (unsigned)i;
+					tv[i] = (m < D && q < qn && l < d.L) ? ws[l] : make_double2(0.0, 0.0);
+				}
+			}
+			double2 *tdst = tL + wv * 64 + lane;
+#pragma unroll
+			for (int i = 0; i < FL_TPW; i++) tdst[256 * i] = tv[i];
+		}
+	};
+
+	if (resident) stage_taps(0, d.Q); // made visible by the barrier in front of the first compute
+	double xv[NXV];
+	if (resident) load_x(xv, x0, 0);
+
+	for (unsigned t = 0; t < ntr; t++) {
+		const TIn *xt = x0 + (size_t)t * ld;
+		double ar[FL_PASSES][R], ai[FL_PASSES][R];
+#pragma unroll
+		for (int p = 0; p < FL_PASSES; p++)
+#pragma unroll
+			for (int r = 0; r < R; r++) { ar[p][r] = 0; ai[p][r] = 0; }
+
 		for (unsigned qa = 0; qa < d.Q; qa += qt) {
 			const unsigned qn = (d.Q - qa) < qt ? (d.Q - qa) : qt;
-			__syncthreads(); // everyone is done reading the previous stage
-			// ------------------------------------------------------------------ stage
-			if (SMALL) {
-				// contiguous window; always stage 18*256 samples (>= the (8 GW R + qn - 1) D needed)
-				const long long base = ((long long)g0 * R + qa) * DC - d.c;
-				const unsigned pt = tid + ((tid >> (3 + (SMALL ? LOGD : 0))) << (SMALL ? LOGD : 0)); // padded index of element tid; +288 per 256
-				double xv[18];
-				if (base >= 0 && base + 18 * 256 <= (long long)N) { // fast path: no circular wrap
-					const TIn *src = xt + (unsigned)base + tid;
-#pragma unroll
-					for (int i = 0; i < 18; i++) xv[i] = (double)src[256 * i];
-				} else {
-					unsigned idx = wrap_index(base + tid, N);
-					const unsigned step = 256u % N;
-#pragma unroll
-					for (int i = 0; i < 18; i++) {
-						xv[i] = (double)xt[idx];
-						idx += step; if (idx >= N) idx -= N;
-					}
-				}
-				double2 tv[2]; // taps: qn * D <= 512 values, natural order
-#pragma unroll
-				for (int i = 0; i < 2; i++) {
-					const unsigned e = tid + 256u * (unsigned)i, l = qa * DC + e;
-					tv[i] = (e < qn * DC && l < d.L) ? ws[l] : make_double2(0.0, 0.0);
-				}
-#pragma unroll
-				for (int i = 0; i < 18; i++) xL[pt + 288 * i] = xv[i];
-#pragma unroll
-				for (int i = 0; i < 2; i++) tL[tid + 256 * i] = tv[i];
-			} else {
-				// thread (wv, lane) stages rows wv, wv+4, ..., wv+76 of its own lane column (80 rows >= 8R+qn-1+8)
-				const unsigned m = m0 + lane;
-				const long long s_first = ((long long)g0 * R + qa) * D + m0 - d.c;          // row 0, lane 0
-				const long long s_last = s_first + 79ll * D + 63;                           // row 79, lane 63
-				const bool full = m0 + 63 < D;
-				double xv[20];
-				if (full && s_first >= 0 && s_last < (long long)N) { // fast path
-					const TIn *src = xt + (unsigned)(s_first + (long long)wv * D) + lane;
-					const unsigned stride = 4u * D;
-#pragma unroll
-					for (int i = 0; i < 20; i++) xv[i] = (double)src[(size_t)stride * i];
-				} else {
-					const bool mok = m < D;
-					unsigned idx = wrap_index(s_first + (long long)wv * D + (mok ? lane : 0), N);
-					const unsigned step = (unsigned)((4ull * D) % N);
-#pragma unroll
-					for (int i = 0; i < 20; i++) {
-						xv[i] = mok ? (double)xt[idx] : 0.0;
-						idx += step; if (idx >= N) idx -= N;
-					}
-				}
-				double2 tv[4];
-				const unsigned l0 = (qa + wv) * D + m;
-				if (full && (qa + 15u) * D + m0 + 63 < d.L) { // every tap of the 16-row tile exists
-#pragma unroll
-					for (int i = 0; i < 4; i++) tv[i] = ws[l0 + 4u * D * (unsigned)i];
-				} else {
-#pragma unroll
-					for (int i = 0; i < 4; i++) {
-						const unsigned q = wv + 4u * (unsigned)i, l = l0 + 4u * D * (unsigned)i;
-						tv[i] = (m < D && q < qn && l < d.L) ? ws[l] : make_double2(0.0, 0.0);
-					}
-				}
-				double *xdst = xL + wv * 64 + lane;
-#pragma unroll
-				for (int i = 0; i < 20; i++) xdst[256 * i] = xv[i];
-				double2 *tdst = tL + wv * 64 + lane;
-#pragma unroll
-				for (int i = 0; i < 4; i++) tdst[256 * i] = tv[i];
-			}
+			__syncthreads(); // everyone is done reading the previous image (x rows, reduction scratch, taps)
+			if (!resident) { stage_taps(qa, qn); load_x(xv, xt, qa); }
+			store_x(xv);
 			__syncthreads();
+			if (resident && t + 1 < ntr) load_x(xv, xt + ld, 0); // next trace's window flies while this one is computed
 			// ------------------------------------------------------------------ compute: two passes (group slots) per wave
 #pragma unroll
-			for (int p = 0; p < 2; p++) {
+			for (int p = 0; p < FL_PASSES; p++) {
 				const unsigned slot = (unsigned)p * 4u + wv;
-				// one base per pass; every read below is base + compile-time offset
-				const double *xb;
+				const double *xb;  // one base per pass; every read below is base + compile-time offset
 				const double2 *tb;
 				if (SMALL) {
 					const unsigned gl = slot * GW + lane_g;            // group within the workgroup
@@ -179,57 +213,60 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ xt, const u
 #undef FL_XOFF
 			}
 		}
-	}
 
-	// ---------------------------------------------------------------------- combine the phase lanes, store the split partial
-	if (SMALL) {
+		// ------------------------------------------------------------------ combine the phase lanes, store the split partial
+		double *pout = pout0 + (size_t)t * npart * 2;
+		if (SMALL) {
 #pragma unroll
-		for (int p = 0; p < 2; p++) {
-			constexpr int NV = 2 * R;
-			double v[NV];
+			for (int p = 0; p < FL_PASSES; p++) {
+				constexpr int NV = 2 * R;
+				double v[NV];
 #pragma unroll
-			for (int r = 0; r < R; r++) { v[2 * r] = ar[p][r]; v[2 * r + 1] = ai[p][r]; }
-			int n = NV;
-			unsigned first = 0;
-			ReduceScatter<NV, 0>::run(v, (unsigned)(SMALL ? LOGD : 0), lane, n, first);
-			constexpr unsigned dup_mask = LOGD > 4 ? 0x10u : 0u; // NV = 16: bits 0..3 scatter, bit 4 (D = 32) duplicates
-			const unsigned g = g0 + ((unsigned)p * 4u + wv) * GW + lane_g;
-			if (!(lane & dup_mask)) {
+				for (int r = 0; r < R; r++) { v[2 * r] = ar[p][r]; v[2 * r + 1] = ai[p][r]; }
+				int n = NV;
+				unsigned first = 0;
+				ReduceScatter<NV, 0>::run(v, (unsigned)LG, lane, n, first);
+				constexpr unsigned dup_mask = LOGD == 5 ? 0x10u : 0u; // NV = 16: bits 0..3 scatter, bit 4 (D = 32) duplicates
+				const unsigned g = g0 + ((unsigned)p * 4u + wv) * GW + lane_g;
+				if (!(lane & dup_mask)) {
 #pragma unroll
-				for (int i = 0; i < NV; i++) {
-					if (i < n) {
-						const unsigned id = first + i, ri = id & 1, r = id >> 1;
-						const unsigned k = g * R + r;
-						if (k < d.Ns) pout[(size_t)k * 2 + ri] = ri ? -v[i] : v[i]; // conj
+					for (int i = 0; i < NV; i++) {
+						if (i < n) {
+							const unsigned id = first + i, ri = id & 1, r = id >> 1;
+							const unsigned k = g * R + r;
+							if (k < d.Ns) pout[(size_t)k * 2 + ri] = ri ? -v[i] : v[i]; // conj
+						}
 					}
 				}
 			}
-		}
-	} else {
-		// 64-lane reduction through a wave-private LDS transpose: row i (stride 65 doubles: conflict-free both
-		// ways) holds value i of every lane; lane (o = lane&15, quarter = lane>>4) sums 16 entries of row o.
-		__syncthreads(); // all waves are done with the x image
-		double *scr = xL + wv * 1056;
+		} else {
+			// 64-lane reduction through a wave-private LDS transpose: row i (stride 65 doubles: conflict-free both
+			// ways) holds value i of every lane; lane (o = lane&15, quarter = lane>>4) sums 16 entries of row o.
+			__syncthreads(); // all waves are done with the x image
+			double *scr = xL + wv * 1056;
 #pragma unroll
-		for (int p = 0; p < 2; p++) {
+			for (int p = 0; p < FL_PASSES; p++) {
 #pragma unroll
-			for (int r = 0; r < R; r++) { scr[(2 * r) * 65 + lane] = ar[p][r]; scr[(2 * r + 1) * 65 + lane] = ai[p][r]; }
-			const unsigned o = lane & 15, qd = lane >> 4;
-			const double *src = scr + o * 65 + qd * 16;
-			double sum = src[0];
+				for (int r = 0; r < R; r++) { scr[(2 * r) * 65 + lane] = ar[p][r]; scr[(2 * r + 1) * 65 + lane] = ai[p][r]; }
+				const unsigned o = lane & 15, qd = lane >> 4;
+				const double *src = scr + o * 65 + qd * 16;
+				double sum = src[0];
 #pragma unroll
-			for (int t = 1; t < 16; t++) sum += src[t];
-			sum += __shfl_xor(sum, 16, 64);
-			sum += __shfl_xor(sum, 32, 64);
-			const unsigned k = (g0 + (unsigned)p * 4u + wv) * R + (o >> 1);
-			if (qd == 0 && k < d.Ns) pout[(size_t)k * 2 + (o & 1)] = (o & 1) ? -sum : sum; // conj
+				for (int tt = 1; tt < 16; tt++) sum += src[tt];
+				sum += __shfl_xor(sum, 16, 64);
+				sum += __shfl_xor(sum, 32, 64);
+				const unsigned k = (g0 + (unsigned)p * 4u + wv) * R + (o >> 1);
+				if (qd == 0 && k < d.Ns) pout[(size_t)k * 2 + (o & 1)] = (o & 1) ? -sum : sum; // conj
+			}
 		}
 	}
 }
 
+// grid = (workgroups of all LDS scales, trace slices); a workgroup handles traces [slice*tps, min(ntr, (slice+1)*tps))
 template <typename TIn>
-__global__ void __launch_bounds__(256) k_fwd_lds(const TIn *__restrict__ x, size_t ld, unsigned N, const ScaleDesc *__restrict__ sc,
-                                                 unsigned S, const double2 *__restrict__ w, double2 *__restrict__ part, size_t npart)
+__global__ void __launch_bounds__(256) k_fwd_lds(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
+                                                 const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
+                                                 double2 *__restrict__ part, size_t npart)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	double2 *tL = (double2 *)smem;
@@ -242,17 +279,19 @@ __global__ void __launch_bounds__(256) k_fwd_lds(const TIn *__restrict__ x, size
 	}
 	const ScaleDesc d = sc[lo];
 	const unsigned wl = blockIdx.x - d.lds_off;
-	const unsigned split = wl / d.lds_bps, bb = wl - split * d.lds_bps;
-	const TIn *xt = x + (size_t)blockIdx.y * ld;
+	const unsigned chunk = wl / d.lds_bps, bb = wl - chunk * d.lds_bps; // one 64-phase chunk per workgroup (split == chunk)
+	const unsigned t0 = blockIdx.y * tps;
+	const unsigned nt = (ntr - t0) < tps ? (ntr - t0) : tps;
+	const TIn *x0 = x + (size_t)t0 * ld;
 	const double2 *ws = w + d.tap_off;
-	double *pout = (double *)(part + (size_t)blockIdx.y * npart + d.part_off + (size_t)split * d.Ns);
-	if (d.D >= 64) { fwd_lds_body<TIn, 6>(xt, N, d, ws, pout, split, bb, tL, xL); return; }
+	double *pout0 = (double *)(part + (size_t)t0 * npart + d.part_off + (size_t)chunk * d.Ns);
+	if (d.D >= 64) { fwd_lds_body<TIn, 6>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL); return; }
 	switch (d.logDL) {
-	case 0: fwd_lds_body<TIn, 0>(xt, N, d, ws, pout, split, bb, tL, xL); break;
-	case 1: fwd_lds_body<TIn, 1>(xt, N, d, ws, pout, split, bb, tL, xL); break;
-	case 2: fwd_lds_body<TIn, 2>(xt, N, d, ws, pout, split, bb, tL, xL); break;
-	case 3: fwd_lds_body<TIn, 3>(xt, N, d, ws, pout, split, bb, tL, xL); break;
-	case 4: fwd_lds_body<TIn, 4>(xt, N, d, ws, pout, split, bb, tL, xL); break;
-	default: fwd_lds_body<TIn, 5>(xt, N, d, ws, pout, split, bb, tL, xL); break;
+	case 0: fwd_lds_body<TIn, 0>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL); break;
+	case 1: fwd_lds_body<TIn, 1>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL); break;
+	case 2: fwd_lds_body<TIn, 2>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL); break;
+	case 3: fwd_lds_body<TIn, 3>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL); break;
+	case 4: fwd_lds_body<TIn, 4>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL); break;
+	default: fwd_lds_body<TIn, 5>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL); break;
 	}
 }

@@ -71,6 +71,11 @@ struct ScaleDesc {
 
 struct OctDesc;
 
+#ifndef FL_PASSES
+#define FL_PASSES 2
+#endif
+#define FL_PASSES_HOST FL_PASSES
+
 struct Chunk { // one streaming work item of the partial-stack kernel
 	unsigned long long t0; // first local trace
 	unsigned count;        // traces
@@ -291,7 +296,7 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 	{ // forward decomposition.  Scales with >= 8 output groups and (D >= 64 or D a power of two) run on the
 	  // LDS-staged kernel; the rest (very coarse scales, odd small decimations) on the direct kernel, which
 	  // aims at ~FWD_STEPS tap steps per wave.
-		const unsigned R = 8, FWD_STEPS = 96;
+		const unsigned R = 8, FWD_STEPS = 96, FL_SLOTS_HOST = 4 * FL_PASSES_HOST;
 		const bool no_lds = getenv("TSPWS_FWD_NOLDS") && *getenv("TSPWS_FWD_NOLDS") == '1';
 		unsigned woff = 0, boff = 0;
 		unsigned long long poff = 0;
@@ -306,15 +311,13 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 			const bool pow2 = (d.D & (d.D - 1)) == 0;
 			d.use_lds = (!no_lds && NG >= 8 && (d.D >= 64 || pow2)) ? 1u : 0u;
 			unsigned cps;
-			if (d.use_lds) {
-				const unsigned qtiles = (d.Q + 15) / 16;
-				cps = std::max(1u, 8u / qtiles);
-			} else cps = std::max(1u, (FWD_STEPS + d.Q / 2) / std::max(1u, d.Q));
+			if (d.use_lds) cps = 1; // one 64-phase chunk per workgroup: its taps stay resident in LDS over a slice of traces
+			else cps = std::max(1u, (FWD_STEPS + d.Q / 2) / std::max(1u, d.Q));
 			d.cps = std::min(cps, d.MC);
 			d.nsplit = (d.MC + d.cps - 1) / d.cps;
 			d.ngw = (NG + GW - 1) / GW;
 			d.wave_off = woff; d.lds_off = boff; d.part_off = poff;
-			d.lds_bps = (NG + 8 * GW - 1) / (8 * GW);
+			d.lds_bps = (NG + FL_SLOTS_HOST * GW - 1) / (FL_SLOTS_HOST * GW);
 			if (d.use_lds) boff += d.lds_bps * d.nsplit; else woff += d.ngw * d.nsplit;
 			poff += (unsigned long long)d.nsplit * d.Ns;
 			d.pad0 = d.pad1 = 0;
@@ -730,10 +733,15 @@ template <typename TIn>
 static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double2 *d_part, hipStream_t st)
 {
 	if (p->lds_blocks) {
-		for (size_t t0 = 0; t0 < ntr; t0 += 65535) {
-			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, 65535);
-			hipLaunchKernelGGL((k_fwd_lds<TIn>), dim3(p->lds_blocks, nt), dim3(256), FL_LDS_BYTES, st, d_x + t0 * ld, ld, p->N, p->d_sc, p->S,
-			                   p->d_w, d_part + t0 * p->npart, p->npart);
+		// traces per workgroup: enough slices to fill the GPU (>= ~2048 workgroups), at most 32 traces per slice
+		unsigned tps = (unsigned)std::min<size_t>(ntr, 32);
+		while (tps > 1 && (size_t)p->lds_blocks * ((ntr + tps - 1) / tps) < 2048) tps = (tps + 1) / 2;
+		if (const char *e = getenv("TSPWS_FWD_TPS")) tps = (unsigned)std::max(1, atoi(e));
+		const size_t per_launch = (size_t)tps * 65535;
+		for (size_t t0 = 0; t0 < ntr; t0 += per_launch) {
+			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, per_launch);
+			hipLaunchKernelGGL((k_fwd_lds<TIn>), dim3(p->lds_blocks, (nt + tps - 1) / tps), dim3(256), FL_LDS_BYTES, st, d_x + t0 * ld, ld, nt, tps,
+			                   p->N, p->d_sc, p->S, p->d_w, d_part + t0 * p->npart, p->npart);
 		}
 	}
 	if (p->fwd_waves) {
