@@ -134,10 +134,10 @@ int  tspws_hip_reduce_buffer(tspws_hip_plan *plan, const t_tsPWS *p, size_t mtr_
 int  tspws_hip_stack_finish(tspws_hip_plan *plan, const t_tsPWS *p, size_t mtr_global,
                             float *d_ls, float *d_tsPWS, void *stream);
 
-/* Single-GPU convenience: the same call, pipelined.  The two-stage partial stacks are streamed group by group on
- * `stream` while an internal second stream transforms each finished group (HBM-bound streaming overlaps the
- * FP64-bound CWTs); falls back to _local + _finish for single-stage requests or with TSPWS_NO_OVERLAP=1.  On
- * return all work is ordered on `stream`. */
+/* Single-GPU convenience: _local + _finish in one call.  With TSPWS_OVERLAP=1 a two-stage request is pipelined
+ * instead: the partial stacks are streamed group by group on `stream` while an internal second stream transforms
+ * each finished batch of groups (opt-in: on MI355X the co-running kernels currently slow each other as much as the
+ * overlap gains).  On return all work is ordered on `stream`. */
 int  tspws_hip_stack(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_sigall, size_t ld, size_t mtr,
                      float *d_ls, float *d_tsPWS, void *stream);
 /* Optional timing of the streaming stage inside tspws_hip_stack (HIP events on `stream` around the partial-stack

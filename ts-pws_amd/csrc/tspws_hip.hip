@@ -1162,10 +1162,13 @@ extern "C" int tspws_hip_stack_finish(tspws_hip_plan *pl, const t_tsPWS *p, size
 // streaming is HBM-bound, so they overlap), then weight / inverses / epilogue.  Same results as
 // stack_local + stack_finish (same kernels, same summation order).
 // ------------------------------------------------------------------------------------------
+// Measured on MI355X (round 1): co-running slows the streaming kernel by ~15 % and the transforms by 2-3x, so the
+// pipelined schedule (1.19-1.25 ms) does not beat the plain back-to-back one (1.14-1.18 ms) yet; it stays opt-in
+// (TSPWS_OVERLAP=1) until the transform kernels are less memory-latency sensitive.
 static bool overlap_enabled()
 {
 	static int v = -1;
-	if (v < 0) { const char *e = getenv("TSPWS_NO_OVERLAP"); v = (e && *e == '1') ? 0 : 1; }
+	if (v < 0) { const char *e = getenv("TSPWS_OVERLAP"); v = (e && *e == '1') ? 1 : 0; }
 	return v == 1;
 }
 
