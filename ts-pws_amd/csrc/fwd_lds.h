@@ -22,6 +22,13 @@
 //             a wave fall on distinct banks (group stride 9 D doubles).
 //   Q <= 24 taps per phase: taps resident, one stage per trace.  Q > 24: balanced tiles of <= 24, taps re-staged.
 //
+// Tunables (compile time): FL_WAVES x FL_PASSES group slots per workgroup, FL_BATCH steps per LDS read burst.
+// Measured on MI355X for the 10 x 131072 north-star transforms: 4x2 (251 VGPR, 2 waves/SIMD) 166 us; 8x1 forced to
+// 128 VGPR (4 waves/SIMD, 60 B spill) 177 us; 4x1 with 16-row tap tiles (3 blocks/CU) 178 us.  tools/fma64_peak.hip
+// shows why none of them is near the FP64 roof: a pure v_fma_f64 stream sustains 23 / 42 / 49 / 55 / 60 TFLOP/s at
+// 1 / 2 / 4 / 8 / 16+ waves per SIMD, i.e. the pipe needs >= 4 FMA-issuing waves per SIMD, which this register tile
+// (64 accumulator VGPRs + staging) does not leave room for.  Next round: a <= 64-VGPR tile.
+//
 // Used for scales with at least 8 output groups (N_s >= 64) and D >= 64 or a power of two; everything else
 // (very coarse scales whose parallelism is only in the taps, odd small decimations) stays on k_fwd_poly.
 #pragma once
@@ -30,19 +37,32 @@
 #ifndef FL_QT
 #define FL_QT 24
 #endif
-#ifndef FL_PASSES
-#define FL_PASSES 2                             /* group slots per wave (workgroup = 4 waves x FL_PASSES slots) */
+#ifndef FL_WAVES
+#define FL_WAVES 4                              /* waves per workgroup */
 #endif
-#define FL_SLOTS (4 * FL_PASSES)
+#ifndef FL_PASSES
+#define FL_PASSES 2                             /* group slots per wave (workgroup = FL_WAVES x FL_PASSES slots) */
+#endif
+#ifndef FL_BATCH
+#define FL_BATCH 8                              /* tap steps whose LDS reads are issued together */
+#endif
+#define FL_NT (64 * FL_WAVES)                   /* threads per workgroup */
+#define FL_SLOTS (FL_WAVES * FL_PASSES)
 #if FL_QT % FL_R != 0
 #error FL_QT must be a multiple of FL_R
 #endif
 #define FL_TAPS_BYTES (FL_QT * 64 * 16)         /* 24 KiB */
-#define FL_TPW (FL_QT / 4)                      /* tap rows staged per wave (D >= 64) */
-#define FL_TSMALL (FL_QT * 32 / 256)            /* tap values staged per thread (D < 64: <= FL_QT * 32 taps) */
-#define FL_XROWS (FL_SLOTS * FL_R + FL_QT)      /* rows staged when D >= 64 (FL_SLOTS*R + FL_QT - 1 needed); multiple of 4 */
-#define FL_XSMALL ((FL_SLOTS * 512 + 23 * 32 + 255) / 256) /* D < 64: 256-sample columns staged (window <= FL_SLOTS*512 + 23 D) */
-#define FL_X_ALLOC (((FL_XROWS * 64 > FL_XSMALL * 288 ? FL_XROWS * 64 : FL_XSMALL * 288) > 4224 ? (FL_XROWS * 64 > FL_XSMALL * 288 ? FL_XROWS * 64 : FL_XSMALL * 288) : 4224) + 64)
+#define FL_TPW (FL_QT / FL_WAVES)               /* tap rows staged per wave (D >= 64) */
+#define FL_TSMALL ((FL_QT * 32 + FL_NT - 1) / FL_NT) /* tap values staged per thread (D < 64: <= FL_QT * 32 taps) */
+#if FL_QT % FL_WAVES != 0
+#error FL_QT must be a multiple of FL_WAVES
+#endif
+#define FL_XROWS (FL_SLOTS * FL_R + FL_QT)      /* rows staged when D >= 64 (FL_SLOTS*R + FL_QT - 1 needed); multiple of FL_WAVES */
+#define FL_XSMALL ((FL_SLOTS * 512 + 23 * 32 + FL_NT - 1) / FL_NT) /* D < 64: FL_NT-sample columns staged (window <= FL_SLOTS*512 + 23 D) */
+#define FL_XPAD (FL_NT * 9 / 8)                 /* padded LDS distance of two columns */
+#define FL_SCR 528                              /* reduction scratch per wave: 8 rows x 65 (+8) doubles */
+#define FL_MAX2(a, b) ((a) > (b) ? (a) : (b))
+#define FL_X_ALLOC (FL_MAX2(FL_MAX2(FL_XROWS * 64, FL_XSMALL * FL_XPAD), FL_WAVES * FL_SCR) + 64)
 #define FL_LDS_BYTES (FL_TAPS_BYTES + FL_X_ALLOC * 8)
 
 template <typename TIn, int LOGD>
@@ -55,7 +75,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 	constexpr int LG = SMALL ? LOGD : 0;
 	constexpr unsigned DC = 1u << (SMALL ? LOGD : 6);     // D when SMALL
 	constexpr unsigned GW = SMALL ? (64u >> LG) : 1u;     // groups per wave-slot
-	constexpr int NXV = SMALL ? FL_XSMALL : FL_XROWS / 4; // x values staged per thread
+	constexpr int NXV = SMALL ? FL_XSMALL : FL_XROWS / FL_WAVES; // x values staged per thread
 	const unsigned D = SMALL ? DC : d.D;
 	const unsigned tid = threadIdx.x, lane = tid & 63;
 	const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,13 +97,13 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 	auto load_x = [&](double (&xv)[NXV], const TIn *__restrict__ xt, unsigned qa) {
 		const long long base = x_base(qa);
 		if (SMALL) {
-			if (base >= 0 && base + NXV * 256 <= (long long)N) { // fast path: no circular wrap
+			if (base >= 0 && base + NXV * FL_NT <= (long long)N) { // fast path: no circular wrap
 				const TIn *src = xt + (unsigned)base + tid;
 #pragma unroll
-				for (int i = 0; i < NXV; i++) xv[i] = (double)src[256 * i];
+				for (int i = 0; i < NXV; i++) xv[i] = (double)src[FL_NT * i];
 			} else {
 				unsigned idx = wrap_index(base + tid, N);
-				const unsigned step = 256u % N;
+				const unsigned step = (unsigned)FL_NT % N;
 #pragma unroll
 				for (int i = 0; i < NXV; i++) {
 					xv[i] = (double)xt[idx];
@@ -94,13 +114,13 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 			const long long s_last = base + (long long)(FL_XROWS - 1) * D + 63;
 			if (full && base >= 0 && s_last < (long long)N) { // fast path
 				const TIn *src = xt + (unsigned)(base + (long long)wv * D) + lane;
-				const unsigned stride = 4u * D;
+				const unsigned stride = (unsigned)FL_WAVES * D;
 #pragma unroll
 				for (int i = 0; i < NXV; i++) xv[i] = (double)src[(size_t)stride * i];
 			} else {
 				const bool mok = m < D;
 				unsigned idx = wrap_index(base + (long long)wv * D + (mok ? lane : 0), N);
-				const unsigned step = (unsigned)((4ull * D) % N);
+				const unsigned step = (unsigned)(((unsigned long long)FL_WAVES * D) % N);
 #pragma unroll
 				for (int i = 0; i < NXV; i++) {
 					xv[i] = mok ? (double)xt[idx] : 0.0;
@@ -111,13 +131,13 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 	};
 	auto store_x = [&](const double (&xv)[NXV]) {
 		if (SMALL) {
-			const unsigned pt = tid + ((tid >> (3 + LG)) << LG); // padded index of element tid; +288 per 256 elements
+			const unsigned pt = tid + ((tid >> (3 + LG)) << LG); // padded index of element tid; +FL_XPAD per FL_NT elements
 #pragma unroll
-			for (int i = 0; i < NXV; i++) xL[pt + 288 * i] = xv[i];
+			for (int i = 0; i < NXV; i++) xL[pt + FL_XPAD * i] = xv[i];
 		} else {
 			double *xdst = xL + wv * 64 + lane;
 #pragma unroll
-			for (int i = 0; i < NXV; i++) xdst[256 * i] = xv[i];
+			for (int i = 0; i < NXV; i++) xdst[FL_NT * i] = xv[i];
 		}
 	};
 	auto stage_taps = [&](unsigned qa, unsigned qn) {
@@ -125,27 +145,27 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 			double2 tv[FL_TSMALL];
 #pragma unroll
 			for (int i = 0; i < FL_TSMALL; i++) {
-				const unsigned e = tid + 256u * (unsigned)i, l = qa * DC + e;
+				const unsigned e = tid + (unsigned)FL_NT * (unsigned)i, l = qa * DC + e;
 				tv[i] = (e < qn * DC && l < d.L) ? ws[l] : make_double2(0.0, 0.0);
 			}
 #pragma unroll
-			for (int i = 0; i < FL_TSMALL; i++) tL[tid + 256 * i] = tv[i];
+			for (int i = 0; i < FL_TSMALL; i++) if (tid + FL_NT * i < FL_QT * 64) tL[tid + FL_NT * i] = tv[i];
 		} else {     // rows wv, wv+4, ... of the FL_QT-row tile
 			double2 tv[FL_TPW];
 			const unsigned l0 = (qa + wv) * D + m;
 			if (full && (qa + FL_QT - 1u) * D + m0 + 63 < d.L) { // every tap of the tile exists
 #pragma unroll
-				for (int i = 0; i < FL_TPW; i++) tv[i] = ws[l0 + 4u * D * (unsigned)i];
+				for (int i = 0; i < FL_TPW; i++) tv[i] = ws[l0 + (unsigned)FL_WAVES * D * (unsigned)i];
 			} else {
 #pragma unroll
 				for (int i = 0; i < FL_TPW; i++) {
-					const unsigned q = wv + 4u * (unsigned)i, l = l0 + 4u * D * (unsigned)i;
+					const unsigned q = wv + (unsigned)FL_WAVES * (unsigned)i, l = l0 + (unsigned)FL_WAVES * D * (unsigned)i;
 					tv[i] = (m < D && q < qn && l < d.L) ? ws[l] : make_double2(0.0, 0.0);
 				}
 			}
 			double2 *tdst = tL + wv * 64 + lane;
 #pragma unroll
-			for (int i = 0; i < FL_TPW; i++) tdst[256 * i] = tv[i];
+			for (int i = 0; i < FL_TPW; i++) tdst[FL_NT * i] = tv[i];
 		}
 	};
 
@@ -171,7 +191,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 			// ------------------------------------------------------------------ compute: two passes (group slots) per wave
 #pragma unroll
 			for (int p = 0; p < FL_PASSES; p++) {
-				const unsigned slot = (unsigned)p * 4u + wv;
+				const unsigned slot = (unsigned)p * (unsigned)FL_WAVES + wv;
 				const double *xb;  // one base per pass; every read below is base + compile-time offset
 				const double2 *tb;
 				if (SMALL) {
@@ -188,23 +208,25 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 #pragma unroll
 				for (int j = 0; j < R - 1; j++) xw[j] = xb[FL_XOFF(j)];
 #pragma unroll
-				for (int h = 0; h < FL_QT / R; h++) {
-					if ((unsigned)(h * R) < qn) {
-						double xn[R];
-						double2 tn[R];
+				for (int h = 0; h < FL_QT / FL_BATCH; h++) { // LDS reads of FL_BATCH steps are issued together, then their FMAs
+					if ((unsigned)(h * FL_BATCH) < qn) {
+						double xn[FL_BATCH];
+						double2 tn[FL_BATCH];
 #pragma unroll
-						for (int u = 0; u < R; u++) {
-							xn[u] = xb[FL_XOFF(h * R + u + R - 1)];
-							tn[u] = tb[(h * R + u) * XS];
+						for (int u = 0; u < FL_BATCH; u++) {
+							xn[u] = xb[FL_XOFF(h * FL_BATCH + u + R - 1)];
+							tn[u] = tb[(h * FL_BATCH + u) * XS];
 						}
 #pragma unroll
-						for (int u = 0; u < R; u++) {
-							if ((unsigned)(h * R + u) < qn) {
-								xw[(u + R - 1) % R] = xn[u];
+						for (int u = 0; u < FL_BATCH; u++) {
+							constexpr int dummy = 0; (void)dummy;
+							const int sidx = h * FL_BATCH + u; // compile-time after unrolling
+							if ((unsigned)sidx < qn) {
+								xw[(sidx + R - 1) % R] = xn[u];
 #pragma unroll
 								for (int r = 0; r < R; r++) {
-									ar[p][r] = fma(xw[(u + r) % R], tn[u].x, ar[p][r]);
-									ai[p][r] = fma(xw[(u + r) % R], tn[u].y, ai[p][r]);
+									ar[p][r] = fma(xw[(sidx + r) % R], tn[u].x, ar[p][r]);
+									ai[p][r] = fma(xw[(sidx + r) % R], tn[u].y, ai[p][r]);
 								}
 							}
 						}
@@ -227,7 +249,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 				unsigned first = 0;
 				ReduceScatter<NV, 0>::run(v, (unsigned)LG, lane, n, first);
 				constexpr unsigned dup_mask = LOGD == 5 ? 0x10u : 0u; // NV = 16: bits 0..3 scatter, bit 4 (D = 32) duplicates
-				const unsigned g = g0 + ((unsigned)p * 4u + wv) * GW + lane_g;
+				const unsigned g = g0 + ((unsigned)p * (unsigned)FL_WAVES + wv) * GW + lane_g;
 				if (!(lane & dup_mask)) {
 #pragma unroll
 					for (int i = 0; i < NV; i++) {
@@ -240,23 +262,31 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 				}
 			}
 		} else {
-			// 64-lane reduction through a wave-private LDS transpose: row i (stride 65 doubles: conflict-free both
-			// ways) holds value i of every lane; lane (o = lane&15, quarter = lane>>4) sums 16 entries of row o.
+			// 64-lane reduction through a wave-private LDS transpose, 8 values at a time: row i (stride 65 doubles:
+			// conflict-free both ways) holds value i of every lane; lane (o = lane&7, eighth = lane>>3) sums 8 entries
+			// of row o, three shuffle-adds combine the eighths.
 			__syncthreads(); // all waves are done with the x image
-			double *scr = xL + wv * 1056;
+			double *scr = xL + wv * FL_SCR;
 #pragma unroll
 			for (int p = 0; p < FL_PASSES; p++) {
 #pragma unroll
-				for (int r = 0; r < R; r++) { scr[(2 * r) * 65 + lane] = ar[p][r]; scr[(2 * r + 1) * 65 + lane] = ai[p][r]; }
-				const unsigned o = lane & 15, qd = lane >> 4;
-				const double *src = scr + o * 65 + qd * 16;
-				double sum = src[0];
+				for (int hh = 0; hh < 2; hh++) {
 #pragma unroll
-				for (int tt = 1; tt < 16; tt++) sum += src[tt];
-				sum += __shfl_xor(sum, 16, 64);
-				sum += __shfl_xor(sum, 32, 64);
-				const unsigned k = (g0 + (unsigned)p * 4u + wv) * R + (o >> 1);
-				if (qd == 0 && k < d.Ns) pout[(size_t)k * 2 + (o & 1)] = (o & 1) ? -sum : sum; // conj
+					for (int r = 0; r < 4; r++) {
+						scr[(2 * r) * 65 + lane] = ar[p][hh * 4 + r];
+						scr[(2 * r + 1) * 65 + lane] = ai[p][hh * 4 + r];
+					}
+					const unsigned o = lane & 7, e8 = lane >> 3;
+					const double *src = scr + o * 65 + e8 * 8;
+					double sum = src[0];
+#pragma unroll
+					for (int tt = 1; tt < 8; tt++) sum += src[tt];
+					sum += __shfl_xor(sum, 8, 64);
+					sum += __shfl_xor(sum, 16, 64);
+					sum += __shfl_xor(sum, 32, 64);
+					const unsigned k = (g0 + (unsigned)p * (unsigned)FL_WAVES + wv) * R + (unsigned)hh * 4u + (o >> 1);
+					if (e8 == 0 && k < d.Ns) pout[(size_t)k * 2 + (o & 1)] = (o & 1) ? -sum : sum; // conj
+				}
 			}
 		}
 	}
@@ -264,7 +294,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 
 // grid = (workgroups of all LDS scales, trace slices); a workgroup handles traces [slice*tps, min(ntr, (slice+1)*tps))
 template <typename TIn>
-__global__ void __launch_bounds__(256) k_fwd_lds(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
+__global__ void __launch_bounds__(FL_NT) k_fwd_lds(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
                                                  const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
                                                  double2 *__restrict__ part, size_t npart)
 {

@@ -74,6 +74,9 @@ struct OctDesc;
 #ifndef FL_PASSES
 #define FL_PASSES 2
 #endif
+#ifndef FL_WAVES
+#define FL_WAVES 4
+#endif
 #define FL_PASSES_HOST FL_PASSES
 
 struct Chunk { // one streaming work item of the partial-stack kernel
@@ -296,7 +299,7 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 	{ // forward decomposition.  Scales with >= 8 output groups and (D >= 64 or D a power of two) run on the
 	  // LDS-staged kernel; the rest (very coarse scales, odd small decimations) on the direct kernel, which
 	  // aims at ~FWD_STEPS tap steps per wave.
-		const unsigned R = 8, FWD_STEPS = 96, FL_SLOTS_HOST = 4 * FL_PASSES_HOST;
+		const unsigned R = 8, FWD_STEPS = 96, FL_SLOTS_HOST = FL_WAVES * FL_PASSES_HOST;
 		const bool no_lds = getenv("TSPWS_FWD_NOLDS") && *getenv("TSPWS_FWD_NOLDS") == '1';
 		unsigned woff = 0, boff = 0;
 		unsigned long long poff = 0;
@@ -740,7 +743,7 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 		const size_t per_launch = (size_t)tps * 65535;
 		for (size_t t0 = 0; t0 < ntr; t0 += per_launch) {
 			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, per_launch);
-			hipLaunchKernelGGL((k_fwd_lds<TIn>), dim3(p->lds_blocks, (nt + tps - 1) / tps), dim3(256), FL_LDS_BYTES, st, d_x + t0 * ld, ld, nt, tps,
+			hipLaunchKernelGGL((k_fwd_lds<TIn>), dim3(p->lds_blocks, (nt + tps - 1) / tps), dim3(FL_NT), FL_LDS_BYTES, st, d_x + t0 * ld, ld, nt, tps,
 			                   p->N, p->d_sc, p->S, p->d_w, d_part + t0 * p->npart, p->npart);
 		}
 	}
