@@ -19,7 +19,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "lib", "libtspws_hip.so")
+LIB_PATH = os.environ.get("TSPWS_LIB_PATH") or os.path.join(_HERE, "lib", "libtspws_hip.so")  # override: profiling builds only
 
 time_t = C.c_long
 

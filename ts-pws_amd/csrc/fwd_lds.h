@@ -27,7 +27,11 @@
 // 128 VGPR (4 waves/SIMD, 60 B spill) 177 us; 4x1 with 16-row tap tiles (3 blocks/CU) 178 us.  tools/fma64_peak.hip
 // shows why none of them is near the FP64 roof: a pure v_fma_f64 stream sustains 23 / 42 / 49 / 55 / 60 TFLOP/s at
 // 1 / 2 / 4 / 8 / 16+ waves per SIMD, i.e. the pipe needs >= 4 FMA-issuing waves per SIMD, which this register tile
-// (64 accumulator VGPRs + staging) does not leave room for.  Next round: a <= 64-VGPR tile.
+// (64 accumulator VGPRs + staging) does not leave room for.
+// Ablation (same build, 10 x 131072): baseline 171 us; without the global x loads 151; additionally without the LDS
+// operand reads in the FMA loop 144; additionally without barriers 140 -- i.e. operand supply and synchronisation are
+// only ~30 us; the rest is the FMA stream itself at 2 waves/SIMD (~68 % of the sustained FP64 rate per the
+// micro-benchmark: ~100 us for these 1.6e9 lane-FMAs + 0.9e9 integer VALU ops) plus reduction / stores.
 //
 // Used for scales with at least 8 output groups (N_s >= 64) and D >= 64 or a power of two; everything else
 // (very coarse scales whose parallelism is only in the taps, odd small decimations) stays on k_fwd_poly.

@@ -95,7 +95,9 @@ struct tspws_hip_plan {
 	size_t npart = 0;          // complex partial coefficients per trace (sum of nsplit*Ns)
 	unsigned fwd_waves = 0;    // waves per trace batch of k_fwd_poly
 	unsigned acc_blocks = 0;   // blocks of k_accumulate_parts
-	unsigned lds_blocks = 0;   // workgroups per trace of k_fwd_lds
+	unsigned lds_blocks = 0;   // workgroups per trace slice of k_fwd_lds / workgroups of k_fwd_tl
+	int fwd_kind = 1;          // 0: k_fwd_poly only, 1: k_fwd_lds (+poly), 2: k_fwd_tl (+poly)
+	unsigned tl_rows = 0;      // tap rows (of 64 double2) k_fwd_tl keeps in LDS
 	unsigned inv_waves = 0, inv_noct = 0, inv_ngeneric = 0; // polyphase inverse: waves, octave items, scales left to the generic kernel
 	struct OctDesc *d_oc = nullptr;
 	std::vector<ScaleDesc> sc;
@@ -300,7 +302,10 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 	  // LDS-staged kernel; the rest (very coarse scales, odd small decimations) on the direct kernel, which
 	  // aims at ~FWD_STEPS tap steps per wave.
 		const unsigned R = 8, FWD_STEPS = 96, FL_SLOTS_HOST = FL_WAVES * FL_PASSES_HOST;
-		const bool no_lds = getenv("TSPWS_FWD_NOLDS") && *getenv("TSPWS_FWD_NOLDS") == '1';
+		int kind = 1;
+		if (const char *e = getenv("TSPWS_FWD_KERNEL")) kind = !strcmp(e, "poly") ? 0 : !strcmp(e, "tl") ? 2 : 1;
+		if (getenv("TSPWS_FWD_NOLDS") && *getenv("TSPWS_FWD_NOLDS") == '1') kind = 0;
+		p->fwd_kind = kind;
 		unsigned woff = 0, boff = 0;
 		unsigned long long poff = 0;
 		for (unsigned s = 0; s < S; s++) {
@@ -312,15 +317,21 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 			d.MC = d.D > 64 ? (d.D + 63) / 64 : 1;
 			const unsigned NG = (d.Ns + R - 1) / R, GW = 64 / d.DL;
 			const bool pow2 = (d.D & (d.D - 1)) == 0;
-			d.use_lds = (!no_lds && NG >= 8 && (d.D >= 64 || pow2)) ? 1u : 0u;
+			d.ngw = (NG + GW - 1) / GW;
+			d.use_lds = (kind != 0 && NG >= 8 && (d.D >= 64 || pow2)) ? 1u : 0u;
+			if (kind == 2) { // taps must fit the resident LDS tile (24 rows of 64)
+				const unsigned rows = d.D < 64 ? (d.Q * d.D + 63) / 64 : d.Q;
+				if (rows > 24) d.use_lds = 0;
+				else if (d.use_lds) p->tl_rows = std::max(p->tl_rows, rows);
+			}
 			unsigned cps;
-			if (d.use_lds) cps = 1; // one 64-phase chunk per workgroup: its taps stay resident in LDS over a slice of traces
+			if (d.use_lds) cps = 1; // one 64-phase chunk per workgroup: its taps stay resident in LDS
 			else cps = std::max(1u, (FWD_STEPS + d.Q / 2) / std::max(1u, d.Q));
 			d.cps = std::min(cps, d.MC);
 			d.nsplit = (d.MC + d.cps - 1) / d.cps;
-			d.ngw = (NG + GW - 1) / GW;
 			d.wave_off = woff; d.lds_off = boff; d.part_off = poff;
-			d.lds_bps = (NG + FL_SLOTS_HOST * GW - 1) / (FL_SLOTS_HOST * GW);
+			if (kind == 2) d.lds_bps = std::min(64u, std::max(1u, (d.ngw + 15) / 16)); // workgroups per (scale, chunk)
+			else d.lds_bps = (NG + FL_SLOTS_HOST * GW - 1) / (FL_SLOTS_HOST * GW);
 			if (d.use_lds) boff += d.lds_bps * d.nsplit; else woff += d.ngw * d.nsplit;
 			poff += (unsigned long long)d.nsplit * d.Ns;
 			d.pad0 = d.pad1 = 0;
@@ -730,12 +741,20 @@ static int forward_generic(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t
 
 #include "fwd_poly.h"
 #include "fwd_lds.h"
+#include "fwd_tl.h"
 
 // Forward transform of ntr traces into the split-partial layout part[ntr][npart].
 template <typename TIn>
 static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double2 *d_part, hipStream_t st)
 {
-	if (p->lds_blocks) {
+	if (p->lds_blocks && p->fwd_kind == 2) {
+		const size_t lds = (size_t)p->tl_rows * 1024 + 4 * TL_SCR * sizeof(double);
+		for (size_t t0 = 0; t0 < ntr; t0 += 65534) { // (trace pairs inside the kernel: keep launches even)
+			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, 65534);
+			hipLaunchKernelGGL((k_fwd_tl<TIn>), dim3(p->lds_blocks), dim3(256), lds, st, d_x + t0 * ld, ld, nt, p->N, p->d_sc, p->S, p->d_w,
+			                   d_part + t0 * p->npart, p->npart, p->tl_rows);
+		}
+	} else if (p->lds_blocks) {
 		// traces per workgroup: enough slices to fill the GPU (>= ~2048 workgroups), at most 32 traces per slice
 		unsigned tps = (unsigned)std::min<size_t>(ntr, 32);
 		while (tps > 1 && (size_t)p->lds_blocks * ((ntr + tps - 1) / tps) < 2048) tps = (tps + 1) / 2;
