@@ -7,7 +7,9 @@ import json
 import sys
 import time
 
-sys.path.insert(0, "tests")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
 import torch
 import abi

@@ -48,7 +48,7 @@
 #define FL_PASSES 2                             /* group slots per wave (workgroup = FL_WAVES x FL_PASSES slots) */
 #endif
 #ifndef FL_BATCH
-#define FL_BATCH 8                              /* tap steps whose LDS reads are issued together */
+#define FL_BATCH 4                              /* tap steps per burst: LDS reads issued together, then straight-line FMAs */
 #endif
 #define FL_NT (64 * FL_WAVES)                   /* threads per workgroup */
 #define FL_SLOTS (FL_WAVES * FL_PASSES)
@@ -157,7 +157,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 		} else {     // rows wv, wv+4, ... of the FL_QT-row tile
 			double2 tv[FL_TPW];
 			const unsigned l0 = (qa + wv) * D + m;
-			if (full && (qa + FL_QT - 1u) * D + m0 + 63 < d.L) { // every tap of the tile exists
+			if (qn == FL_QT && full && (qa + FL_QT - 1u) * D + m0 + 63 < d.L) { // a full tile whose every tap exists
 #pragma unroll
 				for (int i = 0; i < FL_TPW; i++) tv[i] = ws[l0 + (unsigned)FL_WAVES * D * (unsigned)i];
 			} else {
@@ -223,15 +223,15 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 						}
 #pragma unroll
 						for (int u = 0; u < FL_BATCH; u++) {
-							constexpr int dummy = 0; (void)dummy;
+							// no per-step guard: taps past the filter end are staged as exact zeros and the x image always
+							// holds the rows of a whole burst, so a burst is straight-line code (per-step branches turned
+							// the window registers into phi copies and cost an issue bubble each)
 							const int sidx = h * FL_BATCH + u; // compile-time after unrolling
-							if ((unsigned)sidx < qn) {
-								xw[(sidx + R - 1) % R] = xn[u];
+							xw[(sidx + R - 1) % R] = xn[u];
 #pragma unroll
-								for (int r = 0; r < R; r++) {
-									ar[p][r] = fma(xw[(sidx + r) % R], tn[u].x, ar[p][r]);
-									ai[p][r] = fma(xw[(sidx + r) % R], tn[u].y, ai[p][r]);
-								}
+							for (int r = 0; r < R; r++) {
+								ar[p][r] = fma(xw[(sidx + r) % R], tn[u].x, ar[p][r]);
+								ai[p][r] = fma(xw[(sidx + r) % R], tn[u].y, ai[p][r]);
 							}
 						}
 					}
