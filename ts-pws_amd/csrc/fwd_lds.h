@@ -249,10 +249,10 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 				double v[NV];
 #pragma unroll
 				for (int r = 0; r < R; r++) { v[2 * r] = ar[p][r]; v[2 * r + 1] = ai[p][r]; }
-				int n = NV;
-				unsigned first = 0;
-				ReduceScatter<NV, 0>::run(v, (unsigned)LG, lane, n, first);
-				constexpr unsigned dup_mask = LOGD == 5 ? 0x10u : 0u; // NV = 16: bits 0..3 scatter, bit 4 (D = 32) duplicates
+				int n;
+				unsigned first;
+				valu_rs16<LG>(v, lane, n, first); // permlane / DPP exchanges over the D lanes of each group (no LDS traffic)
+				constexpr unsigned dup_mask = LOGD == 5 ? 0x1u : 0u; // D = 32: the last bit (0) was a butterfly, odd lanes duplicate
 				const unsigned g = g0 + ((unsigned)p * (unsigned)FL_WAVES + wv) * GW + lane_g;
 				if (!(lane & dup_mask)) {
 #pragma unroll
@@ -266,31 +266,17 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 				}
 			}
 		} else {
-			// 64-lane reduction through a wave-private LDS transpose, 8 values at a time: row i (stride 65 doubles:
-			// conflict-free both ways) holds value i of every lane; lane (o = lane&7, eighth = lane>>3) sums 8 entries
-			// of row o, three shuffle-adds combine the eighths.
-			__syncthreads(); // all waves are done with the x image
-			double *scr = xL + wv * FL_SCR;
+			// 64-lane reduction on the VALU (valu_reduce16: permlane swaps + DPP, no LDS traffic, no extra barrier):
+			// every lane ends with element o = 8*b5 + 4*b4 + 2*b3 + b2 of (re0, im0, re1, im1, ...); one lane per quad stores
 #pragma unroll
 			for (int p = 0; p < FL_PASSES; p++) {
+				double v[2 * R];
 #pragma unroll
-				for (int hh = 0; hh < 2; hh++) {
-#pragma unroll
-					for (int r = 0; r < 4; r++) {
-						scr[(2 * r) * 65 + lane] = ar[p][hh * 4 + r];
-						scr[(2 * r + 1) * 65 + lane] = ai[p][hh * 4 + r];
-					}
-					const unsigned o = lane & 7, e8 = lane >> 3;
-					const double *src = scr + o * 65 + e8 * 8;
-					double sum = src[0];
-#pragma unroll
-					for (int tt = 1; tt < 8; tt++) sum += src[tt];
-					sum += __shfl_xor(sum, 8, 64);
-					sum += __shfl_xor(sum, 16, 64);
-					sum += __shfl_xor(sum, 32, 64);
-					const unsigned k = (g0 + (unsigned)p * (unsigned)FL_WAVES + wv) * R + (unsigned)hh * 4u + (o >> 1);
-					if (e8 == 0 && k < d.Ns) pout[(size_t)k * 2 + (o & 1)] = (o & 1) ? -sum : sum; // conj
-				}
+				for (int r = 0; r < R; r++) { v[2 * r] = ar[p][r]; v[2 * r + 1] = ai[p][r]; }
+				const double sum = valu_reduce16(v, lane);
+				const unsigned o = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+				const unsigned k = (g0 + (unsigned)p * (unsigned)FL_WAVES + wv) * R + (o >> 1);
+				if ((lane & 3) == 0 && k < d.Ns) pout[(size_t)k * 2 + (o & 1)] = (o & 1) ? -sum : sum; // conj
 			}
 		}
 	}

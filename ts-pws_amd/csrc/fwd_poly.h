@@ -61,6 +61,115 @@ struct ReduceScatter {
 	}
 };
 
+// ---- 64-lane reduce-scatter of 16 doubles on the VALU (no LDS traffic) ------------------------------------------
+// gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves / 16-lane rows in ONE VALU op: with A = the
+// element the lower partner keeps and B = the element the upper partner keeps, swap(A, B) leaves {own A, partner's A}
+// in the lower lanes and {partner's B, own B} in the upper lanes, so A + B is the reduced element on both sides -- no
+// selects.  Lane bits 3 and 2 use DPP (row_ror:8 = xor 8, row_half_mirror pairs i <-> 7-i across bit 2), bits 1, 0 are
+// plain quad butterflies.  On return every lane holds ONE finished sum: element  8*b5 + 4*b4 + 2*b3 + b2  of v
+// (b_k = bit k of the lane id); the four lanes of a quad hold the same value.
+__device__ __forceinline__ double dpp_mov_f64(double x, const int ctrl_sel)
+{
+	const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+	unsigned rl, rh;
+	switch (ctrl_sel) {
+	case 0: rl = __builtin_amdgcn_update_dpp(0u, lo, 0x128, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0u, hi, 0x128, 0xf, 0xf, true); break; // row_ror:8
+	case 1: rl = __builtin_amdgcn_update_dpp(0u, lo, 0x141, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0u, hi, 0x141, 0xf, 0xf, true); break; // row_half_mirror
+	case 2: rl = __builtin_amdgcn_update_dpp(0u, lo, 0x4E, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0u, hi, 0x4E, 0xf, 0xf, true); break;   // quad xor 2
+	default: rl = __builtin_amdgcn_update_dpp(0u, lo, 0xB1, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0u, hi, 0xB1, 0xf, 0xf, true); break;  // quad xor 1
+	}
+	return __hiloint2double((int)rh, (int)rl);
+}
+
+template <bool ROW16>
+__device__ __forceinline__ double swap_add_f64(double a, double b)
+{
+	const unsigned al = (unsigned)__double2loint(a), ah = (unsigned)__double2hiint(a);
+	const unsigned bl = (unsigned)__double2loint(b), bh = (unsigned)__double2hiint(b);
+	if (ROW16) {
+		const auto l = __builtin_amdgcn_permlane16_swap(al, bl, false, false);
+		const auto h = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+		return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+	}
+	const auto l = __builtin_amdgcn_permlane32_swap(al, bl, false, false);
+	const auto h = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
+	return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+
+__device__ __forceinline__ double valu_reduce16(const double (&v)[16], const unsigned lane)
+{
+	double s8[8], s4[4], s2[2];
+#pragma unroll
+	for (int i = 0; i < 8; i++) s8[i] = swap_add_f64<false>(v[i], v[i + 8]);   // lane bit 5
+#pragma unroll
+	for (int i = 0; i < 4; i++) s4[i] = swap_add_f64<true>(s8[i], s8[i + 4]);  // lane bit 4
+	const bool up3 = (lane & 8) != 0, up2 = (lane & 4) != 0;
+#pragma unroll
+	for (int i = 0; i < 2; i++) {                                              // lane bit 3
+		const double send = up3 ? s4[i] : s4[i + 2], keep = up3 ? s4[i + 2] : s4[i];
+		s2[i] = keep + dpp_mov_f64(send, 0);
+	}
+	const double send = up2 ? s2[0] : s2[1], keep = up2 ? s2[1] : s2[0];       // lane bit 2 (mirror pairing)
+	double r = keep + dpp_mov_f64(send, 1);
+	r += dpp_mov_f64(r, 2);
+	r += dpp_mov_f64(r, 3);
+	return r;
+}
+
+// ---- reduce-scatter of 16 doubles over the low LOGD lane bits on the VALU -------------------------------------------
+// Same bookkeeping as ReduceScatter (a lane whose bit is set keeps the upper half of the live values; on return the
+// lane holds `n` finished sums, elements first .. first+n-1), but the lane bits are visited from the highest down and
+// every exchange is a permlane swap (bit 4) or a DPP move (bits 3..0): no ds_bpermute, i.e. no LDS-pipe traffic.
+template <int NCUR, int CTRL_SEL>
+__device__ __forceinline__ void dpp_rs_stage(double (&v)[16], const bool up)
+{
+	constexpr int half = NCUR / 2;
+#pragma unroll
+	for (int i = 0; i < half; i++) {
+		const double send = up ? v[i] : v[i + half], keep = up ? v[i + half] : v[i];
+		v[i] = keep + dpp_mov_f64(send, CTRL_SEL);
+	}
+}
+
+template <int LOGD>
+__device__ __forceinline__ void valu_rs16(double (&v)[16], const unsigned lane, int &n, unsigned &first)
+{
+	static_assert(LOGD >= 0 && LOGD <= 5, "group of at most 32 phase lanes");
+	n = 16; first = 0;
+	if constexpr (LOGD >= 5) { // bit 4: 16-lane rows, swap form (no selects)
+#pragma unroll
+		for (int i = 0; i < 8; i++) v[i] = swap_add_f64<true>(v[i], v[i + 8]);
+		n = 8; if (lane & 16) first += 8;
+	}
+	if constexpr (LOGD >= 4) { // bit 3: row_ror:8
+		if constexpr (LOGD >= 5) dpp_rs_stage<8, 0>(v, (lane & 8) != 0); else dpp_rs_stage<16, 0>(v, (lane & 8) != 0);
+		n >>= 1; if (lane & 8) first += (unsigned)n;
+	}
+	if constexpr (LOGD >= 3) { // bit 2: row_half_mirror
+		if constexpr (LOGD >= 5) dpp_rs_stage<4, 1>(v, (lane & 4) != 0);
+		else if constexpr (LOGD == 4) dpp_rs_stage<8, 1>(v, (lane & 4) != 0);
+		else dpp_rs_stage<16, 1>(v, (lane & 4) != 0);
+		n >>= 1; if (lane & 4) first += (unsigned)n;
+	}
+	if constexpr (LOGD >= 2) { // bit 1: quad xor 2
+		if constexpr (LOGD >= 5) dpp_rs_stage<2, 2>(v, (lane & 2) != 0);
+		else if constexpr (LOGD == 4) dpp_rs_stage<4, 2>(v, (lane & 2) != 0);
+		else if constexpr (LOGD == 3) dpp_rs_stage<8, 2>(v, (lane & 2) != 0);
+		else dpp_rs_stage<16, 2>(v, (lane & 2) != 0);
+		n >>= 1; if (lane & 2) first += (unsigned)n;
+	}
+	if constexpr (LOGD >= 1) { // bit 0: quad xor 1 (a plain butterfly once a single value is left)
+		if constexpr (LOGD >= 5) v[0] += dpp_mov_f64(v[0], 3);
+		else {
+			if constexpr (LOGD == 4) dpp_rs_stage<2, 3>(v, (lane & 1) != 0);
+			else if constexpr (LOGD == 3) dpp_rs_stage<4, 3>(v, (lane & 1) != 0);
+			else if constexpr (LOGD == 2) dpp_rs_stage<8, 3>(v, (lane & 1) != 0);
+			else dpp_rs_stage<16, 3>(v, (lane & 1) != 0);
+			n >>= 1; if (lane & 1) first += (unsigned)n;
+		}
+	}
+}
+
 template <typename TIn, int B>
 __global__ void __launch_bounds__(256) k_fwd_poly(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned N,
                                                   const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
@@ -149,7 +258,24 @@ __global__ void __launch_bounds__(256) k_fwd_poly(const TIn *__restrict__ x, siz
 		}
 	}
 
-	// ---- combine the DL phase lanes of each group: reduce-scatter over lane bits 0..logDL-1 ----
+	// ---- combine the DL phase lanes of each group ----
+	if (d.logDL == 6) { // 64 phase lanes (every coarse scale): VALU reduction, one trace at a time, no LDS traffic
+		const unsigned o = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+#pragma unroll
+		for (int b = 0; b < B; b++) {
+			double v16[16];
+#pragma unroll
+			for (int r = 0; r < R; r++) { v16[2 * r] = ar[b][r]; v16[2 * r + 1] = ai[b][r]; }
+			const double sum = valu_reduce16(v16, lane);
+			const unsigned t = blockIdx.y * B + b, k = k0 + (o >> 1);
+			if ((lane & 3) == 0 && t < ntr && k < d.Ns) {
+				double *dst = (double *)(part + (size_t)t * npart + d.part_off + (size_t)split * d.Ns);
+				dst[(size_t)k * 2 + (o & 1)] = (o & 1) ? -sum : sum; // conj
+			}
+		}
+		return;
+	}
+	// fewer than 64 phase lanes per group: shuffle reduce-scatter over lane bits 0..logDL-1
 	constexpr int NV = 2 * B * R;
 	double v[NV];
 #pragma unroll
