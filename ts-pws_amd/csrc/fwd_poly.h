@@ -343,8 +343,11 @@ __global__ void __launch_bounds__(256) k_gather_parts(const double2 *__restrict_
 }
 
 // ST += sum_b Y_b ; PS += sum_b Y_b/|Y_b|  straight from the split partials (ts_pws1f_lib.c:489-492).
-// One block = 256 consecutive coefficients of ONE scale (acc_off[s] = first block of scale s), so the scale
-// lookup and descriptor reads are wave-uniform scalar work.
+// One block works on ONE scale (acc2_off[s] = its first block), so the scale lookup and descriptor reads are
+// wave-uniform scalar work.  Scales without splits: 256 coefficients per block, one thread each.  Split scales (coarse
+// scales: few coefficients, up to 32 partials each): 32 coefficients per block, 8 lanes per coefficient share the
+// partial loads and combine with three shuffles -- otherwise a handful of threads would walk hundreds of dependent-
+// latency loads and set the kernel's duration.
 __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restrict__ part, size_t npart, const ScaleDesc *__restrict__ sc,
                                                           unsigned S, unsigned ntr, double2 *__restrict__ ST, double2 *__restrict__ PS,
                                                           int zero_first)
@@ -352,28 +355,37 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 	unsigned lo = 0, hi = S;
 	while (hi - lo > 1) {
 		const unsigned mid = (lo + hi) >> 1;
-		if (sc[mid].acc_off <= blockIdx.x) lo = mid; else hi = mid;
+		if (sc[mid].acc2_off <= blockIdx.x) lo = mid; else hi = mid;
 	}
 	const unsigned Ns = sc[lo].Ns, nsplit = sc[lo].nsplit;
-	const unsigned k = (blockIdx.x - sc[lo].acc_off) * 256 + threadIdx.x;
-	if (k >= Ns) return;
-	const size_t i = sc[lo].coef_off + k;
-	const double2 *p0 = part + sc[lo].part_off + k;
-	double2 st = zero_first ? make_double2(0, 0) : ST[i];
-	double2 ps = zero_first ? make_double2(0, 0) : PS[i];
+	const bool wide = nsplit > 1;
+	const unsigned sub = wide ? (threadIdx.x & 7) : 0, stride = wide ? 8u : 1u;
+	const unsigned k = (blockIdx.x - sc[lo].acc2_off) * (wide ? 32u : 256u) + (wide ? threadIdx.x >> 3 : threadIdx.x);
+	const bool live = k < Ns;
+	if (!wide && !live) return;
+	const unsigned kc = live ? k : Ns - 1; // lanes past the end still take part in the shuffles
+	const size_t i = sc[lo].coef_off + kc;
+	const double2 *p0 = part + sc[lo].part_off + kc;
+	double2 st = make_double2(0, 0), ps = make_double2(0, 0);
+	if (!zero_first && sub == 0) { st = ST[i]; ps = PS[i]; }
 	for (unsigned b = 0; b < ntr; b++) {
 		const double2 *p = p0 + (size_t)b * npart;
-		double2 v = p[0];
-		// split partials in groups of 8 independent loads (nsplit is block-uniform), summed in split order
-		for (unsigned sp = 1; sp < nsplit; sp += 8) {
-			double2 t[8];
+		double2 v = make_double2(0.0, 0.0);
+		for (unsigned sp = sub; sp < nsplit; sp += 4 * stride) { // up to four independent loads per lane and round
+			double2 t[4];
 #pragma unroll
-			for (int j = 0; j < 8; j++) t[j] = (sp + j < nsplit) ? p[(size_t)(sp + j) * Ns] : make_double2(0.0, 0.0);
+			for (int j = 0; j < 4; j++) t[j] = (sp + (unsigned)j * stride < nsplit) ? p[(size_t)(sp + (unsigned)j * stride) * Ns] : make_double2(0.0, 0.0);
 #pragma unroll
-			for (int j = 0; j < 8; j++) { v.x += t[j].x; v.y += t[j].y; }
+			for (int j = 0; j < 4; j++) { v.x += t[j].x; v.y += t[j].y; }
 		}
-		st.x += v.x; st.y += v.y;
-		add_unit_phasor(ps, v);
+		if (wide) {
+#pragma unroll
+			for (int o = 1; o < 8; o <<= 1) { v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); }
+		}
+		if (sub == 0) {
+			st.x += v.x; st.y += v.y;
+			add_unit_phasor(ps, v);
+		}
 	}
-	ST[i] = st; PS[i] = ps;
+	if (sub == 0 && live) { ST[i] = st; PS[i] = ps; }
 }

@@ -65,7 +65,8 @@ struct ScaleDesc {
 	unsigned acc_off;           // first 256-coefficient block of this scale in k_accumulate_parts
 	unsigned use_lds;           // 1: forward transform by k_fwd_lds (fwd_lds.h), 0: k_fwd_poly
 	unsigned lds_off, lds_bps;  // first workgroup of this scale in k_fwd_lds, workgroups per split
-	unsigned pad0, pad1;
+	unsigned acc2_off;          // first block of this scale in k_accumulate_parts (32 coefficients per block when split)
+	unsigned pad1;
 	unsigned long long part_off; // offset of this scale's [nsplit][Ns] partial block
 };
 
@@ -94,7 +95,8 @@ struct tspws_hip_plan {
 	size_t ncoef = 0, ntaps = 0;
 	size_t npart = 0;          // complex partial coefficients per trace (sum of nsplit*Ns)
 	unsigned fwd_waves = 0;    // waves per trace batch of k_fwd_poly
-	unsigned acc_blocks = 0;   // blocks of k_accumulate_parts
+	unsigned acc_blocks = 0;   // blocks of k_accumulate_masked (256 coefficients each)
+	unsigned acc2_blocks = 0;  // blocks of k_accumulate_parts
 	unsigned lds_blocks = 0;   // workgroups per trace slice of k_fwd_lds / workgroups of k_fwd_tl
 	int fwd_kind = 1;          // 0: k_fwd_poly only, 1: k_fwd_lds (+poly), 2: k_fwd_tl (+poly)
 	unsigned tl_rows = 0;      // tap rows (of 64 double2) k_fwd_tl keeps in LDS
@@ -334,7 +336,7 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 			else d.lds_bps = (NG + FL_SLOTS_HOST * GW - 1) / (FL_SLOTS_HOST * GW);
 			if (d.use_lds) boff += d.lds_bps * d.nsplit; else woff += d.ngw * d.nsplit;
 			poff += (unsigned long long)d.nsplit * d.Ns;
-			d.pad0 = d.pad1 = 0;
+			d.pad1 = 0;
 		}
 		p->fwd_waves = woff; p->lds_blocks = boff; p->npart = poff;
 	}
@@ -342,6 +344,8 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 		p->sc[s].inv_fast = (N % p->sc[s].D == 0) ? 1u : 0u;
 		p->sc[s].acc_off = p->acc_blocks;
 		p->acc_blocks += (p->sc[s].Ns + 255) / 256;
+		p->sc[s].acc2_off = p->acc2_blocks;
+		p->acc2_blocks += p->sc[s].nsplit > 1 ? (p->sc[s].Ns + 31) / 32 : (p->sc[s].Ns + 255) / 256;
 	}
 
 	hipError_t e;
@@ -875,7 +879,7 @@ static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld,
 	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
 		const size_t nb = std::min(batch, ntr - t0);
 		if ((rc = forward_parts<TIn>(p, d_x + t0 * ld, nb, ld, (double2 *)v, st))) return rc;
-		hipLaunchKernelGGL(k_accumulate_parts, dim3(p->acc_blocks), dim3(256), 0, st, (const double2 *)v, p->npart, p->d_sc, p->S,
+		hipLaunchKernelGGL(k_accumulate_parts, dim3(p->acc2_blocks), dim3(256), 0, st, (const double2 *)v, p->npart, p->d_sc, p->S,
 		                   (unsigned)nb, (double2 *)d_ST, (double2 *)d_PS, t0 == 0 ? 1 : 0);
 	}
 	HIP_TRY(hipGetLastError());
@@ -1296,7 +1300,7 @@ extern "C" int tspws_hip_stack(tspws_hip_plan *pl, const t_tsPWS *p, const float
 			HIP_TRY(hipEventRecord(pl->ev_grp[g], A));
 			HIP_TRY(hipStreamWaitEvent(Bq, pl->ev_grp[g], 0));
 			if ((rc = forward_parts<double>(pl, P + (size_t)gb * N, nb, N, part + (size_t)gb * pl->npart, Bq))) return rc;
-			hipLaunchKernelGGL(k_accumulate_parts, dim3(pl->acc_blocks), dim3(256), 0, Bq, (const double2 *)(part + (size_t)gb * pl->npart),
+			hipLaunchKernelGGL(k_accumulate_parts, dim3(pl->acc2_blocks), dim3(256), 0, Bq, (const double2 *)(part + (size_t)gb * pl->npart),
 			                   pl->npart, pl->d_sc, pl->S, nb, (double2 *)ST, (double2 *)PS, gb == 0 ? 1 : 0);
 		}
 	}
@@ -1672,7 +1676,7 @@ extern "C" int tspws_hip_convergence(tspws_hip_plan *pl, const t_tsPWS *p, const
 		if (!p->Kmax || p->Kmax >= Tr) { // incremental single-stage step (tspws_stacks_float_1step, :835-863)
 			K = (unsigned)Tr;
 			if ((rc = forward_parts<float>(pl, d_x + i * ld, 1, ld, part, st))) return rc;
-			hipLaunchKernelGGL(k_accumulate_parts, dim3(pl->acc_blocks), dim3(256), 0, st, (const double2 *)part, pl->npart, pl->d_sc, pl->S, 1u,
+			hipLaunchKernelGGL(k_accumulate_parts, dim3(pl->acc2_blocks), dim3(256), 0, st, (const double2 *)part, pl->npart, pl->d_sc, pl->S, 1u,
 			                   (double2 *)ST, (double2 *)PS, i == 0 ? 1 : 0);
 		} else { // two-stage over the first Tr traces, recomputed from scratch like the reference (:266-268)
 			K = p->Kmax;
