@@ -380,3 +380,45 @@ def test_random_subsampling_vs_oracle(lib, kw):
         assert abi.relerr(a["sub_ts"][m], b["sub_ts"][m]) < TOL32, m
     if kw["subsmpl_p"] == 1.0 and not kw.get("Kmax"):  # every trace kept: each subsample is the full single-stage stack
         assert abi.relerr(a["sub_ts"][0], a["tsPWS"]) < TOL32
+
+
+# ------------------------------------------------------------------------------- layout edge cases
+@pytest.mark.parametrize("pad", [4, 1])
+def test_padded_rows_and_many_traces(lib, torch, pad):
+    """Row stride ld > N (vectorised when ld % 4 == 0, scalar otherwise) through the device-resident path."""
+    mtr, N, K = 70, 4096, 7
+    p = tspws.resolve(abi.default_params(Kmax=K, unbiased=1), N)
+    pl = tspws.Plan(p, N)
+    X = abi.synth_traces(mtr, N, seed=44)
+    buf = torch.zeros((mtr, N + pad), dtype=torch.float32, device="cuda")
+    buf[:, :N] = torch.as_tensor(X, device="cuda")
+    view = buf[:, :N]  # shape (mtr, N), stride (N + pad, 1)
+    assert view.stride(0) == N + pad
+    ls, ts = pl.stack(view)
+    torch.cuda.synchronize()
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(Kmax=K, unbiased=1), X)
+    assert abi.relerr(ls.cpu().numpy(), want["ls"]) < TOL32 and abi.relerr(ts.cpu().numpy(), want["tsPWS"]) < TOL32
+    # single-stage through the same strided view (float input path of the forward kernels)
+    p1 = tspws.resolve(abi.default_params(), N)
+    pl1 = tspws.Plan(p1, N)
+    ls1, ts1 = pl1.stack(view[:12])
+    torch.cuda.synchronize()
+    want1 = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(), X[:12])
+    assert abi.relerr(ts1.cpu().numpy(), want1["tsPWS"]) < TOL32 and abi.relerr(ls1.cpu().numpy(), want1["ls"]) < TOL32
+
+
+def test_plan_reuse_and_argument_errors(lib, torch):
+    N = 2048
+    p = tspws.resolve(abi.default_params(Kmax=4), N)
+    pl = tspws.Plan(p, N)
+    X = tspws.synth(16, N, seed=9)
+    a = [t.cpu().numpy() for t in pl.stack(X)]
+    b = [t.cpu().numpy() for t in pl.stack(X)]       # same plan, same inputs: bit-identical (deterministic reductions)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    h = C.c_void_p()
+    assert lib.tspws_hip_plan_create(C.byref(h), 1, 4, 4, N, 2.0, 1.0, abi.W0_DEFAULT, 0, 0) == 7      # real families are out of scope
+    assert lib.tspws_hip_plan_create(C.byref(h), -1, 0, 4, N, 2.0, 1.0, abi.W0_DEFAULT, 0, 0) == 7     # empty frame
+    assert lib.tspws_hip_plan_create(C.byref(h), -1, 4, 4, N, 2.0, 1.0, abi.W0_DEFAULT, 0, 99) == 5    # no such device
+    assert lib.tspws_hip_partial_stacks(pl.h, None, N, 4, 0, 4, 2, None, N, None) == -1
+    assert b"partial_stacks" in lib.tspws_hip_last_error()

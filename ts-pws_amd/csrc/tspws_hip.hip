@@ -303,7 +303,9 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 	{ // forward decomposition.  Scales with >= 8 output groups and (D >= 64 or D a power of two) run on the
 	  // LDS-staged kernel; the rest (very coarse scales, odd small decimations) on the direct kernel, which
 	  // aims at ~FWD_STEPS tap steps per wave.
-		const unsigned R = 8, FWD_STEPS = 96, FL_SLOTS_HOST = FL_WAVES * FL_PASSES_HOST;
+		unsigned FWD_STEPS = 96; // tap steps per wave of the direct kernel (more splits = shorter dependent load chains)
+		if (const char *e = getenv("TSPWS_FWD_STEPS")) FWD_STEPS = (unsigned)std::max(8, atoi(e));
+		const unsigned R = 8, FL_SLOTS_HOST = FL_WAVES * FL_PASSES_HOST;
 		int kind = 1;
 		if (const char *e = getenv("TSPWS_FWD_KERNEL")) kind = !strcmp(e, "poly") ? 0 : !strcmp(e, "tl") ? 2 : 1;
 		if (getenv("TSPWS_FWD_NOLDS") && *getenv("TSPWS_FWD_NOLDS") == '1') kind = 0;
