@@ -430,16 +430,31 @@ extern "C" int tspws_hip_alloc(void **d, size_t bytes, int device)
 	return 0;
 }
 extern "C" int tspws_hip_free(void *d) { if (d) HIP_TRY(hipFree(d)); return 0; }
+// Large host buffers are pinned in place for the duration of the copy: measured on the MI355X box, a pageable 2 GB
+// hipMemcpy runs at ~16 GB/s while hipHostRegister (~10 ms per GB) + copy runs at ~57 GB/s.
+static bool pin_for_copy(const void *h, size_t bytes)
+{
+	return bytes >= ((size_t)32 << 20) && hipHostRegister(const_cast<void *>(h), bytes, hipHostRegisterDefault) == hipSuccess;
+}
+
 extern "C" int tspws_hip_upload(void *d, const void *h, size_t bytes, void *s)
 {
-	HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, S_(s)));
-	HIP_TRY(hipStreamSynchronize(S_(s)));
+	const bool pinned = pin_for_copy(h, bytes);
+	if (!pinned) (void)hipGetLastError(); // a failed registration is not an error: fall back to the pageable path
+	hipError_t e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, S_(s));
+	if (e == hipSuccess) e = hipStreamSynchronize(S_(s));
+	if (pinned) (void)hipHostUnregister(const_cast<void *>(h));
+	HIP_TRY(e);
 	return 0;
 }
 extern "C" int tspws_hip_download(void *h, const void *d, size_t bytes, void *s)
 {
-	HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, S_(s)));
-	HIP_TRY(hipStreamSynchronize(S_(s)));
+	const bool pinned = pin_for_copy(h, bytes);
+	if (!pinned) (void)hipGetLastError();
+	hipError_t e = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, S_(s));
+	if (e == hipSuccess) e = hipStreamSynchronize(S_(s));
+	if (pinned) (void)hipHostUnregister(h);
+	HIP_TRY(e);
 	return 0;
 }
 extern "C" int tspws_hip_zero(void *d, size_t bytes, void *s) { HIP_TRY(hipMemsetAsync(d, 0, bytes, S_(s))); return 0; }
