@@ -690,6 +690,117 @@ int orc_tspws_main(t_tsPWS *p, t_tsPWS_out *out, t_data *in)
 	return 0;
 }
 
+/* --------------------------------------------------------------------------
+ * Trace-/scale-parallel OpenMP variant of the main stack (single- or two-stage, no resampling): the "honest
+ * stronger" host baseline of BASELINE.md section 3.  Same arithmetic and the same per-element summation order as
+ * orc_tspws_main (results are bit-identical); only the loops are distributed: partial stacks by column blocks,
+ * forward transforms by (trace, scale), accumulation / weighting by coefficient, inverse by sample.
+ * -------------------------------------------------------------------------- */
+static void forward_one_scale(const orc_frame *f, unsigned s, const double *x, cplx *Y)
+{
+	const size_t N = f->N;
+	const cplx *w = f->w + f->tap_off[s];
+	cplx *y = Y + f->coef_off[s];
+	const size_t L = f->L[s], D = f->D[s], c = (size_t)f->c[s];
+	for (size_t k = 0; k < f->Ns[s]; k++) {
+		const size_t n0 = (N + k * D - c) % N;
+		const size_t l0 = (N - n0 < L) ? N - n0 : L;
+		cplx acc = 0;
+		const double *xp = x + n0;
+		for (size_t l = 0; l < l0; l++) acc += xp[l] * w[l];
+		for (size_t l = l0; l < L; l++) acc += x[l - l0] * w[l];
+		y[k] = conj(acc);
+	}
+}
+
+static void inverse_mt(const orc_frame *f, const cplx *Y, double *xrec)
+{
+	const size_t N = f->N;
+#pragma omp parallel for schedule(static)
+	for (size_t n = 0; n < N; n++) {
+		double tot = 0;
+		for (unsigned s = 0; s < f->S; s++) {
+			const cplx *wd = f->wd + f->tap_off[s];
+			const cplx *y = Y + f->coef_off[s];
+			const size_t L = f->L[s], D = f->D[s], cd = (size_t)f->cd[s];
+			const size_t n0 = (N + n - cd) % N, l0 = N - n0, lim = L < l0 ? L : l0;
+			double acc = 0, bf;
+			if (D > 1) {
+				size_t l = (D - n0 % D) % D, q = (n0 + D - 1) / D;
+				for (; l < lim; l += D, q++) acc += creal(wd[l]) * creal(y[q]) + cimag(wd[l]) * cimag(y[q]);
+				q = 0;
+				for (l = l0; l < L; l += D, q++) acc += creal(wd[l]) * creal(y[q]) + cimag(wd[l]) * cimag(y[q]);
+				bf = (double)D * acc;
+			} else {
+				for (size_t l = 0; l < lim; l++) acc += creal(wd[l]) * creal(y[n0 + l]) + cimag(wd[l]) * cimag(y[n0 + l]);
+				for (size_t l = lim; l < L; l++) acc += creal(wd[l]) * creal(y[l - l0]) + cimag(wd[l]) * cimag(y[l - l0]);
+				bf = acc;
+			}
+			tot += (log(2.0) / (2 * f->Cpsi * f->V * f->scale[s])) * bf;
+		}
+		xrec[n] = tot;
+	}
+}
+
+int orc_tspws_main_mt(t_tsPWS *p, t_tsPWS_out *out, t_data *in)
+{
+	if (!p || !out || !in) return -1;
+	if (p->fold || p->lrm || p->convergence || p->subsmpl_N || p->jackknife_n) return orc_tspws_main(p, out, in);
+	const float *sigall = in->sigall;
+	const size_t max = (size_t)in->hdr.max, mtr = p->Nmax ? p->Nmax : in->hdr.mtr;
+	orc_resolve(p, (unsigned)max, in->hdr.dt);
+	orc_frame *f = orc_frame_create(p->type, p->J, p->V, (unsigned)max, p->s0, p->b0, p->w0, (int)p->uni);
+	if (!f) return 4;
+	if (!mtr) { orc_frame_destroy(f); return 0; }
+	const size_t nc = orc_frame_ncoef(f);
+	const int two_stage = !(!p->Kmax || p->Kmax > mtr);
+	const unsigned K = two_stage ? p->Kmax : (unsigned)mtr;
+	cplx *ST = calloc(nc, sizeof(cplx)), *PS = calloc(nc, sizeof(cplx)), *OUT = malloc(nc * sizeof(cplx));
+	double *xa = malloc(max * sizeof(double)), *xb = malloc(max * sizeof(double));
+	const size_t batch = two_stage ? K : (mtr < 64 ? mtr : 64);
+	cplx *Y = malloc(batch * nc * sizeof(cplx));
+	double *X = malloc(batch * max * sizeof(double));
+	for (size_t t0 = 0; t0 < (two_stage ? (size_t)K : mtr); t0 += batch) {
+		const size_t nb = two_stage ? K : (mtr - t0 < batch ? mtr - t0 : batch);
+		if (two_stage) { /* partial stacks by column blocks: every element still sums its traces in order */
+#pragma omp parallel for schedule(static)
+			for (size_t n0 = 0; n0 < max; n0 += 2048) {
+				const size_t n1 = n0 + 2048 < max ? n0 + 2048 : max;
+				for (unsigned g = 0; g < K; g++) for (size_t n = n0; n < n1; n++) X[g * max + n] = 0;
+				for (size_t i = 0; i < mtr; i++) {
+					const size_t g = (size_t)floor((double)(i * K) / (double)mtr);
+					const float *x = sigall + i * max;
+					double *pg = X + g * max;
+					for (size_t n = n0; n < n1; n++) pg[n] += (double)x[n];
+				}
+			}
+		} else {
+#pragma omp parallel for schedule(static)
+			for (size_t b = 0; b < nb; b++)
+				for (size_t n = 0; n < max; n++) X[b * max + n] = (double)sigall[(t0 + b) * max + n];
+		}
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+		for (size_t b = 0; b < nb; b++)
+			for (unsigned s = 0; s < f->S; s++) forward_one_scale(f, f->S - 1 - s, X + b * max, Y + b * nc);
+#pragma omp parallel for schedule(static)
+		for (size_t i = 0; i < nc; i++)
+			for (size_t b = 0; b < nb; b++) {
+				cplx v = Y[b * nc + i];
+				ST[i] += v;
+				v /= cabs(v);
+				if (creal(v * conj(v)) <= 1.001) PS[i] += v;
+			}
+	}
+	weight(OUT, ST, PS, nc, K, (unsigned)mtr, p->wu, p->unbiased);
+	inverse_mt(f, OUT, xa);
+	inverse_mt(f, ST, xb);
+	for (size_t n = 0; n < max; n++) out->ls[n] = (float)xb[n] / (unsigned)mtr;
+	for (size_t n = 0; n < max; n++) out->tsPWS[n] = (float)xa[n];
+	free(Y); free(X); free(ST); free(PS); free(OUT); free(xa); free(xb);
+	orc_frame_destroy(f);
+	return 0;
+}
+
 /* Stand-alone pieces exposed to the tests ------------------------------------ */
 void orc_accumulate(double *ST, double *PS, const double *Y, size_t ncoef)
 {

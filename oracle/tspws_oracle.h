@@ -34,6 +34,7 @@ void orc_resolve(t_tsPWS *p, unsigned nsamp, float dt);
 int  orc_subsampling_plan(char *sel, size_t J, size_t K);
 int  orc_jackknife_plan(char *sel, const time_t *tm, size_t mtr, unsigned d, unsigned n, unsigned C);
 int  orc_tspws_main(t_tsPWS *p, t_tsPWS_out *out, t_data *in);
+int  orc_tspws_main_mt(t_tsPWS *p, t_tsPWS_out *out, t_data *in); /* OpenMP trace-/scale-parallel variant, bit-identical results */
 
 #ifdef __cplusplus
 }

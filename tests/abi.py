@@ -200,6 +200,7 @@ def oracle():
         lib.orc_jackknife_plan.restype = i
         lib.orc_jackknife_plan.argtypes = [vp, vp, sz, u, u, u]
         lib.orc_tspws_main.restype = i
+        lib.orc_tspws_main_mt.restype = i
         lib._typed = True
     return lib
 

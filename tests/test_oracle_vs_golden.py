@@ -142,3 +142,14 @@ def test_example_data(golden):
         assert abi.relerr(r["ls"], g[f"{name}/ls"]) < 2e-7, name
         assert abi.relerr(r["tsPWS"], g[f"{name}/tsPWS"]) < 2e-7, name
         assert r["params"].fold == g[f"{name}/out/fold"].item()
+
+
+def test_parallel_restatement_is_bit_identical():
+    """orc_tspws_main_mt (the stronger host baseline of bench.py) only redistributes loops."""
+    X = abi.synth_traces(40, 4096, seed=5)
+    for kw in (dict(Kmax=10, unbiased=1), dict(), dict(type=-3, Kmax=4), dict(wu=1.5)):
+        p = abi.default_params(**kw)
+        a = abi.run_main(abi.oracle().orc_tspws_main, p, X)
+        b = abi.run_main(abi.oracle().orc_tspws_main_mt, p, X)
+        np.testing.assert_array_equal(a["ls"], b["ls"])
+        np.testing.assert_array_equal(a["tsPWS"], b["tsPWS"])
