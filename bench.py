@@ -123,7 +123,7 @@ def main():
             traffic = None
 
     res = {
-        "metric": "stacked samples/s (Morlet ts-PWS, 10k x 131072)",
+        "metric": baseline_metric(),
         "value": mtr_global * N * args.steps / dt,
         "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -147,6 +147,14 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def baseline_metric():
+    """The metric string of BASELINE.json (its `metric` is quoted on the 10k x 131072 Morlet config this bench runs)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "stacked samples/s (Morlet ts-PWS, 10k\u00d7131072) + % HBM roofline, 1/2/4/8 GPU"
 
 
 def cpu_baseline(abi, X, params_in, ls, ts, N, mtr):

@@ -32,11 +32,18 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 	if (tspws == NULL || out == NULL || in == NULL) { printf("tspws_main: NULL input\n"); return -1; }
 
 	const int    max   = in->hdr.max;
-	const size_t mtr   = tspws->Nmax ? tspws->Nmax : in->hdr.mtr;
+	size_t mtr = tspws->Nmax ? tspws->Nmax : in->hdr.mtr;
 	const float  beg   = in->hdr.beg, dt = in->hdr.dt;
 	const unsigned nsamp = (unsigned)max;
 	const int dev = device_from_env();
 	int rc = 0, do_fold = 0;
+
+	/* The reference reads past the end of sigall when Nmax exceeds the trace count (:65, unchecked); here the request
+	 * is clamped instead of faulting. */
+	if (tspws->Nmax > in->hdr.mtr) {
+		printf("tspws_main: Nmax = %u exceeds the %u traces given; using them all.\n", tspws->Nmax, in->hdr.mtr);
+		mtr = in->hdr.mtr;
+	}
 
 	/* fold test, same float arithmetic as :72 */
 	if (tspws->fold) {

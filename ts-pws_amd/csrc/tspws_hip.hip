@@ -1469,19 +1469,31 @@ static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d
 		                   d_P + (size_t)r0 * N, N);
 	}
 	HIP_TRY(hipGetLastError());
-	// per replica: stacks of the KM partials, weight with (KM, K_c), inverse, outputs
+	// Replicas are processed in batches: ONE forward launch transforms the KM partials of a whole batch of replicas (the
+	// kernels fill the GPU far better with 100 traces than with 10), then per replica the phase accumulation and the
+	// weight (KM, K_c), and the inverses two replicas at a time.
 	const size_t nc = pl->ncoef;
-	if ((rc = scratch(pl, SCR_JKOUT, (6 * nc + N) * sizeof(double), &v))) return rc;
-	double *OUT = (double *)v, *ST = OUT + 2 * nc, *PS = ST + 2 * nc, *xr = PS + 2 * nc;
-	for (unsigned c = 0; c < C; c++) {
-		const double *Pc = d_P + (size_t)c * KM * N;
-		h_mtr_out[c] = (unsigned)Kc[c];
-		if ((rc = tspws_hip_stacks_double(pl, Pc, KM, N, ST, PS, s))) return rc;
-		if ((rc = tspws_hip_weight(pl, OUT, ST, PS, KM, (unsigned)Kc[c], p->wu, p->unbiased, s))) return rc;
-		if ((rc = tspws_hip_inverse(pl, OUT, 1, xr, s))) return rc;
-		if ((rc = tspws_hip_epilogue(nullptr, d_ts_out + (size_t)c * N, nullptr, xr, N, 1, s))) return rc;
-		hipLaunchKernelGGL(k_jk_linear, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, Pc, KM, N, 1. / (double)Kc[c],
-		                   d_ls_out + (size_t)c * N);
+	unsigned RB = (unsigned)std::max<size_t>(1, std::min<size_t>(C, ((size_t)1 << 30) / std::max<size_t>(1, (size_t)KM * pl->npart * sizeof(double2))));
+	if (RB > 1) RB &= ~1u; // pairs for the two-set inverse
+	if ((rc = scratch(pl, SCR_PART, (size_t)RB * KM * pl->npart * sizeof(double2), &v))) return rc;
+	double2 *part = (double2 *)v;
+	if ((rc = scratch(pl, SCR_JKOUT, ((size_t)RB * 2 * nc + 4 * nc + (size_t)RB * N) * sizeof(double), &v))) return rc;
+	double *OUT = (double *)v, *ST = OUT + (size_t)RB * 2 * nc, *PS = ST + 2 * nc, *xr = PS + 2 * nc;
+	for (unsigned c0 = 0; c0 < C; c0 += RB) {
+		const unsigned nr = std::min(RB, C - c0);
+		if ((rc = forward_parts<double>(pl, d_P + (size_t)c0 * KM * N, (size_t)nr * KM, N, part, st))) return rc;
+		for (unsigned j = 0; j < nr; j++) {
+			const unsigned c = c0 + j;
+			h_mtr_out[c] = (unsigned)Kc[c];
+			hipLaunchKernelGGL(k_accumulate_parts, dim3(pl->acc2_blocks), dim3(256), 0, st, (const double2 *)(part + (size_t)j * KM * pl->npart),
+			                   pl->npart, pl->d_sc, pl->S, KM, (double2 *)ST, (double2 *)PS, 1);
+			if ((rc = tspws_hip_weight(pl, OUT + (size_t)j * 2 * nc, ST, PS, KM, (unsigned)Kc[c], p->wu, p->unbiased, s))) return rc;
+			hipLaunchKernelGGL(k_jk_linear, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_P + (size_t)c * KM * N, KM, N, 1. / (double)Kc[c],
+			                   d_ls_out + (size_t)c * N);
+		}
+		if ((rc = tspws_hip_inverse(pl, OUT, nr, xr, s))) return rc;
+		for (unsigned j = 0; j < nr; j++)
+			if ((rc = tspws_hip_epilogue(nullptr, d_ts_out + (size_t)(c0 + j) * N, nullptr, xr + (size_t)j * N, N, 1, s))) return rc;
 	}
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st)); // host tables above go out of scope
