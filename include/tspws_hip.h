@@ -90,6 +90,12 @@ int  tspws_hip_partial_stacks(tspws_hip_plan *plan, const float *d_sigall, size_
                               size_t mtr_local, size_t first, size_t mtr_global, unsigned Kmax,
                               double *d_P, size_t ldP, void *stream);
 
+/* Same, restricted to the groups [g_begin, g_end): only those rows of P are written.  Lets a multi-GPU caller start the
+ * all-reduce of the first groups while the later ones are still being streamed. */
+int  tspws_hip_partial_stacks_range(tspws_hip_plan *plan, const float *d_sigall, size_t ld,
+                                    size_t mtr_local, size_t first, size_t mtr_global, unsigned Kmax,
+                                    unsigned g_begin, unsigned g_end, double *d_P, size_t ldP, void *stream);
+
 /* ---- frame transforms ------------------------------------------------------------ */
 /* Forward frame CWT of ntr real traces (row stride ld elements) into d_Y[ntr][ncoef] complex.
  * Takes over complex_1D_wavelet_dec (wavelet_v7.c:43-64) -> cdotx_dc (cdotx.c:35-72). */

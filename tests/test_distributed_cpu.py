@@ -22,8 +22,11 @@ tspws = importlib.import_module("ts-pws_amd")
 class OraclePlan:
     """CPU stand-in with the interface stack_sharded needs; arithmetic by the oracle."""
 
-    def __init__(self, params, N):
+    def __init__(self, params, N, ranged=True):
         self.p = abi.resolve(params, N)
+        self.params = self.p  # stack_sharded looks at params.Kmax to choose the overlapped two-half reduction
+        if not ranged:
+            self.partial_stacks_range = None
         self.N = N
         self.f = abi.OracleFrame.from_params(self.p, N)
         self.buf = None
@@ -53,6 +56,15 @@ class OraclePlan:
             for i in range(x.shape[0]):
                 Y = self.f.forward(x[i].astype(np.float64))
                 abi.oracle().orc_accumulate(ST.ctypes.data, PS.ctypes.data, Y.ctypes.data, nc)
+
+    def partial_stacks_range(self, traces, first, mtr_global, g_begin, g_end):
+        x = traces.numpy()
+        P = self.reduce_buffer(mtr_global).numpy().reshape(self.p.Kmax, self.N)
+        P[g_begin:g_end] = 0
+        for i in range(x.shape[0]):
+            g = int(np.floor(float((first + i) * self.p.Kmax) / float(mtr_global)))
+            if g_begin <= g < g_end:
+                P[g] += x[i].astype(np.float64)
 
     def stack_finish(self, mtr_global, ls, ts):
         nc = self.f.ncoef

@@ -193,6 +193,17 @@ def test_partial_stacks_bit_exact_groups(lib, torch, mtr, N, K):
     tspws.check(lib.tspws_hip_partial_stacks(pl.h, Xd[h:].data_ptr(), N, mtr - h, h, mtr, K, B.data_ptr(), N, None))
     torch.cuda.synchronize()
     assert np.max(np.abs((A + B).cpu().numpy() - P)) <= 1e-13 * max(1.0, np.max(np.abs(P)))
+    # group ranges (the multi-GPU overlap streams the groups in two halves): rows outside the range stay untouched,
+    # rows inside are bit-identical to the one-shot call
+    if K >= 2:
+        R = torch.full((K, N), np.nan, dtype=torch.float64, device="cuda")
+        g = K // 2
+        tspws.check(lib.tspws_hip_partial_stacks_range(pl.h, Xd.data_ptr(), N, mtr, 0, mtr, K, 0, g, R.data_ptr(), N, None))
+        torch.cuda.synchronize()
+        assert torch.isnan(R[g:]).all()
+        tspws.check(lib.tspws_hip_partial_stacks_range(pl.h, Xd.data_ptr(), N, mtr, 0, mtr, K, g, K, R.data_ptr(), N, None))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(R.cpu().numpy(), got)
 
 
 def test_prologue_kernels(lib, torch):

@@ -86,6 +86,7 @@ SYMBOLS = {
     "tspws_hip_fold": (_i, [_vp, _sz, _sz, _sz, _vp]),
     "tspws_hip_remove_mean": (_i, [_vp, _sz, _sz, _sz, _vp]),
     "tspws_hip_partial_stacks": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _u, _vp, _sz, _vp]),
+    "tspws_hip_partial_stacks_range": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _u, _u, _u, _vp, _sz, _vp]),
     "tspws_hip_forward_f64": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "tspws_hip_forward_f32": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "tspws_hip_inverse": (_i, [_vp, _vp, _sz, _vp, _vp]),
@@ -199,6 +200,13 @@ class Plan:
         check(self.lib.tspws_hip_stack_local(self.h, C.byref(self.params), traces.data_ptr(), ld, mtr, first, mtr_global, self._stream()),
               "stack_local")
 
+    def partial_stacks_range(self, traces, first, mtr_global, g_begin, g_end):
+        """Two-stage only: stream the groups [g_begin, g_end) of this shard into rows of the reduce buffer."""
+        mtr, ld = traces.shape[0], traces.stride(0) if traces.shape[0] > 1 else traces.shape[1]
+        buf = self.reduce_buffer(mtr_global)
+        check(self.lib.tspws_hip_partial_stacks_range(self.h, traces.data_ptr(), ld, mtr, first, mtr_global, self.params.Kmax, g_begin, g_end,
+                                                      buf.data_ptr(), self.N, self._stream()), "partial_stacks_range")
+
     def stack_finish(self, mtr_global, ls, ts):
         check(self.lib.tspws_hip_stack_finish(self.h, C.byref(self.params), mtr_global, ls.data_ptr(), ts.data_ptr(), self._stream()),
               "stack_finish")
@@ -242,9 +250,23 @@ def stack_sharded(plan, traces, first=0, mtr_global=None, group=None):
     import torch
     import torch.distributed as dist
     mtr_global = traces.shape[0] if mtr_global is None else mtr_global
-    plan.stack_local(traces, first, mtr_global)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(plan.reduce_buffer(mtr_global), op=dist.ReduceOp.SUM, group=group)
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    K = getattr(getattr(plan, "params", None), "Kmax", 0)
+    if distributed and callable(getattr(plan, "partial_stacks_range", None)) and K >= 2 and K <= mtr_global:
+        # two-stage: the sum is row-separable, so the all-reduce of the first half of the groups runs (on the collective's
+        # own stream) while the second half is still being streamed -- still one logical reduction of P[Kmax][N]
+        half = K // 2
+        buf = plan.reduce_buffer(mtr_global).view(K, plan.N)
+        plan.partial_stacks_range(traces, first, mtr_global, 0, half)
+        w1 = dist.all_reduce(buf[:half], op=dist.ReduceOp.SUM, group=group, async_op=True)
+        plan.partial_stacks_range(traces, first, mtr_global, half, K)
+        w2 = dist.all_reduce(buf[half:], op=dist.ReduceOp.SUM, group=group, async_op=True)
+        w1.wait()
+        w2.wait()
+    else:
+        plan.stack_local(traces, first, mtr_global)
+        if distributed:
+            dist.all_reduce(plan.reduce_buffer(mtr_global), op=dist.ReduceOp.SUM, group=group)
     ls = torch.empty(plan.N, dtype=torch.float32, device=traces.device)
     ts = torch.empty(plan.N, dtype=torch.float32, device=traces.device)
     plan.stack_finish(mtr_global, ls, ts)

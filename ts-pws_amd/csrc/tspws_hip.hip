@@ -604,8 +604,10 @@ __global__ void __launch_bounds__(256) k_reduce_chunks(const double *__restrict_
 
 // Launch the streaming pass for an arbitrary chunk table (rows destinations).
 static int run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, const std::vector<Chunk> &chunks,
-                      const std::vector<unsigned> &row_first, unsigned rows, double *d_P, size_t ldP, hipStream_t st, bool upload)
+                      const std::vector<unsigned> &row_first, unsigned rows, double *d_P, size_t ldP, hipStream_t st, bool upload,
+                      unsigned row_begin = 0, unsigned row_end = ~0u)
 {
+	row_end = std::min(row_end, rows);
 	const size_t nck = chunks.size();
 	const size_t ldpc = (N + 3) & ~(size_t)3;
 	void *d_tab = nullptr, *d_pc = nullptr;
@@ -621,13 +623,14 @@ static int run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, 
 	}
 	const unsigned bx = (unsigned)((N + 1023) / 1024);
 	const bool vec = (N % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x & 15) == 0);
-	for (size_t c0 = 0; c0 < nck; c0 += 65535) {
-		const unsigned ny = (unsigned)std::min<size_t>(nck - c0, 65535);
+	const size_t ck0 = row_first[row_begin], ck1 = row_first[row_end]; // chunks are sorted by destination row
+	for (size_t c0 = ck0; c0 < ck1; c0 += 65535) {
+		const unsigned ny = (unsigned)std::min<size_t>(ck1 - c0, 65535);
 		if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, (double *)d_pc + c0 * ldpc, ldpc);
 		else hipLaunchKernelGGL(k_partial<false>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, (double *)d_pc + c0 * ldpc, ldpc);
 	}
-	for (unsigned r0 = 0; r0 < rows; r0 += 65535) {
-		const unsigned ny = std::min(rows - r0, 65535u);
+	for (unsigned r0 = row_begin; r0 < row_end; r0 += 65535) {
+		const unsigned ny = std::min(row_end - r0, 65535u);
 		hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((N + 255) / 256), ny), dim3(256), 0, st, (const double *)d_pc, ldpc,
 		                   d_rf + r0, d_P + (size_t)r0 * ldP, ldP, N);
 	}
@@ -685,6 +688,16 @@ extern "C" int tspws_hip_partial_stacks(tspws_hip_plan *p, const float *d_x, siz
 	HIP_TRY(hipSetDevice(p->device));
 	const bool upload = build_group_chunks(p, mtr_local, first, mtr_global, Kmax);
 	return run_chunks(p, d_x, ld, p->N, p->chunks, p->row_first, Kmax, d_P, ldP, S_(stream), upload);
+}
+
+extern "C" int tspws_hip_partial_stacks_range(tspws_hip_plan *p, const float *d_x, size_t ld, size_t mtr_local, size_t first,
+                                              size_t mtr_global, unsigned Kmax, unsigned g_begin, unsigned g_end, double *d_P, size_t ldP,
+                                              void *stream)
+{
+	if (!p || !d_x || !d_P || !Kmax || !mtr_global || g_begin > g_end || g_end > Kmax) return fail(TSPWS_E_ARG, "partial_stacks_range: bad argument");
+	HIP_TRY(hipSetDevice(p->device));
+	const bool upload = build_group_chunks(p, mtr_local, first, mtr_global, Kmax);
+	return run_chunks(p, d_x, ld, p->N, p->chunks, p->row_first, Kmax, d_P, ldP, S_(stream), upload, g_begin, g_end);
 }
 
 // ------------------------------------------------------------------------------------------
