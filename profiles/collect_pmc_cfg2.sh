@@ -1,0 +1,15 @@
+#!/bin/bash
+# usage: bash profiles/collect_pmc_fwd.sh TAG [ENV=VAL...]  -- SQ/LDS counters for the forward kernels
+TAG=$1; shift
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/pmcc_$TAG
+mkdir -p $OUT
+for kv in "$@"; do export "$kv"; done
+cd /tmp && export TMPDIR=/tmp
+run() { n=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -o p -- python3 $R/tools/cfg2_run.py 1024 > $OUT/$n.log 2>&1; }
+run a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
+run b SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_SCA
+run c SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_VMEM SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES
+cd $R
+python3 profiles/summarize_pmc.py $OUT > gpurun_out/pmcc_$TAG.txt 2>&1
+grep -A 30 "^k_fwd" gpurun_out/pmcc_$TAG.txt

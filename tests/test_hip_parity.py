@@ -433,3 +433,32 @@ def test_plan_reuse_and_argument_errors(lib, torch):
     assert lib.tspws_hip_plan_create(C.byref(h), -1, 4, 4, N, 2.0, 1.0, abi.W0_DEFAULT, 0, 99) == 5    # no such device
     assert lib.tspws_hip_partial_stacks(pl.h, None, N, 4, 0, 4, 2, None, N, None) == -1
     assert b"partial_stacks" in lib.tspws_hip_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,N,ntr", [
+    (dict(), 4096, 3), (dict(), 16501, 5), (dict(type=-3), 8192, 2), (dict(w0=2 * np.pi), 32768, 9),
+    (dict(s0=3.7, J=5), 3001, 2), (dict(), 131072, 2), (dict(J=2), 64, 3), (dict(b0=4.0), 65536, 2),
+    (dict(b0=0.25), 32768, 2),  # filters longer than the matrix kernel accepts: the plan must fall back to the VALU kernels
+])
+def test_forward_matrix_pipe_kernel(lib, torch, kw, N, ntr, monkeypatch):
+    """Opt-in FP64-MFMA forward kernel (csrc/fwd_mfma.h, TSPWS_FWD_KERNEL=mfma): same coefficients as the oracle,
+    float and double inputs, whole two-stage call included."""
+    monkeypatch.setenv("TSPWS_FWD_KERNEL", "mfma")
+    p = abi.resolve(abi.default_params(**kw), N)
+    f = abi.OracleFrame.from_params(p, N)
+    pl = tspws.Plan(p, N)
+    X = abi.synth_traces(ntr, N, seed=33)
+    Y = dev_forward(torch, pl, X.astype(np.float64))
+    Y32 = dev_forward(torch, pl, X)
+    for t in range(ntr):
+        Yo = f.forward(X[t].astype(np.float64))
+        assert abi.relerr(Y[t], Yo) < TOL64
+        assert abi.relerr(Y32[t], Yo) < TOL64
+    pk = tspws.resolve(abi.default_params(Kmax=2, unbiased=1, **kw), N)
+    plk = tspws.Plan(pk, N)
+    Xd = torch.as_tensor(X, device="cuda")
+    ls, ts = plk.stack(Xd)
+    torch.cuda.synchronize()
+    b = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(Kmax=2, unbiased=1, **kw), X)
+    assert abi.relerr(ts.cpu().numpy(), b["tsPWS"]) < TOL32

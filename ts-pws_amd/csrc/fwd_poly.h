@@ -76,6 +76,7 @@ __device__ __forceinline__ double dpp_mov_f64(double x, const int ctrl_sel)
 	case 0: rl = __builtin_amdgcn_update_dpp(0u, lo, 0x128, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0u, hi, 0x128, 0xf, 0xf, true); break; // row_ror:8
 	case 1: rl = __builtin_amdgcn_update_dpp(0u, lo, 0x141, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0u, hi, 0x141, 0xf, 0xf, true); break; // row_half_mirror
 	case 2: rl = __builtin_amdgcn_update_dpp(0u, lo, 0x4E, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0u, hi, 0x4E, 0xf, 0xf, true); break;   // quad xor 2
+	case 4: rl = __builtin_amdgcn_update_dpp(0u, lo, 0x124, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0u, hi, 0x124, 0xf, 0xf, true); break; // row_ror:4
 	default: rl = __builtin_amdgcn_update_dpp(0u, lo, 0xB1, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0u, hi, 0xB1, 0xf, 0xf, true); break;  // quad xor 1
 	}
 	return __hiloint2double((int)rh, (int)rl);

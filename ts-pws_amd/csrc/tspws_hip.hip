@@ -70,6 +70,23 @@ struct ScaleDesc {
 	unsigned long long part_off; // offset of this scale's [nsplit][Ns] partial block
 };
 
+// one work group of the matrix-pipe forward kernel (fwd_mfma.h): up to two voice pairs of an octave sharing one x image
+struct FwdGroup {
+	unsigned D, Ns, Mc, logMc, MC, cps, nsplit, css; // decimation, outputs, phases per chunk, chunks, chunks per split / per staged sub-split
+	unsigned nob, upi, TQ, P, Pu, RT, NP;            // output blocks (4 TQ outputs), units per work item, tiles per unit, plane / unit pitch, rows staged, pairs
+	unsigned bl_doubles, s0, bper;                   // LDS doubles reserved for the B tiles of a sub-split, first scale, B doubles per chunk
+	long long cp;                                    // origin of the image rows
+	unsigned Kq[2], rofs[2], nv[2];                  // per pair: tap steps, row offset into the image, voices
+	unsigned long long bt_off[2];                    // per pair: B table offset (doubles)
+	unsigned long long po[4];                        // per voice: offset of its [nsplit][Ns] partial block (double2)
+};
+#define FM_MAXGROUPS 64
+
+#define FM_KQCAP_HOST 8
+#ifndef FM_TAMAX
+#define FM_TAMAX 8
+#endif
+#define FM_TAMAX_HOST FM_TAMAX
 struct OctDesc;
 
 #ifndef FL_PASSES
@@ -98,7 +115,11 @@ struct tspws_hip_plan {
 	unsigned acc_blocks = 0;   // blocks of k_accumulate_masked (256 coefficients each)
 	unsigned acc2_blocks = 0;  // blocks of k_accumulate_parts
 	unsigned lds_blocks = 0;   // workgroups per trace slice of k_fwd_lds / workgroups of k_fwd_tl
-	int fwd_kind = 1;          // 0: k_fwd_poly only, 1: k_fwd_lds (+poly), 2: k_fwd_tl (+poly)
+	int fwd_kind = 1;          // 0: k_fwd_poly only, 1: k_fwd_lds (+poly), 2: k_fwd_tl (+poly), 3: k_fwd_mfma
+	std::vector<FwdGroup> pairs; // fwd_kind 3: work groups, their B tables and work items
+	FwdGroup *d_pairs = nullptr;
+	double *d_bt = nullptr;
+	size_t mfma_lds = 0;
 	unsigned tl_rows = 0;      // tap rows (of 64 double2) k_fwd_tl keeps in LDS
 	unsigned inv_waves = 0, inv_noct = 0, inv_ngeneric = 0; // polyphase inverse: waves, octave items, scales left to the generic kernel
 	struct OctDesc *d_oc = nullptr;
@@ -252,12 +273,109 @@ static double cpsi_host(int type, double w0)
 }
 
 static int build_inverse_items(tspws_hip_plan *p); // defined next to the inverse kernels
+static int upload_mfma_tables(tspws_hip_plan *p);  // defined next to the forward kernels
 
 extern "C" int tspws_hip_device_count(void)
 {
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
 	return n;
+}
+
+// Work decomposition of k_fwd_mfma (fwd_mfma.h): the voices of an octave (same D) are paired, up to two pairs share a
+// work group (one x image), every group gets its tile geometry, its split of the phases and the partial-block layout of
+// its voices (which replaces the one of the VALU kernels).  false = a filter is too long / too many groups.
+static bool build_mfma_pairs(tspws_hip_plan *p)
+{
+	unsigned TARGET = 1024; // matrix instructions per wave (unit run) the decomposition aims at
+	if (const char *e = getenv("TSPWS_MFMA_TARGET")) TARGET = (unsigned)std::max(16, atoi(e));
+	unsigned TAMAX = FM_TAMAX_HOST;
+	if (const char *e = getenv("TSPWS_MFMA_TA")) TAMAX = (unsigned)std::max(1, std::min((int)FM_TAMAX_HOST, atoi(e)));
+	p->pairs.clear();
+	unsigned long long btoff = 0, poff = 0;
+	size_t lds = 0;
+	std::vector<unsigned> new_nsplit(p->S);           // committed to the scale table only when every group fits
+	std::vector<unsigned long long> new_poff(p->S);
+	for (unsigned s = 0; s < p->S;) {
+		// voices of this octave that share the decimation
+		unsigned e = s + 1;
+		while (e < p->S && e / p->V == s / p->V && p->sc[e].D == p->sc[s].D && p->sc[e].Ns == p->sc[s].Ns) e++;
+		const unsigned D = p->sc[s].D;
+		for (unsigned g0 = s; g0 < e; g0 += 4) {
+			const unsigned g1 = std::min(e, g0 + 4);
+			FwdGroup d;
+			memset(&d, 0, sizeof d);
+			d.s0 = g0; d.D = D; d.Ns = p->sc[g0].Ns;
+			d.NP = (g1 - g0 + 1) / 2;
+			long long cg = 0;
+			for (unsigned v = g0; v < g1; v++) cg = std::max<long long>(cg, p->sc[v].c);
+			d.cp = cg;
+			unsigned rows_needed = 0; // max over the pairs of 4 Kq + row offset
+			for (unsigned pi = 0; pi < d.NP; pi++) {
+				const unsigned v0 = g0 + 2 * pi, v1 = std::min(v0 + 1, g1 - 1);
+				d.nv[pi] = v1 > v0 ? 2 : 1;
+				const long long cmax = std::max(p->sc[v0].c, p->sc[v1].c);
+				const unsigned r = (unsigned)((cg - cmax) / (long long)D); // whole rows between the group origin and the pair origin
+				const long long cpp = cg - (long long)r * D;
+				d.rofs[pi] = r;
+				unsigned Lp = 0;
+				for (unsigned v = v0; v <= v1; v++) Lp = std::max(Lp, p->sc[v].L + (unsigned)(cpp - p->sc[v].c));
+				const unsigned Qp = (Lp + D - 1) / D;
+				d.Kq[pi] = (Qp + 3) / 4;
+				if (d.Kq[pi] > FM_KQCAP_HOST) { if (getenv("TSPWS_DEBUG")) fprintf(stderr, "mfma: Kq %u at scale %u\n", d.Kq[pi], v0); return false; }
+				rows_needed = std::max(rows_needed, 4 * d.Kq[pi] + r);
+			}
+			unsigned mc = 1, lg = 0;
+			while (mc < D && mc < 4) { mc <<= 1; lg++; }
+			d.Mc = mc; d.logMc = lg;
+			d.MC = (D + mc - 1) / mc;
+			const unsigned kqsum = d.Kq[0] + d.Kq[1];
+			unsigned tq = 1;
+			while (tq < TAMAX && 4 * tq < d.Ns) tq <<= 1;
+			d.TQ = tq;
+			d.nob = (d.Ns + 4 * tq - 1) / (4 * tq);
+			d.RT = 4 * tq + rows_needed - 1;
+			const unsigned rpi = 64 / mc;
+			unsigned P = d.RT + rpi;            // slack: staging rows past RT; nothing is read past RT
+			while (P % 32 != 16) P++;
+			d.P = P;
+			unsigned Pu = mc * P;
+			while (Pu % 32 != 8) Pu++;          // the four units of an operand read hit disjoint banks
+			d.Pu = Pu;
+			const unsigned per_chunk = mc * tq * kqsum;            // matrix instructions per chunk and quad of units
+			const unsigned bper = mc * kqsum * 16;                 // B doubles per chunk
+			d.cps = std::max(1u, std::min(d.MC, TARGET / std::max(1u, per_chunk)));
+			d.nsplit = (d.MC + d.cps - 1) / d.cps;
+			if (d.nsplit > 64) { d.cps = (d.MC + 63) / 64; d.nsplit = (d.MC + d.cps - 1) / d.cps; } // the accumulate kernel walks the splits
+			d.css = std::max(1u, std::min(d.cps, (8u * 256u) / bper)); // <= 16 KB of tiles per staged sub-split
+			if (bper > 8u * 256u) { if (getenv("TSPWS_DEBUG")) fprintf(stderr, "mfma: bper %u\n", bper); return false; }
+			d.bl_doubles = (d.css * bper + 63) & ~63u;
+			const unsigned nss = (d.cps + d.css - 1) / d.css;
+			unsigned nuq = nss > 1 ? 1u : std::max(1u, TARGET / std::max(1u, per_chunk * d.cps)); // quads of units per wave
+			nuq = std::min(nuq, 16u);                                                            // one descriptor lane per unit
+			d.upi = 16 * nuq;
+			d.bper = bper;
+			d.bt_off[0] = btoff;                                     // [chunk][pair][quad][kappa][64]
+			d.bt_off[1] = btoff + (unsigned long long)mc * d.Kq[0] * 16;
+			btoff += (unsigned long long)d.MC * bper;
+			lds = std::max(lds, ((size_t)d.bl_doubles + 16 * (size_t)d.Pu + 64) * sizeof(double));
+			for (unsigned v = g0; v < g1; v++) { // partial blocks [nsplit][Ns] of the voices
+				new_nsplit[v] = d.nsplit; new_poff[v] = poff; d.po[v - g0] = poff;
+				poff += (unsigned long long)d.nsplit * d.Ns;
+			}
+			p->pairs.push_back(d);
+		}
+		s = e;
+	}
+	if (p->pairs.size() > FM_MAXGROUPS) { if (getenv("TSPWS_DEBUG")) fprintf(stderr, "mfma: %zu groups\n", p->pairs.size()); return false; }
+	if (getenv("TSPWS_DEBUG"))
+		for (const FwdGroup &d : p->pairs)
+			fprintf(stderr, "mfma group s0=%u D=%u Ns=%u NP=%u Kq=%u,%u rofs=%u,%u Mc=%u MC=%u cps=%u nsplit=%u css=%u TQ=%u nob=%u upi=%u RT=%u P=%u bper=%u\n", d.s0, d.D, d.Ns, d.NP, d.Kq[0], d.Kq[1], d.rofs[0], d.rofs[1], d.Mc, d.MC, d.cps, d.nsplit, d.css, d.TQ, d.nob, d.upi, d.RT, d.P, d.bper);
+	for (unsigned v = 0; v < p->S; v++) { p->sc[v].nsplit = new_nsplit[v]; p->sc[v].part_off = new_poff[v]; }
+	p->npart = poff;
+	p->mfma_lds = lds;
+	p->fwd_waves = 0; p->lds_blocks = 0;
+	return true;
 }
 
 extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J, unsigned V, unsigned N, double s0,
@@ -307,7 +425,7 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 		if (const char *e = getenv("TSPWS_FWD_STEPS")) FWD_STEPS = (unsigned)std::max(8, atoi(e));
 		const unsigned R = 8, FL_SLOTS_HOST = FL_WAVES * FL_PASSES_HOST;
 		int kind = 1;
-		if (const char *e = getenv("TSPWS_FWD_KERNEL")) kind = !strcmp(e, "poly") ? 0 : !strcmp(e, "tl") ? 2 : 1;
+		if (const char *e = getenv("TSPWS_FWD_KERNEL")) kind = !strcmp(e, "poly") ? 0 : !strcmp(e, "tl") ? 2 : !strcmp(e, "mfma") ? 3 : 1;
 		if (getenv("TSPWS_FWD_NOLDS") && *getenv("TSPWS_FWD_NOLDS") == '1') kind = 0;
 		p->fwd_kind = kind;
 		unsigned woff = 0, boff = 0;
@@ -341,6 +459,7 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 			d.pad1 = 0;
 		}
 		p->fwd_waves = woff; p->lds_blocks = boff; p->npart = poff;
+		if (kind == 3 && !build_mfma_pairs(p)) { p->fwd_kind = 1; p->pairs.clear(); } // a filter too long for the matrix kernel: VALU kernels
 	}
 	for (unsigned s = 0; s < S; s++) {
 		p->sc[s].inv_fast = (N % p->sc[s].D == 0) ? 1u : 0u;
@@ -365,6 +484,9 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 		tspws_hip_plan_destroy(p);
 		return fail(e == hipErrorNoBinaryForGpu ? TSPWS_E_NODEV : TSPWS_E_HIP, "plan_create: tap kernel", e);
 	}
+	if (p->fwd_kind == 3) {
+		if (int rc = upload_mfma_tables(p)) { tspws_hip_plan_destroy(p); return rc; }
+	}
 	*out = p;
 	return 0;
 }
@@ -379,6 +501,8 @@ extern "C" void tspws_hip_plan_destroy(tspws_hip_plan *p)
 	if (p->ev_done) (void)hipEventDestroy(p->ev_done);
 	if (p->aux) (void)hipStreamDestroy(p->aux);
 	if (p->d_oc) (void)hipFree(p->d_oc);
+	if (p->d_pairs) (void)hipFree(p->d_pairs);
+	if (p->d_bt) (void)hipFree(p->d_bt);
 	if (p->d_sc) (void)hipFree(p->d_sc);
 	if (p->d_w) (void)hipFree(p->d_w);
 	if (p->d_wd) (void)hipFree(p->d_wd);
@@ -776,11 +900,61 @@ static int forward_generic(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t
 #include "fwd_poly.h"
 #include "fwd_lds.h"
 #include "fwd_tl.h"
+#include "fwd_mfma.h"
+static_assert(FM_KQCAP == FM_KQCAP_HOST, "tap-step cap");
 
-// Forward transform of ntr traces into the split-partial layout part[ntr][npart].
+static int upload_mfma_tables(tspws_hip_plan *p)
+{
+	const size_t np = p->pairs.size();
+	unsigned long long nbt = 0;
+	for (const FwdGroup &d : p->pairs) nbt = std::max(nbt, d.bt_off[0] + (unsigned long long)d.MC * d.bper);
+	HIP_TRY(hipMalloc(&p->d_pairs, np * sizeof(FwdGroup)));
+	HIP_TRY(hipMalloc(&p->d_bt, std::max<unsigned long long>(nbt, 1) * sizeof(double)));
+	HIP_TRY(hipMemcpy(p->d_pairs, p->pairs.data(), np * sizeof(FwdGroup), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(p->d_sc, p->sc.data(), p->S * sizeof(ScaleDesc), hipMemcpyHostToDevice)); // nsplit / part_off changed
+	for (const FwdGroup &d : p->pairs) {
+		unsigned v = d.s0;
+		for (unsigned pi = 0; pi < d.NP; pi++) {
+			const ScaleDesc &a = p->sc[v], &b = p->sc[v + (d.nv[pi] > 1 ? 1 : 0)];
+			const unsigned long long n = (unsigned long long)d.MC * d.Mc * d.Kq[pi] * 16;
+			const long long cpp = d.cp - (long long)d.rofs[pi] * d.D;
+			hipLaunchKernelGGL(k_build_bt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, p->d_bt + d.bt_off[0], (const double2 *)p->d_w, n, d.D,
+			                   d.Kq[pi], cpp, d.nv[pi], a.tap_off, a.L, a.c, b.tap_off, b.L, b.c, d.Mc, d.bper, pi ? d.Mc * d.Kq[0] * 16 : 0u);
+			v += d.nv[pi];
+		}
+	}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipDeviceSynchronize());
+	return 0;
+}
+
 template <typename TIn>
 static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double2 *d_part, hipStream_t st)
 {
+	if (p->fwd_kind == 3) {
+		size_t per_launch = 1u << 20; // keeps the unit counters in 32 bits
+		for (const FwdGroup &d : p->pairs) per_launch = std::min<size_t>(per_launch, std::max<size_t>(1, 0x7fffffffu / std::max(1u, d.nob)));
+		for (size_t t0 = 0; t0 < ntr; t0 += per_launch) {
+			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, per_launch);
+			FwdOffsets offs;
+			unsigned long long items = 0;
+			const unsigned ng = (unsigned)p->pairs.size();
+			for (unsigned g = 0; g < ng; g++) {
+				const FwdGroup &d = p->pairs[g];
+				offs.off[g] = (unsigned)items;
+				static int only = -2; // debug knob: time a single group (results are then incomplete)
+				if (only == -2) { const char *e = getenv("TSPWS_MFMA_ONLY_GROUP"); only = e ? atoi(e) : -1; }
+				if (only >= 0 && (unsigned)only != g) continue;
+				items += (unsigned long long)d.nsplit * (((unsigned long long)nt * d.nob + d.upi - 1) / d.upi);
+			}
+			offs.off[ng] = (unsigned)items;
+			if (items >= (1ull << 31)) return fail(TSPWS_E_ARG, "forward: too many work items in one launch");
+			hipLaunchKernelGGL((k_fwd_mfma<TIn>), dim3((unsigned)items), dim3(256), p->mfma_lds, st, d_x + t0 * ld, ld, nt, p->N, p->d_pairs, ng, offs,
+			                   p->d_bt, d_part + t0 * p->npart, p->npart);
+		}
+		HIP_TRY(hipGetLastError());
+		return 0;
+	}
 	if (p->lds_blocks && p->fwd_kind == 2) {
 		const size_t lds = (size_t)p->tl_rows * 1024 + 4 * TL_SCR * sizeof(double);
 		for (size_t t0 = 0; t0 < ntr; t0 += 65534) { // (trace pairs inside the kernel: keep launches even)
