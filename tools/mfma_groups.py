@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(%r, ".."))
 sys.path.insert(0, os.path.join(%r, "..", "tests"))
 import numpy as np, torch, abi, ctypes as C
 tspws = importlib.import_module("ts-pws_amd"); lib = tspws.load()
-N, K = 131072, 10
+N, K = 131072, int(os.environ.get("MG_TRACES", "10"))
 p = tspws.resolve(abi.default_params(Kmax=K), N)
 pl = tspws.Plan(p, N)
 x = torch.randn(K, N, dtype=torch.float64, device="cuda")
@@ -21,7 +21,7 @@ torch.cuda.synchronize(); print("%%.1f" %% ((time.perf_counter() - t0) / 10 * 1e
 ''' % (here, here)
 groups = [int(a) for a in sys.argv[1:]] or ([-1] + list(range(14)))
 for g in groups:
-    env = dict(os.environ, TSPWS_FWD_KERNEL="mfma")
+    env = dict(os.environ); env.setdefault("TSPWS_FWD_KERNEL", "mfma")
     if g >= 0: env["TSPWS_MFMA_ONLY_GROUP"] = str(g)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
-    print("group", g, "us per forward(10 traces) incl. gather:", out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:])
+    print("group", g, "us per forward incl. gather:", out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:])

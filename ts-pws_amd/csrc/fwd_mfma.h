@@ -33,8 +33,14 @@
 // (k_fwd_lds + k_fwd_poly); 1024 x 32768 single-stage 8.0 ms against 6.1 ms.  PMC (profiles/r01_mfma_forward_pmc.txt):
 // 9.2-10.5 M matrix instructions = 68 us of pipe time, i.e. the pipe is 25-30 % busy; per matrix instruction a wave still
 // issues 2.3 VALU + 1.8 SALU + 0.4 LDS instructions and spends a third of its life in s_waitcnt, and the 10 KB image per
-// wave caps the occupancy at 2 waves per SIMD.  Next steps: software-pipeline the operand reads of consecutive
-// (phase, pair) products, trim the address arithmetic of fetch / staging, float images for float input.
+// wave caps the occupancy at 2 waves per SIMD.  Steady-state ablation (tools/mfma_sweep.sh, 256 traces, one octave: 448 us
+// against 127 us of pipe time): without the (phase, pair) products 175 us, i.e. the products cost 273 us = 2.1x their
+// pipe time (operand reads are not overlapped with the previous product's instructions); without the global x loads
+// -93 us, without the staging writes -98 us (both include the wait for the prefetched rows: with Mc = 4 a row segment
+// is 32 bytes -- 16 for float input -- so every 128-byte line is fetched four to eight times, from HBM once the traces
+// outgrow the L2), without the stores -49 us.  Next steps: software-pipeline the operand reads of consecutive products,
+// stage full lines (a workgroup-shared 16-phase row tile), trim the address arithmetic, float images for float input.
+// Ablation macros: FM_ABL_NOX, FM_ABL_NOSTAGE, FM_ABL_NOLDSREAD, FM_ABL_NOMULT, FM_ABL_NOSTORE (make EXTRA_HIPFLAGS=-D...).
 #pragma once
 
 #ifndef FM_TAMAX
@@ -81,10 +87,17 @@ template <int TQ, int KQ, bool FIRST>
 __device__ __forceinline__ void fm_pair_mult(double (&C)[TQ], const double *__restrict__ ap, const double *__restrict__ bp)
 {
 	double A[TQ + KQ - 1], B[KQ];
+#ifdef FM_ABL_NOLDSREAD
+#pragma unroll
+	for (int kap = 0; kap < KQ; kap++) B[kap] = (double)(size_t)bp + kap;
+#pragma unroll
+	for (int id = 0; id < TQ + KQ - 1; id++) A[id] = (double)(size_t)ap + id;
+#else
 #pragma unroll
 	for (int kap = 0; kap < KQ; kap++) B[kap] = bp[kap * 16];
 #pragma unroll
 	for (int id = 0; id < TQ + KQ - 1; id++) A[id] = ap[4 * id];
+#endif
 #pragma unroll
 	for (int kap = 0; kap < KQ; kap++)
 #pragma unroll
@@ -215,6 +228,7 @@ __device__ __forceinline__ void fwd_mfma_wg_body(const TIn *__restrict__ x, cons
 				const bool first_chunk = c0 + ch == 0, last_chunk = c0 + ch + 1 == nch;
 				const bool rag = (ch0 + c0 + ch) * Mc + Mc > D; // phases past D are staged as zeros (they must not inject Inf * 0)
 				__builtin_amdgcn_wave_barrier();
+#ifndef FM_ABL_NOSTAGE
 				if (rag) {
 					const bool ok = (ch0 + c0 + ch) * Mc + ml < D;
 #pragma unroll
@@ -227,6 +241,9 @@ __device__ __forceinline__ void fwd_mfma_wg_body(const TIn *__restrict__ x, cons
 #pragma unroll
 						for (int it = 0; it < NIMAX; it++) if ((unsigned)it < NI) stp[(unsigned)b * Pu + (unsigned)it * RPI] = xv[b][it]; // rows past RT land in the plane's slack
 				}
+#else
+				if (xv[0][0] == 1.234e300) stp[0] = xv[1][0] + xv[2][0] + xv[3][0];
+#endif
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
 				// next step in the order (ss, quad, chunk)
@@ -273,7 +290,11 @@ __device__ __forceinline__ void fwd_mfma_wg_body(const TIn *__restrict__ x, cons
 #pragma unroll
 							for (int a = 0; a < TQ; a++) {
 								const double val = p ? C1[a] : C0[a];
+#ifdef FM_ABL_NOSTORE
+								if (act && val == 1.234e300) dst[8 * a] = val;
+#else
 								if (act && nb + 4 * (unsigned)a < Ns) dst[8 * a] = (j & 1) ? -val : val; // conj
+#endif
 							}
 						}
 					}

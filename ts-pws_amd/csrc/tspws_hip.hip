@@ -1012,6 +1012,9 @@ static int forward_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld
 	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
 		const size_t nb = std::min(batch, ntr - t0);
 		if ((rc = forward_parts<TIn>(p, d_x + t0 * ld, nb, ld, (double2 *)v, st))) return rc;
+		static int nogather = -1; // timing knob for tools/mfma_groups.py: forward kernels only (Y is then not written)
+		if (nogather < 0) nogather = getenv("TSPWS_DEBUG_NOGATHER") ? 1 : 0;
+		if (!nogather)
 		hipLaunchKernelGGL(k_gather_parts, dim3((unsigned)((p->ncoef + 255) / 256), (unsigned)nb), dim3(256), 0, st, (const double2 *)v,
 		                   p->npart, p->d_sc, p->S, (double2 *)d_Y + t0 * p->ncoef, p->ncoef);
 	}
