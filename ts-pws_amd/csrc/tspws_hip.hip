@@ -114,13 +114,12 @@ struct tspws_hip_plan {
 	unsigned fwd_waves = 0;    // waves per trace batch of k_fwd_poly
 	unsigned acc_blocks = 0;   // blocks of k_accumulate_masked (256 coefficients each)
 	unsigned acc2_blocks = 0;  // blocks of k_accumulate_parts
-	unsigned lds_blocks = 0;   // workgroups per trace slice of k_fwd_lds / workgroups of k_fwd_tl
-	int fwd_kind = 1;          // 0: k_fwd_poly only, 1: k_fwd_lds (+poly), 2: k_fwd_tl (+poly), 3: k_fwd_mfma
+	unsigned lds_blocks = 0;   // workgroups per trace slice of k_fwd_lds
+	int fwd_kind = 1;          // 0: k_fwd_poly only, 1: k_fwd_lds (+poly), 3: k_fwd_mfma (opt-in)
 	std::vector<FwdGroup> pairs; // fwd_kind 3: work groups, their B tables and work items
 	FwdGroup *d_pairs = nullptr;
 	double *d_bt = nullptr;
 	size_t mfma_lds = 0;
-	unsigned tl_rows = 0;      // tap rows (of 64 double2) k_fwd_tl keeps in LDS
 	unsigned inv_waves = 0, inv_noct = 0, inv_ngeneric = 0; // polyphase inverse: waves, octave items, scales left to the generic kernel
 	struct OctDesc *d_oc = nullptr;
 	std::vector<ScaleDesc> sc;
@@ -425,7 +424,7 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 		if (const char *e = getenv("TSPWS_FWD_STEPS")) FWD_STEPS = (unsigned)std::max(8, atoi(e));
 		const unsigned R = 8, FL_SLOTS_HOST = FL_WAVES * FL_PASSES_HOST;
 		int kind = 1;
-		if (const char *e = getenv("TSPWS_FWD_KERNEL")) kind = !strcmp(e, "poly") ? 0 : !strcmp(e, "tl") ? 2 : !strcmp(e, "mfma") ? 3 : 1;
+		if (const char *e = getenv("TSPWS_FWD_KERNEL")) kind = !strcmp(e, "poly") ? 0 : !strcmp(e, "mfma") ? 3 : 1;
 		if (getenv("TSPWS_FWD_NOLDS") && *getenv("TSPWS_FWD_NOLDS") == '1') kind = 0;
 		p->fwd_kind = kind;
 		unsigned woff = 0, boff = 0;
@@ -441,19 +440,13 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 			const bool pow2 = (d.D & (d.D - 1)) == 0;
 			d.ngw = (NG + GW - 1) / GW;
 			d.use_lds = (kind != 0 && NG >= 8 && (d.D >= 64 || pow2)) ? 1u : 0u;
-			if (kind == 2) { // taps must fit the resident LDS tile (24 rows of 64)
-				const unsigned rows = d.D < 64 ? (d.Q * d.D + 63) / 64 : d.Q;
-				if (rows > 24) d.use_lds = 0;
-				else if (d.use_lds) p->tl_rows = std::max(p->tl_rows, rows);
-			}
 			unsigned cps;
 			if (d.use_lds) cps = 1; // one 64-phase chunk per workgroup: its taps stay resident in LDS
 			else cps = std::max(1u, (FWD_STEPS + d.Q / 2) / std::max(1u, d.Q));
 			d.cps = std::min(cps, d.MC);
 			d.nsplit = (d.MC + d.cps - 1) / d.cps;
 			d.wave_off = woff; d.lds_off = boff; d.part_off = poff;
-			if (kind == 2) d.lds_bps = std::min(64u, std::max(1u, (d.ngw + 15) / 16)); // workgroups per (scale, chunk)
-			else d.lds_bps = (NG + FL_SLOTS_HOST * GW - 1) / (FL_SLOTS_HOST * GW);
+			d.lds_bps = (NG + FL_SLOTS_HOST * GW - 1) / (FL_SLOTS_HOST * GW);
 			if (d.use_lds) boff += d.lds_bps * d.nsplit; else woff += d.ngw * d.nsplit;
 			poff += (unsigned long long)d.nsplit * d.Ns;
 			d.pad1 = 0;
@@ -899,7 +892,6 @@ static int forward_generic(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t
 
 #include "fwd_poly.h"
 #include "fwd_lds.h"
-#include "fwd_tl.h"
 #include "fwd_mfma.h"
 static_assert(FM_KQCAP == FM_KQCAP_HOST, "tap-step cap");
 
@@ -955,14 +947,7 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 		HIP_TRY(hipGetLastError());
 		return 0;
 	}
-	if (p->lds_blocks && p->fwd_kind == 2) {
-		const size_t lds = (size_t)p->tl_rows * 1024 + 4 * TL_SCR * sizeof(double);
-		for (size_t t0 = 0; t0 < ntr; t0 += 65534) { // (trace pairs inside the kernel: keep launches even)
-			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, 65534);
-			hipLaunchKernelGGL((k_fwd_tl<TIn>), dim3(p->lds_blocks), dim3(256), lds, st, d_x + t0 * ld, ld, nt, p->N, p->d_sc, p->S, p->d_w,
-			                   d_part + t0 * p->npart, p->npart, p->tl_rows);
-		}
-	} else if (p->lds_blocks) {
+	if (p->lds_blocks) {
 		// traces per workgroup: enough slices to fill the GPU (>= ~2048 workgroups), at most 32 traces per slice
 		unsigned tps = (unsigned)std::min<size_t>(ntr, 32);
 		while (tps > 1 && (size_t)p->lds_blocks * ((ntr + tps - 1) / tps) < 2048) tps = (tps + 1) / 2;
