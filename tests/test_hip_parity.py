@@ -338,21 +338,64 @@ def test_synth_generator_matches_host_recipe(lib, torch):
 
 
 def test_full_size_properties(lib, torch):
-    """BASELINE sizes (north-star shape, fewer traces than 10k to stay in seconds): properties that
-    do not need the oracle -- group sums add up to the total, and a constant ensemble stacks to itself."""
-    mtr, N, K = 512, 131072, 10
+    """BASELINE configs[2] at its full size (10 000 x 131 072, two-stage K = 10, unbiased): properties that do not need
+    the oracle -- the group sums add up to the total, the call is linear in the data (ls and tsPWS scale with a
+    positive factor), shards of the traces reduce to the unsharded buffer, and a coherent ensemble stacks to itself."""
+    mtr, N, K = 10000, 131072, 10
     p = tspws.resolve(abi.default_params(Kmax=K, unbiased=1), N)
     pl = tspws.Plan(p, N)
     Xd = tspws.synth(mtr, N, seed=1)
     pl.stack_local(Xd, 0, mtr)
-    P = pl.reduce_buffer(mtr).view(K, N)
-    tot = Xd.double().sum(dim=0)
-    assert float((P.sum(dim=0) - tot).abs().max()) <= 1e-9
+    P = pl.reduce_buffer(mtr).view(K, N).clone()
+    tot = torch.zeros(N, dtype=torch.float64, device="cuda")
+    for t0 in range(0, mtr, 500):
+        tot += Xd[t0:t0 + 500].double().sum(dim=0)
+    assert float((P.sum(dim=0) - tot).abs().max()) <= 1e-8
+    # group membership g = floor(i K / mtr): group 3 alone
+    g3 = Xd[3000:4000].double().sum(dim=0)
+    assert float((P[3] - g3).abs().max()) <= 1e-9
+    # four shards with global indices, reduce buffers added
+    acc = torch.zeros_like(P)
+    for r in range(4):
+        f, c = tspws.shard_range(mtr, r, 4)
+        pl.stack_local(Xd[f:f + c], f, mtr)
+        acc += pl.reduce_buffer(mtr).view(K, N)
+    assert float((acc - P).abs().max()) <= 1e-9
+    ls, ts = pl.stack(Xd)
+    ls, ts = ls.clone(), ts.clone()
+    # linearity: a power-of-two factor scales every intermediate exactly
+    Xd *= 4.0
+    ls4, ts4 = pl.stack(Xd)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal((ls4 / 4).cpu().numpy(), ls.cpu().numpy())
+    np.testing.assert_array_equal((ts4 / 4).cpu().numpy(), ts.cpu().numpy())
     # identical traces: phase stack is fully coherent -> tsPWS == ls == ICWT(CWT(x)) (unbiased weight = 1)
     Xc = Xd[:1].repeat(64, 1).contiguous()
-    ls, ts = pl.stack(Xc)
+    lsc, tsc = pl.stack(Xc)
     torch.cuda.synchronize()
-    assert abi.relerr(ts.cpu().numpy(), ls.cpu().numpy()) < 1e-6
+    assert abi.relerr(tsc.cpu().numpy(), lsc.cpu().numpy()) < 1e-6
+
+
+def test_full_size_single_stage_properties(lib, torch):
+    """BASELINE configs[1] at its full size (1024 x 32768, w0 = 2 pi, single stage): a two-stage call with one trace per
+    group is the same computation, and the result is invariant under a permutation of the traces (up to summation order)."""
+    mtr, N = 1024, 32768
+    p1 = tspws.resolve(abi.default_params(w0=2 * np.pi), N)
+    pl1 = tspws.Plan(p1, N)
+    Xd = tspws.synth(mtr, N, seed=2)
+    ls1, ts1 = pl1.stack(Xd)
+    ls1, ts1 = ls1.clone(), ts1.clone()
+    pk = tspws.resolve(abi.default_params(w0=2 * np.pi, Kmax=mtr), N)
+    plk = tspws.Plan(pk, N)
+    lsk, tsk = plk.stack(Xd)
+    torch.cuda.synchronize()
+    assert abi.relerr(tsk.cpu().numpy(), ts1.cpu().numpy()) < 1e-6
+    assert abi.relerr(lsk.cpu().numpy(), ls1.cpu().numpy()) < 1e-6
+    perm = torch.randperm(mtr, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    lsp, tsp = pl1.stack(Xd[perm].contiguous())
+    torch.cuda.synchronize()
+    assert abi.relerr(tsp.cpu().numpy(), ts1.cpu().numpy()) < 1e-6
+    assert abi.relerr(lsp.cpu().numpy(), ls1.cpu().numpy()) < 1e-6
 
 
 # --------------------------------------------------------- convergence / random subsampling
