@@ -24,4 +24,7 @@ for g in groups:
     env = dict(os.environ); env.setdefault("TSPWS_FWD_KERNEL", "mfma")
     if g >= 0: env["TSPWS_MFMA_ONLY_GROUP"] = str(g)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    if os.environ.get("MG_VERBOSE"):
+        print("\n".join(l for l in out.stdout.splitlines() if l.startswith("blk"))[:6000])
+        print("\n".join(l for l in out.stderr.splitlines() if l.startswith("mfma"))[:6000])
     print("group", g, "us per forward incl. gather:", out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:])

@@ -43,10 +43,7 @@
 // Ablation macros: FM_ABL_NOX, FM_ABL_NOSTAGE, FM_ABL_NOLDSREAD, FM_ABL_NOMULT, FM_ABL_NOSTORE (make EXTRA_HIPFLAGS=-D...).
 #pragma once
 
-#ifndef FM_TAMAX
-#define FM_TAMAX 8 /* tiles (of 4 outputs) per unit */
-#endif
-#define FM_KQCAP 8 /* tap steps (of 4 rows) per phase this kernel accepts; longer filters stay on the VALU kernels */
+#include "fwd_mfma_types.h"
 
 // B tiles of one pair inside its group's table, zero outside the filters / past phase D:
 //   bt[chunk * chunk_stride + pair_off + ((ml Kq + kappa) 16 + 4 k + j)],   m = chunk Mc + ml
@@ -303,8 +300,6 @@ __device__ __forceinline__ void fwd_mfma_wg_body(const TIn *__restrict__ x, cons
 		}
 	}
 }
-
-struct FwdOffsets { unsigned off[FM_MAXGROUPS + 1]; }; // first work item of every group for this launch's trace count
 
 template <typename TIn>
 __global__ void __launch_bounds__(256) k_fwd_mfma(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned N,

@@ -70,22 +70,8 @@ struct ScaleDesc {
 	unsigned long long part_off; // offset of this scale's [nsplit][Ns] partial block
 };
 
-// one work group of the matrix-pipe forward kernel (fwd_mfma.h): up to two voice pairs of an octave sharing one x image
-struct FwdGroup {
-	unsigned D, Ns, Mc, logMc, MC, cps, nsplit, css; // decimation, outputs, phases per chunk, chunks, chunks per split / per staged sub-split
-	unsigned nob, upi, TQ, P, Pu, RT, NP;            // output blocks (4 TQ outputs), units per work item, tiles per unit, plane / unit pitch, rows staged, pairs
-	unsigned bl_doubles, s0, bper;                   // LDS doubles reserved for the B tiles of a sub-split, first scale, B doubles per chunk
-	long long cp;                                    // origin of the image rows
-	unsigned Kq[2], rofs[2], nv[2];                  // per pair: tap steps, row offset into the image, voices
-	unsigned long long bt_off[2];                    // per pair: B table offset (doubles)
-	unsigned long long po[4];                        // per voice: offset of its [nsplit][Ns] partial block (double2)
-};
-#define FM_MAXGROUPS 64
-
-#define FM_KQCAP_HOST 8
-#ifndef FM_TAMAX
-#define FM_TAMAX 8
-#endif
+#include "fwd_mfma_types.h"
+#define FM_KQCAP_HOST FM_KQCAP
 #define FM_TAMAX_HOST FM_TAMAX
 struct OctDesc;
 
@@ -345,7 +331,10 @@ static bool build_mfma_pairs(tspws_hip_plan *p)
 			const unsigned bper = mc * kqsum * 16;                 // B doubles per chunk
 			d.cps = std::max(1u, std::min(d.MC, TARGET / std::max(1u, per_chunk)));
 			d.nsplit = (d.MC + d.cps - 1) / d.cps;
-			if (d.nsplit > 64) { d.cps = (d.MC + 63) / 64; d.nsplit = (d.MC + d.cps - 1) / d.cps; } // the accumulate kernel walks the splits
+			// the accumulate kernel walks the splits of every coefficient: at most 64 of them, more (up to 512) only for the
+			// coarse scales whose few outputs would otherwise leave most of the GPU without work
+			const unsigned smax = std::max(64u, std::min(512u, 4096u / std::max(1u, d.Ns)));
+			if (d.nsplit > smax) { d.cps = (d.MC + smax - 1) / smax; d.nsplit = (d.MC + d.cps - 1) / d.cps; }
 			d.css = std::max(1u, std::min(d.cps, (8u * 256u) / bper)); // <= 16 KB of tiles per staged sub-split
 			if (bper > 8u * 256u) { if (getenv("TSPWS_DEBUG")) fprintf(stderr, "mfma: bper %u\n", bper); return false; }
 			d.bl_doubles = (d.css * bper + 63) & ~63u;
@@ -928,21 +917,40 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 		for (const FwdGroup &d : p->pairs) per_launch = std::min<size_t>(per_launch, std::max<size_t>(1, 0x7fffffffu / std::max(1u, d.nob)));
 		for (size_t t0 = 0; t0 < ntr; t0 += per_launch) {
 			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, per_launch);
-			FwdOffsets offs;
-			unsigned long long items = 0;
 			const unsigned ng = (unsigned)p->pairs.size();
-			for (unsigned g = 0; g < ng; g++) {
-				const FwdGroup &d = p->pairs[g];
-				offs.off[g] = (unsigned)items;
-				static int only = -2; // debug knob: time a single group (results are then incomplete)
-				if (only == -2) { const char *e = getenv("TSPWS_MFMA_ONLY_GROUP"); only = e ? atoi(e) : -1; }
-				if (only >= 0 && (unsigned)only != g) continue;
-				items += (unsigned long long)d.nsplit * (((unsigned long long)nt * d.nob + d.upi - 1) / d.upi);
+			static int only = -2, spec_on = -1; // debug knobs: time a single group (results are then incomplete); generic kernel only
+			if (only == -2) { const char *e = getenv("TSPWS_MFMA_ONLY_GROUP"); only = e ? atoi(e) : -1; }
+			if (spec_on < 0) { const char *e = getenv("TSPWS_MFMA_SPEC"); spec_on = (e && *e == '0') ? 0 : 1; }
+			auto items_of = [&](const FwdGroup &d) { return (unsigned long long)d.nsplit * (((unsigned long long)nt * d.nob + d.upi - 1) / d.upi); };
+			auto spec_ok = [&](const FwdGroup &d) {
+				return spec_on && d.TQ == 8 && d.Mc == 4 && d.D % 4 == 0 && fwd_mfma_spec_has(d.Kq[0], d.NP > 1 ? d.Kq[1] : 0);
+			};
+			std::vector<char> done(ng, 0);
+			for (unsigned g0 = 0; g0 <= ng; g0++) { // one launch per (Kq0, Kq1) of the specialised groups, then one for the rest
+				const bool rest = g0 == ng;
+				if (!rest && (done[g0] || !spec_ok(p->pairs[g0]))) continue;
+				const unsigned k0 = rest ? 0 : p->pairs[g0].Kq[0], k1 = rest ? 0 : (p->pairs[g0].NP > 1 ? p->pairs[g0].Kq[1] : 0);
+				FwdOffsets offs;
+				unsigned long long items = 0;
+				for (unsigned g = 0; g < ng; g++) {
+					const FwdGroup &d = p->pairs[g];
+					offs.off[g] = (unsigned)items;
+					if (only >= 0 && (unsigned)only != g) continue;
+					if (done[g]) continue;
+					if (!rest && !(spec_ok(d) && d.Kq[0] == k0 && (d.NP > 1 ? d.Kq[1] : 0) == k1)) continue;
+					items += items_of(d);
+					done[g] = 1;
+				}
+				offs.off[ng] = (unsigned)items;
+				if (items >= (1ull << 31)) return fail(TSPWS_E_ARG, "forward: too many work items in one launch");
+				if (!items) continue;
+				if (rest)
+					hipLaunchKernelGGL((k_fwd_mfma<TIn>), dim3((unsigned)items), dim3(256), p->mfma_lds, st, d_x + t0 * ld, ld, nt, p->N, p->d_pairs, ng, offs,
+					                   p->d_bt, d_part + t0 * p->npart, p->npart);
+				else
+					fwd_mfma_spec_launch(sizeof(TIn) == 4, k0, k1, (unsigned)items, p->mfma_lds, st, d_x + t0 * ld, ld, nt, p->N, p->d_pairs, ng, offs, p->d_bt,
+					                     d_part + t0 * p->npart, p->npart);
 			}
-			offs.off[ng] = (unsigned)items;
-			if (items >= (1ull << 31)) return fail(TSPWS_E_ARG, "forward: too many work items in one launch");
-			hipLaunchKernelGGL((k_fwd_mfma<TIn>), dim3((unsigned)items), dim3(256), p->mfma_lds, st, d_x + t0 * ld, ld, nt, p->N, p->d_pairs, ng, offs,
-			                   p->d_bt, d_part + t0 * p->npart, p->npart);
 		}
 		HIP_TRY(hipGetLastError());
 		return 0;
@@ -976,6 +984,14 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 	return 0;
 }
 
+// scratch for the split partials of one batch of transformed traces (bigger batches = fewer, fuller launches)
+static size_t part_budget_bytes()
+{
+	static size_t v = 0;
+	if (!v) { const char *e = getenv("TSPWS_PART_MB"); v = (size_t)(e ? std::max(16, atoi(e)) : 2048) << 20; }
+	return v;
+}
+
 static bool use_generic_forward()
 {
 	static int v = -1;
@@ -990,7 +1006,7 @@ static int forward_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld
 	if (!ntr) return 0;
 	HIP_TRY(hipSetDevice(p->device));
 	if (use_generic_forward()) return forward_generic<TIn>(p, d_x, ntr, ld, d_Y, st);
-	const size_t batch = std::min<size_t>(ntr, std::max<size_t>(2, (((size_t)256 << 20) / (p->npart * sizeof(double2))) & ~(size_t)1));
+	const size_t batch = std::min<size_t>(ntr, std::max<size_t>(2, ((part_budget_bytes()) / (p->npart * sizeof(double2))) & ~(size_t)1));
 	void *v;
 	int rc = scratch(p, SCR_PART, batch * p->npart * sizeof(double2), &v);
 	if (rc) return rc;
@@ -1065,7 +1081,7 @@ static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld,
 		return 0;
 	}
 	// trace batch sized to keep the partial-coefficient scratch around 256 MiB (even, for the 2-trace tiles)
-	const size_t batch = std::min<size_t>(ntr, std::max<size_t>(2, (((size_t)256 << 20) / (p->npart * sizeof(double2))) & ~(size_t)1));
+	const size_t batch = std::min<size_t>(ntr, std::max<size_t>(2, ((part_budget_bytes()) / (p->npart * sizeof(double2))) & ~(size_t)1));
 	void *v;
 	if ((rc = scratch(p, SCR_PART, batch * p->npart * sizeof(double2), &v))) return rc;
 	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
