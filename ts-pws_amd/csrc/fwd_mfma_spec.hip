@@ -5,15 +5,18 @@
 // the NEXT (phase, pair) product read from LDS while the current one multiplies, the products alone sustain 64-68
 // TFLOP/s (82-87 % of the 78.6 peak) at one to four waves per SIMD; read-then-multiply reaches 55-65.  The runtime
 // switch on the tap steps inside the loops of fwd_mfma.h costs most of that, hence one kernel per (KQ0, KQ1):
-// a plan uses one or two of them.  Only groups with TQ = 8 and Mc = 4 run here; the rest stay on the generic kernel.
+// a plan uses a handful of them.  Variants: (TQ, Mc) = (8,4) for every tap-step pair up to 8, (4,4), (2,4), (8,2) up to 5;
+// anything else (D = 1, ragged phase chunks, one tap step) stays on the generic kernel of fwd_mfma.h.
 //
 // Measured (round 1, MI355X): a wave of a (4,5) group lives 18 us for 864 matrix instructions (s_memtime breakdown with
 // -DFS_TIMING: products 56 %, x fetch 11 %, staging 8 %, stores 5 %, barriers 3 %, set-up 15 %), i.e. two waves per SIMD
 // keep the pipe ~70 % busy.  1024 x 32768 single-stage (float input, V = 5) in one batch: 3.05 ms for the nine octaves
-// that run here (61 % pipe utilisation, 70 % of the issued MACs useful: the fifth voice has no partner) against 3.85 ms
-// for ten octaves on k_fwd_lds; the generic kernel then spends 1.8 ms on the remaining D = 2 and coarse (TQ < 8)
-// groups, so the whole call is 5.9 ms vs 5.7 ms.  North-star (10 traces): 137 us here + 115 us generic vs 187 us on the
-// VALU kernels.  Still opt-in; next: TQ = 2, 4 and Mc = 2 variants of this file to retire the generic kernel.
+// with TQ = 8, Mc = 4 (61 % pipe utilisation, 70 % of the issued MACs useful: the fifth voice has no partner) against
+// 3.85 ms for ten octaves on k_fwd_lds; whole call 5.9-6.1 ms vs 5.7 ms on the VALU kernels.  North-star (10 traces,
+// TSPWS_MFMA_TARGET=640): four launches, 24 + 134 + 19 + 25 = 203 us vs 187 us on the VALU kernels, and the accumulate
+// kernel pays 64 instead of 26 us for the extra phase splits of the coarse scales.  Still opt-in.  Next: run the small
+// (TQ, Mc) launches beside the big one, reduce the splits of the coarse scales before the accumulate kernel, keep
+// workgroups resident across work items (the 10-trace problem is 6 rounds of 23 us workgroups: set-up and tails).
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdio.h>
@@ -41,44 +44,45 @@ __device__ __forceinline__ void fs_mult(double (&C)[TQ], const double (&A)[TQ + 
 		for (int a = 0; a < TQ; a++) C[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[a + k], B[k], (FIRST && k == 0) ? 0.0 : C[a], 0, 0, 0);
 }
 
-// the four phases of a chunk, both pairs, software pipelined (KQ1 == 0: one pair, its phases alternate two operand sets)
-template <int KQ0, int KQ1, bool FIRST>
-__device__ __forceinline__ void fs_chunk(double (&C0)[8], double (&C1)[8], const double *__restrict__ ap0, const double *__restrict__ ap1,
+// the MC phases of a chunk, both pairs, software pipelined (KQ1 == 0: one pair, its phases alternate two operand sets)
+template <int TQ, int MC, int KQ0, int KQ1, bool FIRST>
+__device__ __forceinline__ void fs_chunk(double (&C0)[TQ], double (&C1)[TQ], const double *__restrict__ ap0, const double *__restrict__ ap1,
                                          const double *__restrict__ bl0, const double *__restrict__ bl1, const unsigned P)
 {
-	constexpr int TQ = 8;
 	if constexpr (KQ1 > 0) {
 		double A0[TQ + KQ0 - 1], B0[KQ0], A1[TQ + KQ1 - 1], B1[KQ1];
 		fs_load<TQ, KQ0>(A0, B0, ap0, bl0);
 #pragma unroll
-		for (int ph = 0; ph < 4; ph++) {
+		for (int ph = 0; ph < MC; ph++) {
 			fs_load<TQ, KQ1>(A1, B1, ap1 + ph * P, bl1 + ph * KQ1 * 16);
 			if (ph == 0) fs_mult<TQ, KQ0, FIRST>(C0, A0, B0); else fs_mult<TQ, KQ0, false>(C0, A0, B0);
-			if (ph < 3) fs_load<TQ, KQ0>(A0, B0, ap0 + (ph + 1) * P, bl0 + (ph + 1) * KQ0 * 16);
+			if (ph < MC - 1) fs_load<TQ, KQ0>(A0, B0, ap0 + (ph + 1) * P, bl0 + (ph + 1) * KQ0 * 16);
 			if (ph == 0) fs_mult<TQ, KQ1, FIRST>(C1, A1, B1); else fs_mult<TQ, KQ1, false>(C1, A1, B1);
 		}
 	} else {
+		static_assert(MC % 2 == 0, "phase pairs");
 		double Aa[TQ + KQ0 - 1], Ba[KQ0], Ab[TQ + KQ0 - 1], Bb[KQ0];
 		fs_load<TQ, KQ0>(Aa, Ba, ap0, bl0);
-		fs_load<TQ, KQ0>(Ab, Bb, ap0 + P, bl0 + KQ0 * 16);
-		fs_mult<TQ, KQ0, FIRST>(C0, Aa, Ba);
-		fs_load<TQ, KQ0>(Aa, Ba, ap0 + 2 * P, bl0 + 2 * KQ0 * 16);
-		fs_mult<TQ, KQ0, false>(C0, Ab, Bb);
-		fs_load<TQ, KQ0>(Ab, Bb, ap0 + 3 * P, bl0 + 3 * KQ0 * 16);
-		fs_mult<TQ, KQ0, false>(C0, Aa, Ba);
-		fs_mult<TQ, KQ0, false>(C0, Ab, Bb);
+#pragma unroll
+		for (int ph = 0; ph < MC; ph += 2) {
+			fs_load<TQ, KQ0>(Ab, Bb, ap0 + (ph + 1) * P, bl0 + (ph + 1) * KQ0 * 16);
+			if (ph == 0) fs_mult<TQ, KQ0, FIRST>(C0, Aa, Ba); else fs_mult<TQ, KQ0, false>(C0, Aa, Ba);
+			if (ph + 2 < MC) fs_load<TQ, KQ0>(Aa, Ba, ap0 + (ph + 2) * P, bl0 + (ph + 2) * KQ0 * 16);
+			fs_mult<TQ, KQ0, false>(C0, Ab, Bb);
+		}
 	}
 }
 
 #define FS_BREG 8 /* B doubles per thread of a staged sub-split (<= 16 KB per workgroup), as in fwd_mfma.h */
 
-template <typename TIn, int KQ0, int KQ1>
+template <typename TIn, int TQ, int Mc, int KQ0, int KQ1>
 __global__ void __launch_bounds__(256) k_fwd_mfma_t(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned N, const FwdGroup *__restrict__ pd,
                                                     unsigned ngroups, const FwdOffsets offs, const double *__restrict__ bt, double2 *__restrict__ part,
                                                     size_t npart)
 {
-	constexpr int TQ = 8, Mc = 4, RPI = 16;
-	constexpr int NIMAX = (4 * TQ + 4 * FM_KQCAP + 3 + 15) / 16; // staging iterations per unit at 4 phases x 16 rows per iteration
+	constexpr int RPI = 64 / Mc, LOGMC = Mc == 4 ? 2 : 1;
+	constexpr int KQM = KQ0 > KQ1 ? KQ0 : KQ1;
+	constexpr int NIMAX = (4 * TQ + 4 * KQM + 6 + RPI - 1) / RPI; // staging iterations per unit (rows staged <= 4 TQ + 4 KQ + 3 + row offset <= 3)
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	double *smem = (double *)smem_raw;
 	unsigned lo = 0, hi = ngroups;
@@ -95,7 +99,7 @@ __global__ void __launch_bounds__(256) k_fwd_mfma_t(const TIn *__restrict__ x, s
 	const unsigned tid = threadIdx.x, lane = tid & 63;
 	const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const unsigned l_hi = lane >> 4, l_blk = (lane >> 2) & 3, l_lo = lane & 3;
-	const unsigned ml = lane & 3, rs = lane >> 2;
+	const unsigned ml = lane & (Mc - 1), rs = lane >> LOGMC;
 	const unsigned NI = (d.RT + RPI - 1) / RPI;
 	double *Bl = smem;                                       // staged B tiles of the current sub-split
 	double *img = smem + d.bl_doubles + wv * (4 * Pu);       // this wave's image: [unit][phase][row]
@@ -217,10 +221,10 @@ __global__ void __launch_bounds__(256) k_fwd_mfma_t(const TIn *__restrict__ x, s
 				FS_T1(t_fetch);
 				FS_T0();
 				const double *bl0 = Bl + ch * bper + b_lane, *bl1 = bl0 + bper0;
-				if (first_chunk) fs_chunk<KQ0, KQ1, true>(C0, C1, ap0, ap1, bl0, bl1, P);
-				else fs_chunk<KQ0, KQ1, false>(C0, C1, ap0, ap1, bl0, bl1, P);
+				if (first_chunk) fs_chunk<TQ, Mc, KQ0, KQ1, true>(C0, C1, ap0, ap1, bl0, bl1, P);
+				else fs_chunk<TQ, Mc, KQ0, KQ1, false>(C0, C1, ap0, ap1, bl0, bl1, P);
 #ifdef FS_TIMING
-				asm volatile("s_nop 0" :: "v"(C0[7]), "v"(C1[7])); // the last accumulators are done
+				asm volatile("s_nop 0" :: "v"(C0[TQ - 1]), "v"(C1[TQ - 1])); // the last accumulators are done
 				nstep++;
 #endif
 				FS_T1(t_mult);
@@ -260,46 +264,64 @@ __global__ void __launch_bounds__(256) k_fwd_mfma_t(const TIn *__restrict__ x, s
 typedef void (*kern_d)(const double *, size_t, unsigned, unsigned, const FwdGroup *, unsigned, const FwdOffsets, const double *, double2 *, size_t);
 typedef void (*kern_f)(const float *, size_t, unsigned, unsigned, const FwdGroup *, unsigned, const FwdOffsets, const double *, double2 *, size_t);
 
-template <int K0, int K1> struct Fill {
-	static void run(kern_d (&td)[9][9], kern_f (&tf)[9][9])
+// variants: 0 = (TQ 8, Mc 4) for KQ0 in 2..8, KQ1 in {0, 2..8}; 1 = (4, 4), 2 = (2, 4), 3 = (8, 2) for KQ0 in 2..5, KQ1 in {0, 2..5}
+struct Tables {
+	kern_d td[4][9][9];
+	kern_f tf[4][9][9];
+};
+
+template <int V, int TQ, int MC, int KMAX, int K0, int K1> struct Fill {
+	static void run(Tables &t)
 	{
-		td[K0][K1] = k_fwd_mfma_t<double, K0, K1>;
-		tf[K0][K1] = k_fwd_mfma_t<float, K0, K1>;
-		if constexpr (K1 < 8) Fill<K0, (K1 == 0 ? 2 : K1 + 1)>::run(td, tf);
-		else if constexpr (K0 < 8) Fill<K0 + 1, 0>::run(td, tf);
+		t.td[V][K0][K1] = k_fwd_mfma_t<double, TQ, MC, K0, K1>;
+		t.tf[V][K0][K1] = k_fwd_mfma_t<float, TQ, MC, K0, K1>;
+		if constexpr (K1 < KMAX) Fill<V, TQ, MC, KMAX, K0, (K1 == 0 ? 2 : K1 + 1)>::run(t);
+		else if constexpr (K0 < KMAX) Fill<V, TQ, MC, KMAX, K0 + 1, 0>::run(t);
 	}
 };
 
-struct Tables {
-	kern_d td[9][9];
-	kern_f tf[9][9];
-	Tables()
-	{
-		for (int a = 0; a < 9; a++) for (int b = 0; b < 9; b++) { td[a][b] = nullptr; tf[a][b] = nullptr; }
-		Fill<2, 0>::run(td, tf); // KQ0 in 2..8, KQ1 in {0, 2..8}
+const Tables &tables()
+{
+	static Tables t;
+	static bool init = false;
+	if (!init) {
+		for (int v = 0; v < 4; v++) for (int a = 0; a < 9; a++) for (int b = 0; b < 9; b++) { t.td[v][a][b] = nullptr; t.tf[v][a][b] = nullptr; }
+		Fill<0, 8, 4, 8, 2, 0>::run(t);
+		Fill<1, 4, 4, 5, 2, 0>::run(t);
+		Fill<2, 2, 4, 5, 2, 0>::run(t);
+		Fill<3, 8, 2, 5, 2, 0>::run(t);
+		init = true;
 	}
-};
-const Tables &tables() { static Tables t; return t; }
+	return t;
+}
+
+int variant_of(unsigned tq, unsigned mc) { return (tq == 8 && mc == 4) ? 0 : (tq == 4 && mc == 4) ? 1 : (tq == 2 && mc == 4) ? 2 : (tq == 8 && mc == 2) ? 3 : -1; }
 
 } // namespace
 
-int fwd_mfma_spec_has(unsigned kq0, unsigned kq1) { return kq0 < 9 && kq1 < 9 && tables().td[kq0][kq1] != nullptr; }
-
-int fwd_mfma_spec_launch(int is_float, unsigned kq0, unsigned kq1, unsigned items, size_t lds, void *stream, const void *x, size_t ld, unsigned ntr,
-                         unsigned N, const FwdGroup *pd, unsigned ngroups, const FwdOffsets &offs, const double *bt, void *part, size_t npart)
+int fwd_mfma_spec_has(unsigned tq, unsigned mc, unsigned kq0, unsigned kq1)
 {
-	if (!fwd_mfma_spec_has(kq0, kq1) || !items) return 0;
+	const int v = variant_of(tq, mc);
+	return v >= 0 && kq0 < 9 && kq1 < 9 && tables().td[v][kq0][kq1] != nullptr;
+}
+
+int fwd_mfma_spec_launch(int is_float, unsigned tq, unsigned mc, unsigned kq0, unsigned kq1, unsigned items, size_t lds, void *stream, const void *x,
+                         size_t ld, unsigned ntr, unsigned N, const FwdGroup *pd, unsigned ngroups, const FwdOffsets &offs, const double *bt, void *part,
+                         size_t npart)
+{
+	if (!fwd_mfma_spec_has(tq, mc, kq0, kq1) || !items) return 0;
+	const int v = variant_of(tq, mc);
 	if (getenv("TSPWS_DEBUG")) {
 		int nb = -1;
-		if (is_float) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tables().tf[kq0][kq1], 256, lds);
-		else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tables().td[kq0][kq1], 256, lds);
-		fprintf(stderr, "mfma spec (%u,%u): %u items, %zu B LDS, %d workgroups per CU\n", kq0, kq1, items, lds, nb);
+		if (is_float) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tables().tf[v][kq0][kq1], 256, lds);
+		else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tables().td[v][kq0][kq1], 256, lds);
+		fprintf(stderr, "mfma spec TQ %u Mc %u (%u,%u): %u items, %zu B LDS, %d workgroups per CU\n", tq, mc, kq0, kq1, items, lds, nb);
 	}
 	if (is_float)
-		hipLaunchKernelGGL(tables().tf[kq0][kq1], dim3(items), dim3(256), lds, (hipStream_t)stream, (const float *)x, ld, ntr, N, pd, ngroups, offs, bt,
+		hipLaunchKernelGGL(tables().tf[v][kq0][kq1], dim3(items), dim3(256), lds, (hipStream_t)stream, (const float *)x, ld, ntr, N, pd, ngroups, offs, bt,
 		                   (double2 *)part, npart);
 	else
-		hipLaunchKernelGGL(tables().td[kq0][kq1], dim3(items), dim3(256), lds, (hipStream_t)stream, (const double *)x, ld, ntr, N, pd, ngroups, offs, bt,
+		hipLaunchKernelGGL(tables().td[v][kq0][kq1], dim3(items), dim3(256), lds, (hipStream_t)stream, (const double *)x, ld, ntr, N, pd, ngroups, offs, bt,
 		                   (double2 *)part, npart);
 	return 1;
 }

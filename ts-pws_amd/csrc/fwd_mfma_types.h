@@ -20,7 +20,8 @@ struct FwdGroup {
 
 struct FwdOffsets { unsigned off[FM_MAXGROUPS + 1]; }; // first work item of every group in one launch (groups left out have no items)
 
-// fwd_mfma_spec.hip: kernels specialised on the tap steps of both pairs (TQ = 8, Mc = 4).  Returns 1 when it launched.
-int fwd_mfma_spec_launch(int is_float, unsigned kq0, unsigned kq1, unsigned items, size_t lds, void *stream, const void *x, size_t ld, unsigned ntr,
-                         unsigned N, const FwdGroup *pd, unsigned ngroups, const FwdOffsets &offs, const double *bt, void *part, size_t npart);
-int fwd_mfma_spec_has(unsigned kq0, unsigned kq1);
+// fwd_mfma_spec.hip: kernels specialised on (TQ, Mc) and the tap steps of both pairs.  launch returns 1 when it launched.
+int fwd_mfma_spec_launch(int is_float, unsigned tq, unsigned mc, unsigned kq0, unsigned kq1, unsigned items, size_t lds, void *stream, const void *x,
+                         size_t ld, unsigned ntr, unsigned N, const FwdGroup *pd, unsigned ngroups, const FwdOffsets &offs, const double *bt, void *part,
+                         size_t npart);
+int fwd_mfma_spec_has(unsigned tq, unsigned mc, unsigned kq0, unsigned kq1);

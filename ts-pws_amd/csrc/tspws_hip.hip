@@ -923,13 +923,16 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 			if (spec_on < 0) { const char *e = getenv("TSPWS_MFMA_SPEC"); spec_on = (e && *e == '0') ? 0 : 1; }
 			auto items_of = [&](const FwdGroup &d) { return (unsigned long long)d.nsplit * (((unsigned long long)nt * d.nob + d.upi - 1) / d.upi); };
 			auto spec_ok = [&](const FwdGroup &d) {
-				return spec_on && d.TQ == 8 && d.Mc == 4 && d.D % 4 == 0 && fwd_mfma_spec_has(d.Kq[0], d.NP > 1 ? d.Kq[1] : 0);
+				const unsigned rpi = 64 / d.Mc, kqm = std::max(d.Kq[0], d.NP > 1 ? d.Kq[1] : 0u);
+				const bool fits = (d.RT + rpi - 1) / rpi <= (4 * d.TQ + 4 * kqm + 6 + rpi - 1) / rpi; // the kernel's staging registers
+				return spec_on && fits && d.D % d.Mc == 0 && fwd_mfma_spec_has(d.TQ, d.Mc, d.Kq[0], d.NP > 1 ? d.Kq[1] : 0);
 			};
 			std::vector<char> done(ng, 0);
 			for (unsigned g0 = 0; g0 <= ng; g0++) { // one launch per (Kq0, Kq1) of the specialised groups, then one for the rest
 				const bool rest = g0 == ng;
 				if (!rest && (done[g0] || !spec_ok(p->pairs[g0]))) continue;
 				const unsigned k0 = rest ? 0 : p->pairs[g0].Kq[0], k1 = rest ? 0 : (p->pairs[g0].NP > 1 ? p->pairs[g0].Kq[1] : 0);
+				const unsigned tq0 = rest ? 0 : p->pairs[g0].TQ, mc0 = rest ? 0 : p->pairs[g0].Mc;
 				FwdOffsets offs;
 				unsigned long long items = 0;
 				for (unsigned g = 0; g < ng; g++) {
@@ -937,7 +940,7 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 					offs.off[g] = (unsigned)items;
 					if (only >= 0 && (unsigned)only != g) continue;
 					if (done[g]) continue;
-					if (!rest && !(spec_ok(d) && d.Kq[0] == k0 && (d.NP > 1 ? d.Kq[1] : 0) == k1)) continue;
+					if (!rest && !(spec_ok(d) && d.TQ == tq0 && d.Mc == mc0 && d.Kq[0] == k0 && (d.NP > 1 ? d.Kq[1] : 0) == k1)) continue;
 					items += items_of(d);
 					done[g] = 1;
 				}
@@ -948,7 +951,7 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 					hipLaunchKernelGGL((k_fwd_mfma<TIn>), dim3((unsigned)items), dim3(256), p->mfma_lds, st, d_x + t0 * ld, ld, nt, p->N, p->d_pairs, ng, offs,
 					                   p->d_bt, d_part + t0 * p->npart, p->npart);
 				else
-					fwd_mfma_spec_launch(sizeof(TIn) == 4, k0, k1, (unsigned)items, p->mfma_lds, st, d_x + t0 * ld, ld, nt, p->N, p->d_pairs, ng, offs, p->d_bt,
+					fwd_mfma_spec_launch(sizeof(TIn) == 4, tq0, mc0, k0, k1, (unsigned)items, p->mfma_lds, st, d_x + t0 * ld, ld, nt, p->N, p->d_pairs, ng, offs, p->d_bt,
 					                     d_part + t0 * p->npart, p->npart);
 			}
 		}
