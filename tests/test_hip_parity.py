@@ -505,3 +505,31 @@ def test_forward_matrix_pipe_kernel(lib, torch, kw, N, ntr, monkeypatch):
     torch.cuda.synchronize()
     b = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(Kmax=2, unbiased=1, **kw), X)
     assert abi.relerr(ts.cpu().numpy(), b["tsPWS"]) < TOL32
+
+
+@pytest.mark.gpu
+def test_more_than_2_to_32_samples(lib, torch):
+    """BASELINE configs[4] shards 100 000 x 131 072 traces over 8 GPUs; the reference cannot index that (32-bit itr*max,
+    SURVEY section 8).  One GPU with 40 000 traces = 5.2e9 samples crosses 2^32 element offsets: group sums and the
+    last trace must still land where they belong."""
+    mtr, N, K = 40000, 131072, 10
+    p = tspws.resolve(abi.default_params(Kmax=K, unbiased=1), N)
+    pl = tspws.Plan(p, N)
+    Xd = tspws.synth(mtr, N, seed=3)
+    assert Xd.numel() > 2 ** 32
+    pl.stack_local(Xd, 0, mtr)
+    P = pl.reduce_buffer(mtr).view(K, N).clone()
+    g9 = torch.zeros(N, dtype=torch.float64, device="cuda")
+    for t0 in range(36000, 40000, 500):
+        g9 += Xd[t0:t0 + 500].double().sum(dim=0)
+    assert float((P[9] - g9).abs().max()) <= 1e-9
+    before = Xd[-1].double()
+    Xd[-1] += 1.0  # only the very last trace changes -> only group 9 moves, by the (float-rounded) increment
+    delta = Xd[-1].double() - before
+    pl.stack_local(Xd, 0, mtr)
+    P2 = pl.reduce_buffer(mtr).view(K, N)
+    assert float((P2[:9] - P[:9]).abs().max()) == 0.0
+    assert float((P2[9] - P[9] - delta).abs().max()) <= 1e-9
+    ls, ts = pl.stack(Xd)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ts).all()) and bool(torch.isfinite(ls).all())
