@@ -60,7 +60,10 @@ def main():
     mtr_global = mtr_local * world
     first = rank * mtr_local
     params = tspws.resolve(abi.default_params(Kmax=K, unbiased=1), N)
-    plan = tspws.Plan(params, N, device=local)
+    t_plan = time.perf_counter()
+    plan = tspws.Plan(params, N, device=local)  # frame geometry + tap generation on the device (outside the timed region)
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter() - t_plan
     X = tspws.synth(mtr_local, N, seed=1, first=first, device=local)
     lib = tspws.load()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -140,7 +143,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{mtr_local} traces/GPU x {N} samples, Morlet w0=pi*sqrt(2/ln2) V=4 J={params.J}, "
                                f"two-stage K={K} + unbiased phase coherence (BASELINE configs[2]); HBM-resident float32 traces",
-                   "traces_total": mtr_global, "parallelism": f"trace-sharded x{world}, fp64 all-reduce of P[K][N] (two halves, first overlapped with streaming)"},
+                   "traces_total": mtr_global, "plan_create_ms": round(t_plan * 1e3, 3), "parallelism": f"trace-sharded x{world}, fp64 all-reduce of P[K][N] (two halves, first overlapped with streaming)"},
         "roofline": {"bound": "hbm", "kernel": "k_partial (+k_reduce_chunks)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": stream_ms,
