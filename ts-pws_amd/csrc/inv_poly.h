@@ -14,6 +14,13 @@
 //   lanes     = consecutive n0 (taps and outputs coalesced; the coefficient row is wave-uniform when D >= 64)
 //   all V voices of the octave (same D) are summed in registers; octave sums go to obuf[octave][rec][N]
 //   and k_inv_combine adds the <= J octave rows (+ the generic-path row) in a fixed order.
+//
+// Round-1 measurements (north-star frame, 2 coefficient sets: 3584 waves, all resident at once, 50 us): a wave's life is
+// ~13 dependent memory round trips (window preload + blocks of 8 tap steps, for each of the 4 voices) of ~3 us each --
+// 24 vector loads per lane and block from 14 lock-stepped waves per CU -- while its 1.9 k FMAs need < 4 us.  Tried and
+// not faster: the 4 voices on 4 waves with an LDS reduction (49 us: twice the waves no longer fit in one round), all
+// taps of a voice hoisted into registers (152 VGPRs -> two rounds, 112 us), the partial last block as one guarded
+// block (50 us).  What would help is a per-voice bulk load of the coefficient window into LDS, within <= 128 VGPRs.
 #pragma once
 
 #define INV_R 8
