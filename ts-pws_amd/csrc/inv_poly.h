@@ -20,7 +20,11 @@
 // 24 vector loads per lane and block from 14 lock-stepped waves per CU -- while its 1.9 k FMAs need < 4 us.  Tried and
 // not faster: the 4 voices on 4 waves with an LDS reduction (49 us: twice the waves no longer fit in one round), all
 // taps of a voice hoisted into registers (152 VGPRs -> two rounds, 112 us), the partial last block as one guarded
-// block (50 us).  What would help is a per-voice bulk load of the coefficient window into LDS, within <= 128 VGPRs.
+// block (50 us), and an LDS-staged variant (two waves per workgroup, per voice one bulk load of the tap tile and of the
+// coefficient windows, steps out of LDS: 45.6 us at 166 VGPRs / two rounds, 52 us capped to 128 VGPRs).  Its timers
+// put the steps themselves at 24 us per wave with four waves per SIMD: the 6.9 M wave-FMAs of the two reconstructions
+// are 13 us of pipe time at the full v_fma_f64 rate, ~30 us at the rate this chip sustains at that occupancy -- the
+// kernel is closer to its arithmetic bound than the round-trip count suggests.
 #pragma once
 
 #define INV_R 8
