@@ -86,6 +86,13 @@ def main():
         buf = red.view(K, N)
         if i is not None:
             ev[i][0].record()
+        if half == 0:  # a single group: nothing to overlap
+            plan.partial_stacks_range(X, first, mtr_global, 0, K)
+            if i is not None:
+                ev[i][1].record()
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            plan.stack_finish(mtr_global, ls, ts)
+            return
         plan.partial_stacks_range(X, first, mtr_global, 0, half)
         w1 = dist.all_reduce(buf[:half], op=dist.ReduceOp.SUM, async_op=True)
         plan.partial_stacks_range(X, first, mtr_global, half, K)
