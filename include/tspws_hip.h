@@ -140,6 +140,16 @@ int  tspws_hip_reduce_buffer(tspws_hip_plan *plan, const t_tsPWS *p, size_t mtr_
 int  tspws_hip_stack_finish(tspws_hip_plan *plan, const t_tsPWS *p, size_t mtr_global,
                             float *d_ls, float *d_tsPWS, void *stream);
 
+/* The finish stage in pieces, for callers that overlap it with the reduction of the second half of the groups (_range:
+ * two-stage calls only).  _range transforms the already reduced partial stacks g_begin <= g < g_end of the reduce buffer
+ * and adds them to the linear / phase stacks (ts_pws1f_lib.c:885-906); g_begin == 0 starts from zero, and ranges must
+ * be given in increasing order so that the sums keep the reference's trace order.  _tail applies the weight, both inverse
+ * transforms and the epilogue (ts_pws1f_lib.c:226-241).  tspws_hip_stack_finish == _range(0, Kmax) + _tail. */
+int  tspws_hip_stack_finish_range(tspws_hip_plan *plan, const t_tsPWS *p, size_t mtr_global,
+                                  unsigned g_begin, unsigned g_end, void *stream);
+int  tspws_hip_stack_finish_tail(tspws_hip_plan *plan, const t_tsPWS *p, size_t mtr_global,
+                                 float *d_ls, float *d_tsPWS, void *stream);
+
 /* Single-GPU convenience: _local + _finish in one call.  With TSPWS_OVERLAP=1 a two-stage request is pipelined
  * instead: the partial stacks are streamed group by group on `stream` while an internal second stream transforms
  * each finished batch of groups (opt-in: on MI355X the co-running kernels currently slow each other as much as the

@@ -533,3 +533,29 @@ def test_more_than_2_to_32_samples(lib, torch):
     ls, ts = pl.stack(Xd)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(ts).all()) and bool(torch.isfinite(ls).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(Kmax=10, unbiased=1), dict(Kmax=7), dict(type=-3, Kmax=4, wu=1.0)])
+def test_finish_in_pieces_is_bit_identical(lib, torch, kw):
+    """The multi-GPU orchestration transforms the first half of the groups while the second half is still being reduced:
+    stack_finish_range(0, h) + stack_finish_range(h, K) + stack_finish_tail must equal stack_finish bit for bit."""
+    mtr, N = 64, 8192
+    p = tspws.resolve(abi.default_params(**kw), N)
+    pl = tspws.Plan(p, N)
+    K = p.Kmax
+    Xd = tspws.synth(mtr, N, seed=6)
+    ls0, ts0 = pl.stack(Xd)
+    ls0, ts0 = ls0.clone(), ts0.clone()
+    pl.stack_local(Xd, 0, mtr)
+    ls1 = torch.empty_like(ls0)
+    ts1 = torch.empty_like(ts0)
+    h = K // 2
+    pl.stack_finish_range(mtr, 0, h)
+    pl.stack_finish_range(mtr, h, K)
+    pl.stack_finish_tail(mtr, ls1, ts1)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(ls1.cpu().numpy(), ls0.cpu().numpy())
+    np.testing.assert_array_equal(ts1.cpu().numpy(), ts0.cpu().numpy())
+    with pytest.raises(tspws.TspwsError):
+        pl.stack_finish_range(mtr, 3, K + 1)

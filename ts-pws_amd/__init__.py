@@ -98,6 +98,8 @@ SYMBOLS = {
     "tspws_hip_stack_local": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "tspws_hip_reduce_buffer": (_i, [_vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz)]),
     "tspws_hip_stack_finish": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "tspws_hip_stack_finish_range": (_i, [_vp, _vp, _sz, _u, _u, _vp]),
+    "tspws_hip_stack_finish_tail": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "tspws_hip_stack": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "tspws_hip_profile_begin": (_i, [_vp, _sz]),
     "tspws_hip_profile_end": (_i, [_vp, C.POINTER(_d), C.POINTER(_sz)]),
@@ -211,6 +213,16 @@ class Plan:
         check(self.lib.tspws_hip_stack_finish(self.h, C.byref(self.params), mtr_global, ls.data_ptr(), ts.data_ptr(), self._stream()),
               "stack_finish")
 
+    def stack_finish_range(self, mtr_global, g_begin, g_end):
+        """Two-stage: transform the reduced partial stacks [g_begin, g_end) and add them to the linear / phase stacks."""
+        check(self.lib.tspws_hip_stack_finish_range(self.h, C.byref(self.params), mtr_global, g_begin, g_end, self._stream()),
+              "stack_finish_range")
+
+    def stack_finish_tail(self, mtr_global, ls, ts):
+        """Weight, inverse transforms, epilogue (after every group went through stack_finish_range)."""
+        check(self.lib.tspws_hip_stack_finish_tail(self.h, C.byref(self.params), mtr_global, ls.data_ptr(), ts.data_ptr(), self._stream()),
+              "stack_finish_tail")
+
     def stack(self, traces, first=0, mtr_global=None, group=None):
         """ls, tsPWS (float32 cuda tensors) of a shard of HBM-resident traces; see stack_sharded."""
         return stack_sharded(self, traces, first, mtr_global, group)
@@ -261,12 +273,22 @@ def stack_sharded(plan, traces, first=0, mtr_global=None, group=None):
         w1 = dist.all_reduce(buf[:half], op=dist.ReduceOp.SUM, group=group, async_op=True)
         plan.partial_stacks_range(traces, first, mtr_global, half, K)
         w2 = dist.all_reduce(buf[half:], op=dist.ReduceOp.SUM, group=group, async_op=True)
+        ls = torch.empty(plan.N, dtype=torch.float32, device=traces.device)
+        ts = torch.empty(plan.N, dtype=torch.float32, device=traces.device)
         w1.wait()
-        w2.wait()
-    else:
-        plan.stack_local(traces, first, mtr_global)
-        if distributed:
-            dist.all_reduce(plan.reduce_buffer(mtr_global), op=dist.ReduceOp.SUM, group=group)
+        if callable(getattr(plan, "stack_finish_range", None)):
+            # the transforms of the first half of the groups run while the second half is still being reduced
+            plan.stack_finish_range(mtr_global, 0, half)
+            w2.wait()
+            plan.stack_finish_range(mtr_global, half, K)
+            plan.stack_finish_tail(mtr_global, ls, ts)
+        else:
+            w2.wait()
+            plan.stack_finish(mtr_global, ls, ts)
+        return ls, ts
+    plan.stack_local(traces, first, mtr_global)
+    if distributed:
+        dist.all_reduce(plan.reduce_buffer(mtr_global), op=dist.ReduceOp.SUM, group=group)
     ls = torch.empty(plan.N, dtype=torch.float32, device=traces.device)
     ts = torch.empty(plan.N, dtype=torch.float32, device=traces.device)
     plan.stack_finish(mtr_global, ls, ts)

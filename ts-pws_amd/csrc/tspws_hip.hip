@@ -1065,11 +1065,11 @@ extern "C" int tspws_hip_accumulate(tspws_hip_plan *p, const double *d_Y, size_t
 }
 
 template <typename TIn>
-static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, void *s)
-{
+static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, void *s, bool keep = false)
+{ // keep: add to the stacks already in d_ST / d_PS instead of starting from zero
 	HIP_TRY(hipSetDevice(p->device));
 	hipStream_t st = S_(s);
-	if (!ntr) { HIP_TRY(hipMemsetAsync(d_ST, 0, p->ncoef * 16, st)); HIP_TRY(hipMemsetAsync(d_PS, 0, p->ncoef * 16, st)); return 0; }
+	if (!ntr) { if (!keep) { HIP_TRY(hipMemsetAsync(d_ST, 0, p->ncoef * 16, st)); HIP_TRY(hipMemsetAsync(d_PS, 0, p->ncoef * 16, st)); } return 0; }
 	int rc;
 	if (use_generic_forward()) {
 		size_t batch = std::max<size_t>(1, ((size_t)256 << 20) / (p->ncoef * sizeof(double2)));
@@ -1079,7 +1079,7 @@ static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld,
 		for (size_t t0 = 0; t0 < ntr; t0 += batch) {
 			const size_t nb = std::min(batch, ntr - t0);
 			if ((rc = forward_generic<TIn>(p, d_x + t0 * ld, nb, ld, (double *)d_Y, st))) return rc;
-			if ((rc = tspws_hip_accumulate(p, (const double *)d_Y, nb, d_ST, d_PS, t0 == 0, s))) return rc;
+			if ((rc = tspws_hip_accumulate(p, (const double *)d_Y, nb, d_ST, d_PS, t0 == 0 && !keep, s))) return rc;
 		}
 		return 0;
 	}
@@ -1091,7 +1091,7 @@ static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld,
 		const size_t nb = std::min(batch, ntr - t0);
 		if ((rc = forward_parts<TIn>(p, d_x + t0 * ld, nb, ld, (double2 *)v, st))) return rc;
 		hipLaunchKernelGGL(k_accumulate_parts, dim3(p->acc2_blocks), dim3(256), 0, st, (const double2 *)v, p->npart, p->d_sc, p->S,
-		                   (unsigned)nb, (double2 *)d_ST, (double2 *)d_PS, t0 == 0 ? 1 : 0);
+		                   (unsigned)nb, (double2 *)d_ST, (double2 *)d_PS, (t0 == 0 && !keep) ? 1 : 0);
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
@@ -1364,33 +1364,61 @@ extern "C" int tspws_hip_stack_local(tspws_hip_plan *pl, const t_tsPWS *p, const
 	return tspws_hip_stacks_float(pl, d_x, mtr_local, ld, buf, buf + 2 * pl->ncoef, s);
 }
 
-extern "C" int tspws_hip_stack_finish(tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, float *d_ls, float *d_ts, void *s)
+// coefficient block of the finish stage: [OUT | ST | PS] so that the two inverses read rows 0 and 1
+static int finish_block(tspws_hip_plan *pl, double **OUT, double **ST, double **PS)
 {
-	if (!pl || !p) return fail(TSPWS_E_ARG, "stack_finish: NULL");
-	HIP_TRY(hipSetDevice(pl->device));
-	int rc;
 	void *v;
 	const size_t nc = pl->ncoef;
-	// coefficient block: [OUT | ST | PS] so that the two inverses read rows 0 and 1
-	if ((rc = scratch(pl, SCR_OUT, 6 * nc * sizeof(double), &v))) return rc;
-	double *OUT = (double *)v, *ST = OUT + 2 * nc, *PS = ST + 2 * nc;
-	unsigned K;
-	if (is_two_stage(p, mtr_global)) {
-		double *P; size_t nd;
-		if ((rc = tspws_hip_reduce_buffer(pl, p, mtr_global, &P, &nd))) return rc;
-		K = p->Kmax;
-		if ((rc = tspws_hip_stacks_double(pl, P, K, pl->N, ST, PS, s))) return rc;
-	} else {
-		double *B; size_t nd;
-		if ((rc = tspws_hip_reduce_buffer(pl, p, mtr_global, &B, &nd))) return rc;
-		K = (unsigned)mtr_global;
-		HIP_TRY(hipMemcpyAsync(ST, B, 4 * nc * sizeof(double), hipMemcpyDeviceToDevice, S_(s)));
-	}
+	int rc = scratch(pl, SCR_OUT, 6 * nc * sizeof(double), &v);
+	if (rc) return rc;
+	*OUT = (double *)v; *ST = *OUT + 2 * nc; *PS = *ST + 2 * nc;
+	return 0;
+}
+
+extern "C" int tspws_hip_stack_finish_range(tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, unsigned g_begin, unsigned g_end, void *s)
+{
+	if (!pl || !p) return fail(TSPWS_E_ARG, "stack_finish_range: NULL");
+	if (!is_two_stage(p, mtr_global) || g_begin > g_end || g_end > p->Kmax) return fail(TSPWS_E_ARG, "stack_finish_range: two-stage calls, 0 <= g_begin <= g_end <= Kmax");
+	HIP_TRY(hipSetDevice(pl->device));
+	double *OUT, *ST, *PS, *P;
+	size_t nd;
+	int rc;
+	if ((rc = finish_block(pl, &OUT, &ST, &PS))) return rc;
+	if ((rc = tspws_hip_reduce_buffer(pl, p, mtr_global, &P, &nd))) return rc;
+	return stacks_impl<double>(pl, P + (size_t)g_begin * pl->N, g_end - g_begin, pl->N, ST, PS, s, g_begin != 0);
+}
+
+extern "C" int tspws_hip_stack_finish_tail(tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, float *d_ls, float *d_ts, void *s)
+{
+	if (!pl || !p) return fail(TSPWS_E_ARG, "stack_finish_tail: NULL");
+	HIP_TRY(hipSetDevice(pl->device));
+	double *OUT, *ST, *PS;
+	int rc;
+	void *v;
+	if ((rc = finish_block(pl, &OUT, &ST, &PS))) return rc;
+	const unsigned K = is_two_stage(p, mtr_global) ? p->Kmax : (unsigned)mtr_global;
 	if ((rc = tspws_hip_weight(pl, OUT, ST, PS, K, (unsigned)mtr_global, p->wu, p->unbiased, s))) return rc;
 	if ((rc = scratch(pl, SCR_X2, 2 * (size_t)pl->N * sizeof(double), &v))) return rc;
 	double *x2 = (double *)v;
 	if ((rc = tspws_hip_inverse(pl, OUT, 2, x2, s))) return rc; // row 0 = ICWT(OUT), row 1 = ICWT(ST)
 	return tspws_hip_epilogue(d_ls, d_ts, x2 + pl->N, x2, pl->N, (unsigned)mtr_global, s);
+}
+
+extern "C" int tspws_hip_stack_finish(tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, float *d_ls, float *d_ts, void *s)
+{
+	if (!pl || !p) return fail(TSPWS_E_ARG, "stack_finish: NULL");
+	HIP_TRY(hipSetDevice(pl->device));
+	int rc;
+	if (is_two_stage(p, mtr_global)) {
+		if ((rc = tspws_hip_stack_finish_range(pl, p, mtr_global, 0, p->Kmax, s))) return rc;
+	} else {
+		double *OUT, *ST, *PS, *B;
+		size_t nd;
+		if ((rc = finish_block(pl, &OUT, &ST, &PS))) return rc;
+		if ((rc = tspws_hip_reduce_buffer(pl, p, mtr_global, &B, &nd))) return rc;
+		HIP_TRY(hipMemcpyAsync(ST, B, 4 * pl->ncoef * sizeof(double), hipMemcpyDeviceToDevice, S_(s)));
+	}
+	return tspws_hip_stack_finish_tail(pl, p, mtr_global, d_ls, d_ts, s);
 }
 
 // ------------------------------------------------------------------------------------------
