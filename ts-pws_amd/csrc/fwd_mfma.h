@@ -28,6 +28,8 @@
 // img[unit][phase][row] (unit pitch = 8 mod 32 doubles: the four units of an operand read hit disjoint banks), which
 // both pairs read (their origins differ by whole rows), after fetching the rows of its NEXT step into registers.
 //
+// (This file is the GENERIC kernel: tap steps are run-time values.  Groups whose shape has a specialised kernel run on
+// fwd_mfma_spec.hip instead -- see its header for the current numbers; the figures below are for this kernel alone.)
 // Status (round 1): parity-green on every frame of the test suite (tests/test_hip_parity.py::test_forward_matrix_pipe_kernel)
 // but OPT-IN (TSPWS_FWD_KERNEL=mfma): 10 x 131072 north-star transforms take 294 us against 198 us on the VALU kernels
 // (k_fwd_lds + k_fwd_poly); 1024 x 32768 single-stage 8.0 ms against 6.1 ms.  PMC (profiles/r01_mfma_forward_pmc.txt):
