@@ -2,7 +2,7 @@
 # usage (GPU box, repo root): bash profiles/collect_pmc.sh TAG
 # Separate rocprofv3 --pmc passes (counters never combined with sys/hip traces), csv output into gpurun_out/pmc_TAG/
 TAG=${1:-x}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

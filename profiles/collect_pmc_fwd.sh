@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: bash profiles/collect_pmc_fwd.sh TAG [ENV=VAL...]  -- SQ/LDS counters for the forward kernels
 TAG=$1; shift
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmcf_$TAG
 mkdir -p $OUT
 for kv in "$@"; do export "$kv"; done

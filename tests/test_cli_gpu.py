@@ -96,3 +96,19 @@ def test_convergence_and_subsampling_outputs(sac_list, golden):
     assert abi.relerr(steps[-1], g["ex1/tsPWS"]) < 2e-6
     s0 = abi.read_sac(sac_list / "ts_pws_cv_subsmpl_0.sac")
     assert s0["i"][9] == 16501 and np.isfinite(s0["data"]).all() and s0["data"].any()
+
+
+def test_nmax_beyond_the_trace_count_is_clamped(sac_list, golden):
+    """Nmax larger than the traces read: tspws_main clamps it, and the CLI sizes its convergence dumps and the user0 header
+    field with the clamped count (the reference takes Nmax unchecked, ts_pws1f_lib.c:65)."""
+    g = golden["example32"]
+    out = run_cli(sac_list, "list.txt", "osac=nm", "Nmax=1000", "convergence")
+    assert "exceeds" in out
+    ts = abi.read_sac(sac_list / "ts_pws_nm.sac")
+    assert ts["f"][40] == 32.0                                                       # user0 = traces actually stacked
+    assert abi.relerr(ts["data"], g["ex1/tsPWS"]) < 2e-6
+    sim = np.fromfile(sac_list / "ts_pws_nm_convergence", "<f8")
+    assert sim.shape == (32,) and abs(sim[-1] - 1.0) < 1e-6
+    # Nmax below the count still selects a prefix
+    run_cli(sac_list, "list.txt", "osac=n8", "Nmax=8")
+    assert abi.read_sac(sac_list / "ts_pws_n8.sac")["f"][40] == 8.0

@@ -115,3 +115,15 @@ def test_two_rank_shards_match_unsharded(tmp_path, kw):
     for r in range(world):
         assert abi.relerr(np.load(tmp_path / f"ls{r}.npy"), want["ls"]) < 2e-6
         assert abi.relerr(np.load(tmp_path / f"ts{r}.npy"), want["tsPWS"]) < 2e-6
+
+
+def test_empty_shard_reaches_the_collective(tmp_path):
+    """mtr_global < world: rank 0 holds no trace at all, yet it must walk the same sequence of collectives (the
+    overlapped two-half reduction) and end with the same outputs as every other rank."""
+    kw, mtr, N, world = dict(Kmax=2, unbiased=1), 2, 1024, 3
+    assert tspws.shard_range(mtr, 0, world) == (0, 0)
+    mp.spawn(_worker, args=(world, _free_port(), kw, mtr, N, str(tmp_path)), nprocs=world, join=True)
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), abi.synth_traces(mtr, N, seed=17))
+    for r in range(world):
+        assert abi.relerr(np.load(tmp_path / f"ls{r}.npy"), want["ls"]) < 2e-6
+        assert abi.relerr(np.load(tmp_path / f"ts{r}.npy"), want["tsPWS"]) < 2e-6

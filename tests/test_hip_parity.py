@@ -559,3 +559,62 @@ def test_finish_in_pieces_is_bit_identical(lib, torch, kw):
     np.testing.assert_array_equal(ts1.cpu().numpy(), ts0.cpu().numpy())
     with pytest.raises(tspws.TspwsError):
         pl.stack_finish_range(mtr, 3, K + 1)
+
+
+@pytest.mark.gpu
+def test_empty_shard_and_wrapper_checks(lib, torch):
+    """A rank whose shard is empty (mtr_global < world) must still reach the collective: partial_stacks_range and
+    stack_local accept a (0, N) tensor (data_ptr() == 0) and leave zero rows.  The ctypes wrappers reject tensors the C ABI
+    would silently reinterpret."""
+    N, K, mtr_global = 2048, 2, 2
+    p = tspws.resolve(abi.default_params(Kmax=K), N)
+    pl = tspws.Plan(p, N)
+    X = tspws.synth(mtr_global, N, seed=11)
+    buf = pl.reduce_buffer(mtr_global)
+    buf.fill_(7.0)
+    pl.partial_stacks_range(X[:0], 0, mtr_global, 0, 1)
+    pl.partial_stacks_range(X[:0], 0, mtr_global, 1, K)
+    torch.cuda.synchronize()
+    assert float(buf.abs().max()) == 0.0
+    # three "ranks" (empty, trace 0, trace 1) sum to the unsharded partial stacks
+    total = torch.zeros_like(buf)
+    for f, c in ((0, 0), (0, 1), (1, 1)):
+        pl.partial_stacks_range(X[f:f + c], f, mtr_global, 0, K)
+        total += pl.reduce_buffer(mtr_global)
+    pl.stack_local(X, 0, mtr_global)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(total.cpu().numpy(), pl.reduce_buffer(mtr_global).cpu().numpy())
+    # shard outside the ensemble
+    assert lib.tspws_hip_partial_stacks(pl.h, X.data_ptr(), N, 2, 1, 2, K, buf.data_ptr(), N, None) == -1
+    # wrapper argument checks
+    with pytest.raises(tspws.TspwsError):
+        pl.stack_local(X.double(), 0, mtr_global)
+    with pytest.raises(tspws.TspwsError):
+        pl.stack_local(X.t().contiguous().t(), 0, mtr_global)     # column-major view: stride(1) != 1
+    with pytest.raises(tspws.TspwsError):
+        pl.stack_local(X[:, : N // 2], 0, mtr_global)             # wrong trace length
+    with pytest.raises(tspws.TspwsError):
+        pl.stack_single(X, ls=torch.empty(N, dtype=torch.float64, device=X.device))
+
+
+@pytest.mark.gpu
+def test_reduce_buffer_survives_growth(lib, torch):
+    """A reduce-buffer view handed to a collective must stay valid when the same plan later needs a larger buffer
+    (another Kmax / a single-stage call): the outgrown block is retired, not freed, and a fresh view is returned."""
+    N = 2048
+    p = tspws.resolve(abi.default_params(Kmax=2), N)
+    pl = tspws.Plan(p, N)
+    X = tspws.synth(8, N, seed=12)
+    pl.stack_local(X, 0, 8)
+    small = pl.reduce_buffer(8)
+    keep = small.clone()
+    pl.params.Kmax = 8                        # same plan, four times the partial-stack rows
+    big = pl.reduce_buffer(8)
+    assert big.numel() == 8 * N and big.data_ptr() != small.data_ptr()
+    big.fill_(1.0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(small.cpu().numpy(), keep.cpu().numpy())   # old view still readable, untouched
+    pl.params.Kmax = 2
+    ls, ts = pl.stack(X)
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(Kmax=2), X.cpu().numpy())
+    assert abi.relerr(ts.cpu().numpy(), want["tsPWS"]) < TOL32

@@ -4,7 +4,7 @@
 TAG=${1:-x}; shift
 mkdir -p gpurun_out
 (timeout 1500 python -m pytest tests -m gpu -q -x "$@" 2>&1 | tail -40) > gpurun_out/test_$TAG.log
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o b -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu > $R/gpurun_out/bench_$TAG.log 2>&1
 cd $R

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: bash gpu_prof.sh TAG [ENV=VAL ...] -- profile bench.py (no tests) with optional env
 TAG=$1; shift
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done

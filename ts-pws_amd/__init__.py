@@ -190,27 +190,52 @@ class Plan:
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def reduce_buffer(self, mtr_global):
-        """torch view (float64) of the buffer a multi-GPU caller all-reduces between the halves."""
+        """torch view (float64) of the buffer a multi-GPU caller all-reduces between the halves.
+
+        The view aliases library scratch: it is the buffer of THIS (two-stage / single-stage, Kmax, mtr_global) shape.
+        A later call that needs a larger buffer allocates a new block (the old one stays alive until the plan is
+        destroyed, so an in-flight collective on it is safe) -- fetch the view again after changing the shape."""
         import torch
         ptr, n = C.c_void_p(), C.c_size_t()
         check(self.lib.tspws_hip_reduce_buffer(self.h, C.byref(self.params), mtr_global, C.byref(ptr), C.byref(n)), "reduce_buffer")
         return _as_tensor(ptr.value, n.value, torch.float64, self.device)
 
+    def _traces(self, traces):
+        """(rows, row stride) of a float32 [mtr][N] device tensor after checking what the C ABI cannot see."""
+        import torch
+        if traces.dtype != torch.float32 or traces.dim() != 2 or traces.shape[1] != self.N:
+            raise TspwsError(f"traces must be float32 [mtr][{self.N}], got {traces.dtype} {tuple(traces.shape)}")
+        if traces.shape[0] and traces.stride(1) != 1:
+            raise TspwsError("traces must be contiguous along the samples (stride(1) == 1)")
+        if not traces.is_cuda or (traces.device.index or 0) != self.device:
+            raise TspwsError(f"traces live on {traces.device}, the plan on cuda:{self.device}")
+        mtr = traces.shape[0]
+        ld = traces.stride(0) if mtr > 1 else traces.shape[1]
+        if ld < self.N:
+            raise TspwsError("overlapping trace rows (stride(0) < N)")
+        return mtr, ld
+
+    def _out(self, t, name):
+        import torch
+        if t.dtype != torch.float32 or t.numel() < self.N or not t.is_contiguous() or not t.is_cuda or (t.device.index or 0) != self.device:
+            raise TspwsError(f"{name} must be a contiguous float32 tensor of >= {self.N} samples on cuda:{self.device}")
+        return t.data_ptr()
+
     def stack_local(self, traces, first=0, mtr_global=None):
-        mtr, ld = traces.shape[0], traces.stride(0) if traces.shape[0] > 1 else traces.shape[1]
+        mtr, ld = self._traces(traces)
         mtr_global = mtr if mtr_global is None else mtr_global
         check(self.lib.tspws_hip_stack_local(self.h, C.byref(self.params), traces.data_ptr(), ld, mtr, first, mtr_global, self._stream()),
               "stack_local")
 
     def partial_stacks_range(self, traces, first, mtr_global, g_begin, g_end):
         """Two-stage only: stream the groups [g_begin, g_end) of this shard into rows of the reduce buffer."""
-        mtr, ld = traces.shape[0], traces.stride(0) if traces.shape[0] > 1 else traces.shape[1]
+        mtr, ld = self._traces(traces)
         buf = self.reduce_buffer(mtr_global)
         check(self.lib.tspws_hip_partial_stacks_range(self.h, traces.data_ptr(), ld, mtr, first, mtr_global, self.params.Kmax, g_begin, g_end,
                                                       buf.data_ptr(), self.N, self._stream()), "partial_stacks_range")
 
     def stack_finish(self, mtr_global, ls, ts):
-        check(self.lib.tspws_hip_stack_finish(self.h, C.byref(self.params), mtr_global, ls.data_ptr(), ts.data_ptr(), self._stream()),
+        check(self.lib.tspws_hip_stack_finish(self.h, C.byref(self.params), mtr_global, self._out(ls, "ls"), self._out(ts, "ts"), self._stream()),
               "stack_finish")
 
     def stack_finish_range(self, mtr_global, g_begin, g_end):
@@ -220,8 +245,8 @@ class Plan:
 
     def stack_finish_tail(self, mtr_global, ls, ts):
         """Weight, inverse transforms, epilogue (after every group went through stack_finish_range)."""
-        check(self.lib.tspws_hip_stack_finish_tail(self.h, C.byref(self.params), mtr_global, ls.data_ptr(), ts.data_ptr(), self._stream()),
-              "stack_finish_tail")
+        check(self.lib.tspws_hip_stack_finish_tail(self.h, C.byref(self.params), mtr_global, self._out(ls, "ls"), self._out(ts, "ts"),
+                                                   self._stream()), "stack_finish_tail")
 
     def stack(self, traces, first=0, mtr_global=None, group=None):
         """ls, tsPWS (float32 cuda tensors) of a shard of HBM-resident traces; see stack_sharded."""
@@ -230,11 +255,11 @@ class Plan:
     def stack_single(self, traces, ls=None, ts=None):
         """Whole call on ONE GPU through tspws_hip_stack (pipelined streaming + transforms)."""
         import torch
-        mtr, ld = traces.shape[0], traces.stride(0) if traces.shape[0] > 1 else traces.shape[1]
+        mtr, ld = self._traces(traces)
         ls = torch.empty(self.N, dtype=torch.float32, device=traces.device) if ls is None else ls
         ts = torch.empty(self.N, dtype=torch.float32, device=traces.device) if ts is None else ts
-        check(self.lib.tspws_hip_stack(self.h, C.byref(self.params), traces.data_ptr(), ld, mtr, ls.data_ptr(), ts.data_ptr(), self._stream()),
-              "stack")
+        check(self.lib.tspws_hip_stack(self.h, C.byref(self.params), traces.data_ptr(), ld, mtr, self._out(ls, "ls"), self._out(ts, "ts"),
+                                       self._stream()), "stack")
         return ls, ts
 
     def close(self):

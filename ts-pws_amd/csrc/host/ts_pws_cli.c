@@ -285,7 +285,9 @@ int main(int argc, char *argv[])
 	memset(&out, 0, sizeof out);
 	const size_t max = (size_t)in.hdr.max;
 	out.N = (unsigned)max;
-	out.mtr = p.Nmax ? p.Nmax : in.hdr.mtr;
+	/* the reference takes Nmax unchecked (:65); tspws_main clamps it to the traces read, so every size derived from it
+	   (convergence dumps, the user0 header field) uses the clamped count too */
+	out.mtr = (p.Nmax && p.Nmax < in.hdr.mtr) ? p.Nmax : in.hdr.mtr;
 	out.ls = (float *)calloc(max, sizeof(float));
 	out.tsPWS = (float *)calloc(max, sizeof(float));
 	if (!out.ls || !out.tsPWS) { printf("main: Out of memory\n"); return 4; }
@@ -299,12 +301,12 @@ int main(int argc, char *argv[])
 		}
 	}
 	if (p.convergence) { /* :233-243 */
-		out.ls_sim = (double *)malloc(in.hdr.mtr * sizeof(double)); out.tsPWS_sim = (double *)malloc(in.hdr.mtr * sizeof(double));
-		out.ls_misfit = (double *)malloc(in.hdr.mtr * sizeof(double)); out.tsPWS_misfit = (double *)malloc(in.hdr.mtr * sizeof(double));
+		out.ls_sim = (double *)calloc(out.mtr, sizeof(double)); out.tsPWS_sim = (double *)calloc(out.mtr, sizeof(double));
+		out.ls_misfit = (double *)calloc(out.mtr, sizeof(double)); out.tsPWS_misfit = (double *)calloc(out.mtr, sizeof(double));
 		if (!out.ls_sim || !out.tsPWS_sim || !out.ls_misfit || !out.tsPWS_misfit) { printf("main: Out of memory\n"); return 4; }
 		if (p.AllSteps) {
-			out.ls_steps = (float *)malloc((size_t)in.hdr.mtr * max * sizeof(float));
-			out.tsPWS_steps = (float *)malloc((size_t)in.hdr.mtr * max * sizeof(float));
+			out.ls_steps = (float *)calloc((size_t)out.mtr * max, sizeof(float));
+			out.tsPWS_steps = (float *)calloc((size_t)out.mtr * max, sizeof(float));
 			if (!out.ls_steps || !out.tsPWS_steps) { printf("main: Out of memory\n"); return 4; }
 		}
 	}

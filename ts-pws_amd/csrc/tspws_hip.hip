@@ -124,19 +124,31 @@ struct tspws_hip_plan {
 	// optional timing of the streaming stage inside tspws_hip_stack (bench.py roofline leg)
 	std::vector<hipEvent_t> prof_ev;
 	size_t prof_used = 0;
-	// cached chunk table
+	// cached chunk table: the host copy is keyed on (mtr_local, first, mtr_global, K); the device copy becomes valid only
+	// once its upload has been enqueued (ck_dev), other streams order themselves behind it through ck_ev
 	std::vector<Chunk> chunks;
 	std::vector<unsigned> row_first; // per destination row: first chunk, rows+1 entries
 	size_t ck_mtr = 0, ck_first = 0, ck_glob = 0;
 	unsigned ck_K = 0;
-	bool ck_valid = false;
+	bool ck_valid = false, ck_dev = false;
+	hipEvent_t ck_ev = nullptr;
+	hipStream_t ck_stream = nullptr;
+	// blocks of exported slots (tspws_hip_reduce_buffer hands out SCR_P / SCR_STPS) that were outgrown: a caller may
+	// still hold the old pointer (e.g. as the buffer of an in-flight collective), so they live until plan_destroy
+	std::vector<void *> retired;
 };
 
 static int scratch(tspws_hip_plan *p, int slot, size_t bytes, void **out)
 {
 	if (p->scr_bytes[slot] < bytes) {
-		if (p->scr[slot]) { (void)hipFree(p->scr[slot]); p->scr[slot] = nullptr; p->scr_bytes[slot] = 0; }
-		HIP_TRY(hipMalloc(&p->scr[slot], bytes));
+		void *fresh = nullptr;
+		HIP_TRY(hipMalloc(&fresh, bytes));
+		if (p->scr[slot]) {
+			if (slot == SCR_P || slot == SCR_STPS) p->retired.push_back(p->scr[slot]); // exported: see `retired`
+			else (void)hipFree(p->scr[slot]);
+		}
+		if (slot == SCR_TAB) p->ck_dev = false; // the device chunk table lived in the old block
+		p->scr[slot] = fresh;
 		p->scr_bytes[slot] = bytes;
 	}
 	*out = p->scr[slot];
@@ -478,6 +490,8 @@ extern "C" void tspws_hip_plan_destroy(tspws_hip_plan *p)
 	if (!p) return;
 	(void)hipSetDevice(p->device);
 	for (int i = 0; i < SCR_N; i++) if (p->scr[i]) (void)hipFree(p->scr[i]);
+	for (void *b : p->retired) (void)hipFree(b);
+	if (p->ck_ev) (void)hipEventDestroy(p->ck_ev);
 	for (hipEvent_t e : p->ev_grp) (void)hipEventDestroy(e);
 	for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
 	if (p->ev_done) (void)hipEventDestroy(p->ev_done);
@@ -708,25 +722,49 @@ __global__ void __launch_bounds__(256) k_reduce_chunks(const double *__restrict_
 	P[(size_t)row * ldP + n] = acc;
 }
 
+// Device copy of a chunk table.  `cached` = the plan's own group table (build_group_chunks): uploaded once, valid only
+// after the copy has been enqueued, and a call on another stream waits for that copy through ck_ev.  Any other table
+// (masked replicas) is uploaded every time and invalidates the cached device copy, which shares the scratch block.
+static int chunk_tables(tspws_hip_plan *p, const std::vector<Chunk> &chunks, const std::vector<unsigned> &row_first, unsigned rows,
+                        hipStream_t st, bool cached, Chunk **d_chunks, unsigned **d_rf)
+{
+	const size_t nck = chunks.size();
+	const size_t tab_bytes = nck * sizeof(Chunk) + (rows + 1) * sizeof(unsigned);
+	void *d_tab = nullptr;
+	int rc;
+	if ((rc = scratch(p, SCR_TAB, std::max<size_t>(tab_bytes, 16), &d_tab))) return rc;
+	*d_chunks = (Chunk *)d_tab;
+	*d_rf = (unsigned *)((char *)d_tab + nck * sizeof(Chunk));
+	if (cached && p->ck_dev) {
+		if (st != p->ck_stream) HIP_TRY(hipStreamWaitEvent(st, p->ck_ev, 0));
+		return 0;
+	}
+	p->ck_dev = false;
+	if (nck) HIP_TRY(hipMemcpyAsync(*d_chunks, chunks.data(), nck * sizeof(Chunk), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(*d_rf, row_first.data(), (rows + 1) * sizeof(unsigned), hipMemcpyHostToDevice, st));
+	if (cached) {
+		if (!p->ck_ev) HIP_TRY(hipEventCreateWithFlags(&p->ck_ev, hipEventDisableTiming));
+		HIP_TRY(hipEventRecord(p->ck_ev, st));
+		p->ck_stream = st;
+		p->ck_dev = true; // only now: a failed upload must not leave a table that looks valid
+	}
+	return 0;
+}
+
 // Launch the streaming pass for an arbitrary chunk table (rows destinations).
 static int run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, const std::vector<Chunk> &chunks,
-                      const std::vector<unsigned> &row_first, unsigned rows, double *d_P, size_t ldP, hipStream_t st, bool upload,
+                      const std::vector<unsigned> &row_first, unsigned rows, double *d_P, size_t ldP, hipStream_t st, bool cached,
                       unsigned row_begin = 0, unsigned row_end = ~0u)
 {
 	row_end = std::min(row_end, rows);
 	const size_t nck = chunks.size();
 	const size_t ldpc = (N + 3) & ~(size_t)3;
-	void *d_tab = nullptr, *d_pc = nullptr;
-	const size_t tab_bytes = nck * sizeof(Chunk) + (rows + 1) * sizeof(unsigned);
+	void *d_pc = nullptr;
+	Chunk *d_chunks = nullptr;
+	unsigned *d_rf = nullptr;
 	int rc;
-	if ((rc = scratch(p, SCR_TAB, std::max<size_t>(tab_bytes, 16), &d_tab))) return rc;
 	if ((rc = scratch(p, SCR_CHUNK, std::max<size_t>(nck * ldpc * sizeof(double), 16), &d_pc))) return rc;
-	Chunk *d_chunks = (Chunk *)d_tab;
-	unsigned *d_rf = (unsigned *)((char *)d_tab + nck * sizeof(Chunk));
-	if (upload) {
-		if (nck) HIP_TRY(hipMemcpyAsync(d_chunks, chunks.data(), nck * sizeof(Chunk), hipMemcpyHostToDevice, st));
-		HIP_TRY(hipMemcpyAsync(d_rf, row_first.data(), (rows + 1) * sizeof(unsigned), hipMemcpyHostToDevice, st));
-	}
+	if ((rc = chunk_tables(p, chunks, row_first, rows, st, cached, &d_chunks, &d_rf))) return rc;
 	const unsigned bx = (unsigned)((N + 1023) / 1024);
 	const bool vec = (N % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x & 15) == 0);
 	const size_t ck0 = row_first[row_begin], ck1 = row_first[row_end]; // chunks are sorted by destination row
@@ -756,9 +794,10 @@ static unsigned chunk_len_for(size_t N, size_t mtr)
 
 // Chunk table of the two-stage streaming pass: every group's run of local traces is cut into equal pieces
 // (group of global trace i: floor(i*Kmax/mtr_global), ts_pws1f_lib.c:876).  Cached in the plan.
-static bool build_group_chunks(tspws_hip_plan *p, size_t mtr_local, size_t first, size_t mtr_global, unsigned Kmax)
+static void build_group_chunks(tspws_hip_plan *p, size_t mtr_local, size_t first, size_t mtr_global, unsigned Kmax)
 {
-	if (p->ck_valid && p->ck_mtr == mtr_local && p->ck_first == first && p->ck_glob == mtr_global && p->ck_K == Kmax) return false;
+	if (p->ck_valid && p->ck_mtr == mtr_local && p->ck_first == first && p->ck_glob == mtr_global && p->ck_K == Kmax) return;
+	p->ck_dev = false;
 	p->chunks.clear();
 	p->row_first.assign(Kmax + 1, 0);
 	unsigned clen = chunk_len_for(p->N, mtr_local);
@@ -784,26 +823,29 @@ static bool build_group_chunks(tspws_hip_plan *p, size_t mtr_local, size_t first
 	}
 	p->row_first[Kmax] = (unsigned)p->chunks.size();
 	p->ck_mtr = mtr_local; p->ck_first = first; p->ck_glob = mtr_global; p->ck_K = Kmax; p->ck_valid = true;
-	return true;
 }
 
 extern "C" int tspws_hip_partial_stacks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t mtr_local, size_t first,
                                         size_t mtr_global, unsigned Kmax, double *d_P, size_t ldP, void *stream)
 {
-	if (!p || !d_x || !d_P || !Kmax || !mtr_global) return fail(TSPWS_E_ARG, "partial_stacks: bad argument");
+	// an empty shard (mtr_local == 0, d_x may be NULL) is legal: its rows become zeros, so that every rank of a
+	// trace-sharded call reaches the collective
+	if (!p || (!d_x && mtr_local) || !d_P || !Kmax || !mtr_global || first + mtr_local > mtr_global)
+		return fail(TSPWS_E_ARG, "partial_stacks: bad argument");
 	HIP_TRY(hipSetDevice(p->device));
-	const bool upload = build_group_chunks(p, mtr_local, first, mtr_global, Kmax);
-	return run_chunks(p, d_x, ld, p->N, p->chunks, p->row_first, Kmax, d_P, ldP, S_(stream), upload);
+	build_group_chunks(p, mtr_local, first, mtr_global, Kmax);
+	return run_chunks(p, d_x, ld, p->N, p->chunks, p->row_first, Kmax, d_P, ldP, S_(stream), true);
 }
 
 extern "C" int tspws_hip_partial_stacks_range(tspws_hip_plan *p, const float *d_x, size_t ld, size_t mtr_local, size_t first,
                                               size_t mtr_global, unsigned Kmax, unsigned g_begin, unsigned g_end, double *d_P, size_t ldP,
                                               void *stream)
 {
-	if (!p || !d_x || !d_P || !Kmax || !mtr_global || g_begin > g_end || g_end > Kmax) return fail(TSPWS_E_ARG, "partial_stacks_range: bad argument");
+	if (!p || (!d_x && mtr_local) || !d_P || !Kmax || !mtr_global || g_begin > g_end || g_end > Kmax || first + mtr_local > mtr_global)
+		return fail(TSPWS_E_ARG, "partial_stacks_range: bad argument");
 	HIP_TRY(hipSetDevice(p->device));
-	const bool upload = build_group_chunks(p, mtr_local, first, mtr_global, Kmax);
-	return run_chunks(p, d_x, ld, p->N, p->chunks, p->row_first, Kmax, d_P, ldP, S_(stream), upload, g_begin, g_end);
+	build_group_chunks(p, mtr_local, first, mtr_global, Kmax);
+	return run_chunks(p, d_x, ld, p->N, p->chunks, p->row_first, Kmax, d_P, ldP, S_(stream), true, g_begin, g_end);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1494,14 +1536,13 @@ extern "C" int tspws_hip_stack(tspws_hip_plan *pl, const t_tsPWS *p, const float
 		pl->ev_grp.push_back(e);
 	}
 	hipStream_t Bq = pl->aux;
-	const bool upload = build_group_chunks(pl, mtr, 0, mtr, K);
+	build_group_chunks(pl, mtr, 0, mtr, K);
 	const size_t nck = pl->chunks.size(), ldpc = (N + 3) & ~(size_t)3;
 	void *v;
 	double *P; size_t nd;
 	if ((rc = tspws_hip_reduce_buffer(pl, p, mtr, &P, &nd))) return rc;
-	if ((rc = scratch(pl, SCR_TAB, nck * sizeof(Chunk) + (K + 1) * sizeof(unsigned), &v))) return rc;
-	Chunk *d_chunks = (Chunk *)v;
-	unsigned *d_rf = (unsigned *)((char *)v + nck * sizeof(Chunk));
+	Chunk *d_chunks = nullptr;
+	unsigned *d_rf = nullptr;
 	if ((rc = scratch(pl, SCR_CHUNK, nck * ldpc * sizeof(double), &v))) return rc;
 	double *d_pc = (double *)v;
 	if ((rc = scratch(pl, SCR_PART, (size_t)K * pl->npart * sizeof(double2), &v))) return rc;
@@ -1511,10 +1552,7 @@ extern "C" int tspws_hip_stack(tspws_hip_plan *pl, const t_tsPWS *p, const float
 	if ((rc = scratch(pl, SCR_X2, 2 * N * sizeof(double), &v))) return rc;
 	double *x2 = (double *)v;
 	if (pl->inv_noct && (rc = scratch(pl, SCR_OBUF, (size_t)(pl->inv_noct + (pl->inv_ngeneric ? 1 : 0)) * 2 * N * sizeof(double), &v))) return rc;
-	if (upload) {
-		HIP_TRY(hipMemcpyAsync(d_chunks, pl->chunks.data(), nck * sizeof(Chunk), hipMemcpyHostToDevice, A));
-		HIP_TRY(hipMemcpyAsync(d_rf, pl->row_first.data(), (K + 1) * sizeof(unsigned), hipMemcpyHostToDevice, A));
-	}
+	if ((rc = chunk_tables(pl, pl->chunks, pl->row_first, K, A, true, &d_chunks, &d_rf))) return rc;
 	// the aux stream must not start before earlier work on the caller's stream (e.g. a previous call's readers)
 	HIP_TRY(hipEventRecord(pl->ev_grp[K], A));
 	HIP_TRY(hipStreamWaitEvent(Bq, pl->ev_grp[K], 0));
@@ -1670,8 +1708,7 @@ static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d
 	void *v;
 	if ((rc = scratch(pl, SCR_CLS, (size_t)ncls * N * sizeof(double), &v))) return rc;
 	double *d_cls = (double *)v;
-	pl->ck_valid = false; // the shared table scratch is overwritten
-	if ((rc = run_chunks(pl, d_x, ld, N, chunks, row_first, ncls, d_cls, N, st, true))) return rc;
+	if ((rc = run_chunks(pl, d_x, ld, N, chunks, row_first, ncls, d_cls, N, st, false))) return rc; // own table: not the cached one
 	// CSR: (replica, group) -> classes
 	std::vector<unsigned> rp((size_t)C * KM + 1, 0), cols;
 	for (unsigned c = 0; c < C; c++)
