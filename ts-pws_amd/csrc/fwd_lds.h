@@ -50,6 +50,9 @@
 #ifndef FL_BATCH
 #define FL_BATCH 4                              /* tap steps per burst: LDS reads issued together, then straight-line FMAs */
 #endif
+#ifndef FL_PASSES_FINE
+#define FL_PASSES_FINE 1                        /* group slots per wave for D <= 4: the fused kernel keeps 8/D coefficients' stacks per lane and slot */
+#endif
 #define FL_NT (64 * FL_WAVES)                   /* threads per workgroup */
 #define FL_SLOTS (FL_WAVES * FL_PASSES)
 #if FL_QT % FL_R != 0
@@ -69,21 +72,28 @@
 #define FL_X_ALLOC (FL_MAX2(FL_MAX2(FL_XROWS * 64, FL_XSMALL * FL_XPAD), FL_WAVES * FL_SCR) + 64)
 #define FL_LDS_BYTES (FL_TAPS_BYTES + FL_X_ALLOC * 8)
 
-template <typename TIn, int LOGD>
+// FUSE: scales without phase splits (D <= 64) do not write per-trace coefficients at all: the workgroup owns its
+// coefficients for the whole trace slice, so it phase-normalises each one right after the lane reduction and keeps
+// ST += Y, PS += Y/|Y| (ts_pws1f_lib.c:489-492) in registers, in trace order; one store per coefficient and slice at
+// the end (accST / accPS are the slice's [ncoef] planes).  Split scales (D > 64) still write their partials.
+template <typename TIn, int LOGD, bool FUSE, int PASSES>
 __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const size_t ld, const unsigned ntr, const unsigned N, const ScaleDesc &d,
                                              const double2 *__restrict__ ws, double *__restrict__ pout0, const size_t npart,
-                                             const unsigned chunk, const unsigned bb, double2 *tL, double *xL)
+                                             const unsigned chunk, const unsigned bb, double2 *tL, double *xL,
+                                             double2 *__restrict__ accST, double2 *__restrict__ accPS)
 {
 	constexpr int R = FL_R;
 	constexpr bool SMALL = LOGD < 6;
 	constexpr int LG = SMALL ? LOGD : 0;
 	constexpr unsigned DC = 1u << (SMALL ? LOGD : 6);     // D when SMALL
 	constexpr unsigned GW = SMALL ? (64u >> LG) : 1u;     // groups per wave-slot
-	constexpr int NXV = SMALL ? FL_XSMALL : FL_XROWS / FL_WAVES; // x values staged per thread
+	constexpr int SLOTS = FL_WAVES * PASSES;               // group slots of this workgroup
+	constexpr int XROWS = SLOTS * FL_R + FL_QT;            // rows staged when D >= 64
+	constexpr int NXV = SMALL ? (SLOTS * 512 + 23 * 32 + FL_NT - 1) / FL_NT : XROWS / FL_WAVES; // x values staged per thread
 	const unsigned D = SMALL ? DC : d.D;
 	const unsigned tid = threadIdx.x, lane = tid & 63;
 	const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const unsigned g0 = bb * (unsigned)FL_SLOTS * GW;      // first output group of this workgroup
+	const unsigned g0 = bb * (unsigned)SLOTS * GW;      // first output group of this workgroup
 	const unsigned lane_m = SMALL ? (lane & (DC - 1)) : lane;
 	const unsigned lane_g = SMALL ? (lane >> LG) : 0;
 	const unsigned m0 = SMALL ? 0u : chunk * 64u;
@@ -93,7 +103,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 	const bool resident = ntile == 1;
 
 	// ---- trace-independent staging geometry -------------------------------------------------
-	// SMALL: contiguous window of NXV*256 samples starting at base(qa); LARGE: FL_XROWS rows of 64 lanes
+	// SMALL: contiguous window of NXV*256 samples starting at base(qa); LARGE: XROWS rows of 64 lanes
 	auto x_base = [&](unsigned qa) -> long long {
 		return SMALL ? ((long long)g0 * R + qa) * DC - d.c : ((long long)g0 * R + qa) * D + m0 - d.c;
 	};
@@ -115,7 +125,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 				}
 			}
 		} else {
-			const long long s_last = base + (long long)(FL_XROWS - 1) * D + 63;
+			const long long s_last = base + (long long)(XROWS - 1) * D + 63;
 			if (full && base >= 0 && s_last < (long long)N) { // fast path
 				const TIn *src = xt + (unsigned)(base + (long long)wv * D) + lane;
 				const unsigned stride = (unsigned)FL_WAVES * D;
@@ -177,11 +187,21 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 	double xv[NXV];
 	if (resident) load_x(xv, x0, 0);
 
+	constexpr int NACC = FUSE ? (SMALL ? (LOGD <= 3 ? (8 >> LOGD) : 1) : 1) : 1; // complex coefficients per lane and pass
+	const bool fuse = FUSE && d.nsplit == 1;
+	double2 fst[PASSES][NACC], fps[PASSES][NACC];
+	if (FUSE) {
+#pragma unroll
+		for (int p = 0; p < PASSES; p++)
+#pragma unroll
+			for (int i = 0; i < NACC; i++) { fst[p][i] = make_double2(0.0, 0.0); fps[p][i] = make_double2(0.0, 0.0); }
+	}
+
 	for (unsigned t = 0; t < ntr; t++) {
 		const TIn *xt = x0 + (size_t)t * ld;
-		double ar[FL_PASSES][R], ai[FL_PASSES][R];
+		double ar[PASSES][R], ai[PASSES][R];
 #pragma unroll
-		for (int p = 0; p < FL_PASSES; p++)
+		for (int p = 0; p < PASSES; p++)
 #pragma unroll
 			for (int r = 0; r < R; r++) { ar[p][r] = 0; ai[p][r] = 0; }
 
@@ -194,7 +214,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 			if (resident && t + 1 < ntr) load_x(xv, xt + ld, 0); // next trace's window flies while this one is computed
 			// ------------------------------------------------------------------ compute: two passes (group slots) per wave
 #pragma unroll
-			for (int p = 0; p < FL_PASSES; p++) {
+			for (int p = 0; p < PASSES; p++) {
 				const unsigned slot = (unsigned)p * (unsigned)FL_WAVES + wv;
 				const double *xb;  // one base per pass; every read below is base + compile-time offset
 				const double2 *tb;
@@ -240,11 +260,39 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 			}
 		}
 
-		// ------------------------------------------------------------------ combine the phase lanes, store the split partial
+		// ------------------------------------------------------------------ combine the phase lanes
+		if (FUSE && fuse) { // keep the running stacks in registers
+#pragma unroll
+			for (int p = 0; p < PASSES; p++) {
+				double v[2 * R];
+#pragma unroll
+				for (int r = 0; r < R; r++) { v[2 * r] = ar[p][r]; v[2 * r + 1] = ai[p][r]; }
+				if (SMALL) {
+					int n;
+					unsigned first;
+					valu_rs_cplx<LG>(v, lane, n, first);
+#pragma unroll
+					for (int i = 0; i < NACC; i++) {
+						const double2 y = make_double2(v[2 * i], -v[2 * i + 1]); // conj
+						fst[p][i].x += y.x; fst[p][i].y += y.y;
+						add_unit_phasor(fps[p][i], y);
+					}
+				} else {
+					double re, im;
+					unsigned first;
+					valu_reduce_cplx64(v, lane, re, im, first);
+					const double2 y = make_double2(re, -im);
+					fst[p][0].x += y.x; fst[p][0].y += y.y;
+					add_unit_phasor(fps[p][0], y);
+				}
+			}
+			continue;
+		}
+		// ------------------------------------------------------------------ store the split partial
 		double *pout = pout0 + (size_t)t * npart * 2;
 		if (SMALL) {
 #pragma unroll
-			for (int p = 0; p < FL_PASSES; p++) {
+			for (int p = 0; p < PASSES; p++) {
 				constexpr int NV = 2 * R;
 				double v[NV];
 #pragma unroll
@@ -269,7 +317,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 			// 64-lane reduction on the VALU (valu_reduce16: permlane swaps + DPP, no LDS traffic, no extra barrier):
 			// every lane ends with element o = 8*b5 + 4*b4 + 2*b3 + b2 of (re0, im0, re1, im1, ...); one lane per quad stores
 #pragma unroll
-			for (int p = 0; p < FL_PASSES; p++) {
+			for (int p = 0; p < PASSES; p++) {
 				double v[2 * R];
 #pragma unroll
 				for (int r = 0; r < R; r++) { v[2 * r] = ar[p][r]; v[2 * r + 1] = ai[p][r]; }
@@ -280,38 +328,69 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 			}
 		}
 	}
+	if (FUSE && fuse) { // one store per coefficient: the slice's linear and phase stacks
+		constexpr unsigned dup_mask = SMALL ? (LOGD == 5 ? 0x3u : LOGD == 4 ? 0x1u : 0u) : 0x7u; // butterfly bits: duplicates
+		// element offset of the lane's first value, as left by valu_rs_cplx / valu_reduce_cplx64 (a lane whose bit is set
+		// keeps the upper half at every reduce-scatter stage)
+		unsigned first = 0;
+		if (SMALL) {
+			if (LOGD >= 5) first += (lane & 16) ? 8u : 0u;
+			if (LOGD >= 4) first += (lane & 8) ? (LOGD == 5 ? 4u : 8u) : 0u;
+			if (LOGD >= 3) first += (lane & 4) ? (LOGD == 5 ? 2u : LOGD == 4 ? 4u : 8u) : 0u;
+			if (LOGD >= 2 && LOGD <= 4) first += (lane & 2) ? (LOGD == 4 ? 2u : LOGD == 3 ? 4u : 8u) : 0u;
+			if (LOGD >= 1 && LOGD <= 3) first += (lane & 1) ? (LOGD == 3 ? 2u : LOGD == 2 ? 4u : 8u) : 0u;
+		} else first = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2;
+		if (!(lane & dup_mask)) {
+#pragma unroll
+			for (int p = 0; p < PASSES; p++) {
+				const unsigned g = SMALL ? g0 + ((unsigned)p * (unsigned)FL_WAVES + wv) * GW + lane_g : g0 + (unsigned)p * (unsigned)FL_WAVES + wv;
+#pragma unroll
+				for (int i = 0; i < NACC; i++) {
+					const unsigned k = g * R + (first >> 1) + (unsigned)i;
+					if (k < d.Ns) { accST[d.coef_off + k] = fst[p][i]; accPS[d.coef_off + k] = fps[p][i]; }
+				}
+			}
+		}
+	}
 }
 
 // grid = (workgroups of all LDS scales, trace slices); a workgroup handles traces [slice*tps, min(ntr, (slice+1)*tps))
-template <typename TIn>
-__global__ void __launch_bounds__(FL_NT) k_fwd_lds(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
+// FUSE: accST / accPS + slice * acc_stride are the [ncoef] planes that receive the slice's stacks of the unsplit scales.
+template <typename TIn, bool FUSE>
+__global__ void __launch_bounds__(FL_NT, 2) k_fwd_lds(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
                                                  const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
-                                                 double2 *__restrict__ part, size_t npart)
+                                                 double2 *__restrict__ part, size_t npart, double2 *__restrict__ accST,
+                                                 double2 *__restrict__ accPS, size_t acc_stride, unsigned rev)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	double2 *tL = (double2 *)smem;
 	double *xL = (double *)(smem + FL_TAPS_BYTES);
-	// scale of this workgroup: last s with lds_off[s] <= blockIdx.x among the scales that use this kernel
+	// Workgroups are dispatched in blockIdx order and a launch is a few rounds of ~46 us workgroups, so the LAST round sets
+	// the tail: walk the scales from coarse to fine -- the fine scales (D <= 4: one slot per wave, half the work) finish
+	// the launch with short workgroups.
+	const unsigned bid = rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+	// scale of this workgroup: last s with lds_off[s] <= bid among the scales that use this kernel
 	unsigned lo = 0, hi = S;
 	while (hi - lo > 1) {
 		const unsigned mid = (lo + hi) >> 1;
-		if (sc[mid].lds_off <= blockIdx.x) lo = mid; else hi = mid;
+		if (sc[mid].lds_off <= bid) lo = mid; else hi = mid;
 	}
 	const ScaleDesc d = sc[lo];
-	const unsigned wl = blockIdx.x - d.lds_off;
+	const unsigned wl = bid - d.lds_off;
 	const unsigned chunk = wl / d.lds_bps, bb = wl - chunk * d.lds_bps; // one 64-phase chunk per workgroup (split == chunk)
 	const unsigned t0 = blockIdx.y * tps;
 	const unsigned nt = (ntr - t0) < tps ? (ntr - t0) : tps;
 	const TIn *x0 = x + (size_t)t0 * ld;
 	const double2 *ws = w + d.tap_off;
 	double *pout0 = (double *)(part + (size_t)t0 * npart + d.part_off + (size_t)chunk * d.Ns);
-	if (d.D >= 64) { fwd_lds_body<TIn, 6>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL); return; }
+	double2 *aS = FUSE ? accST + (size_t)blockIdx.y * acc_stride : nullptr, *aP = FUSE ? accPS + (size_t)blockIdx.y * acc_stride : nullptr;
+	if (d.D >= 64) { fwd_lds_body<TIn, 6, FUSE, FL_PASSES>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); return; }
 	switch (d.logDL) {
-	case 0: fwd_lds_body<TIn, 0>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL); break;
-	case 1: fwd_lds_body<TIn, 1>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL); break;
-	case 2: fwd_lds_body<TIn, 2>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL); break;
-	case 3: fwd_lds_body<TIn, 3>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL); break;
-	case 4: fwd_lds_body<TIn, 4>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL); break;
-	default: fwd_lds_body<TIn, 5>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL); break;
+	case 0: fwd_lds_body<TIn, 0, false, FL_PASSES_FINE>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break; // D = 1: 8 coefficients per lane and pass would not fit in registers -> stays on the partial path (fuse_ok = 0)
+	case 1: fwd_lds_body<TIn, 1, FUSE, FL_PASSES_FINE>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
+	case 2: fwd_lds_body<TIn, 2, FUSE, FL_PASSES_FINE>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
+	case 3: fwd_lds_body<TIn, 3, FUSE, FL_PASSES>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
+	case 4: fwd_lds_body<TIn, 4, FUSE, FL_PASSES>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
+	default: fwd_lds_body<TIn, 5, FUSE, FL_PASSES>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
 	}
 }

@@ -171,6 +171,62 @@ __device__ __forceinline__ void valu_rs16(double (&v)[16], const unsigned lane, 
 	}
 }
 
+// ---- reductions that keep (re, im) pairs together ------------------------------------------------------------------
+// The fused forward + phase-stack kernel normalises every coefficient right after the phase reduction, so a lane must end
+// with BOTH components of its coefficients.  Same exchanges as valu_rs16 / valu_reduce16, but the reduce-scatter stops at
+// one complex value (two doubles) and the remaining lane bits are plain butterflies on both components.
+// On return the lane holds n >= 2 finished sums = elements first .. first+n-1 (first even) of (re0, im0, re1, im1, ...);
+// lanes that differ only in the butterfly bits hold duplicates.
+template <int LOGD>
+__device__ __forceinline__ void valu_rs_cplx(double (&v)[16], const unsigned lane, int &n, unsigned &first)
+{
+	static_assert(LOGD >= 0 && LOGD <= 5, "group of at most 32 phase lanes");
+	if constexpr (LOGD <= 3) { valu_rs16<LOGD>(v, lane, n, first); return; }
+	n = 16; first = 0;
+	if constexpr (LOGD == 5) { // bit 4: 16-lane rows
+#pragma unroll
+		for (int i = 0; i < 8; i++) v[i] = swap_add_f64<true>(v[i], v[i + 8]);
+		n = 8; if (lane & 16) first += 8;
+		dpp_rs_stage<8, 0>(v, (lane & 8) != 0); n = 4; if (lane & 8) first += 4;  // bit 3
+		dpp_rs_stage<4, 1>(v, (lane & 4) != 0); n = 2; if (lane & 4) first += 2;  // bit 2 (mirror pairing)
+		// bits 1, 0 (and the mirror's flip of them): butterflies -- after both every lane of the quad holds the sum
+		v[0] += dpp_mov_f64(v[0], 2); v[1] += dpp_mov_f64(v[1], 2);
+		v[0] += dpp_mov_f64(v[0], 3); v[1] += dpp_mov_f64(v[1], 3);
+	} else {                   // LOGD == 4
+		dpp_rs_stage<16, 0>(v, (lane & 8) != 0); n = 8; if (lane & 8) first += 8; // bit 3
+		dpp_rs_stage<8, 1>(v, (lane & 4) != 0); n = 4; if (lane & 4) first += 4;  // bit 2
+		dpp_rs_stage<4, 2>(v, (lane & 2) != 0); n = 2; if (lane & 2) first += 2;  // bit 1
+		v[0] += dpp_mov_f64(v[0], 3); v[1] += dpp_mov_f64(v[1], 3);               // bit 0
+	}
+}
+
+// 64 phase lanes: every lane ends with the complex element  first/2 = 4*b5 + 2*b4 + b3  in (re, im); the eight lanes of a
+// half row hold the same pair.
+__device__ __forceinline__ void valu_reduce_cplx64(const double (&v)[16], const unsigned lane, double &re, double &im, unsigned &first)
+{
+	double s8[8], s4[4];
+#pragma unroll
+	for (int i = 0; i < 8; i++) s8[i] = swap_add_f64<false>(v[i], v[i + 8]);   // lane bit 5
+#pragma unroll
+	for (int i = 0; i < 4; i++) s4[i] = swap_add_f64<true>(s8[i], s8[i + 4]);  // lane bit 4
+	const bool up3 = (lane & 8) != 0;
+	double s2[2];
+#pragma unroll
+	for (int i = 0; i < 2; i++) {                                              // lane bit 3
+		const double send = up3 ? s4[i] : s4[i + 2], keep = up3 ? s4[i + 2] : s4[i];
+		s2[i] = keep + dpp_mov_f64(send, 0);
+	}
+	// bits 2, 1, 0: mirror + two quad butterflies = the sum over the eight lanes of the half row
+#pragma unroll
+	for (int i = 0; i < 2; i++) {
+		s2[i] += dpp_mov_f64(s2[i], 1);
+		s2[i] += dpp_mov_f64(s2[i], 2);
+		s2[i] += dpp_mov_f64(s2[i], 3);
+	}
+	re = s2[0]; im = s2[1];
+	first = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2;
+}
+
 template <typename TIn, int B>
 __global__ void __launch_bounds__(256) k_fwd_poly(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned N,
                                                   const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
@@ -343,7 +399,8 @@ __global__ void __launch_bounds__(256) k_gather_parts(const double2 *__restrict_
 	Y[(size_t)blockIdx.y * ncoef + i] = a;
 }
 
-// ST += sum_b Y_b ; PS += sum_b Y_b/|Y_b|  straight from the split partials (ts_pws1f_lib.c:489-492).
+// ST += sum_b Y_b ; PS += sum_b Y_b/|Y_b|  straight from the split partials (ts_pws1f_lib.c:489-492); scales the fused
+// forward kernel stacked itself (fuse_ok) are skipped or combined from its slice planes.
 // One block works on ONE scale (acc2_off[s] = its first block), so the scale lookup and descriptor reads are
 // wave-uniform scalar work.  Scales without splits: 256 coefficients per block, one thread each.  Split scales (coarse
 // scales: few coefficients, up to 32 partials each): 32 coefficients per block, 8 lanes per coefficient share the
@@ -351,7 +408,8 @@ __global__ void __launch_bounds__(256) k_gather_parts(const double2 *__restrict_
 // latency loads and set the kernel's duration.
 __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restrict__ part, size_t npart, const ScaleDesc *__restrict__ sc,
                                                           unsigned S, unsigned ntr, double2 *__restrict__ ST, double2 *__restrict__ PS,
-                                                          int zero_first)
+                                                          int zero_first, int fused, const double2 *__restrict__ fzST,
+                                                          const double2 *__restrict__ fzPS, size_t fz_stride, unsigned nslices)
 {
 	unsigned lo = 0, hi = S;
 	while (hi - lo > 1) {
@@ -359,6 +417,22 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 		if (sc[mid].acc2_off <= blockIdx.x) lo = mid; else hi = mid;
 	}
 	const unsigned Ns = sc[lo].Ns, nsplit = sc[lo].nsplit;
+	if (fused && sc[lo].fuse_ok) {
+		// the forward kernel already stacked this scale: fused == 1, straight into ST / PS (nothing left to do);
+		// fused == 2, one plane pair per trace slice, added here in slice order
+		if (fused == 1) return;
+		const unsigned k = (blockIdx.x - sc[lo].acc2_off) * 256u + threadIdx.x;
+		if (k >= Ns) return;
+		const size_t i = sc[lo].coef_off + k;
+		double2 st = make_double2(0, 0), ps = make_double2(0, 0);
+		if (!zero_first) { st = ST[i]; ps = PS[i]; }
+		for (unsigned j = 0; j < nslices; j++) {
+			const double2 a = fzST[(size_t)j * fz_stride + i], b = fzPS[(size_t)j * fz_stride + i];
+			st.x += a.x; st.y += a.y; ps.x += b.x; ps.y += b.y;
+		}
+		ST[i] = st; PS[i] = ps;
+		return;
+	}
 	const bool wide = nsplit > 1;
 	const unsigned sub = wide ? (threadIdx.x & 7) : 0, stride = wide ? 8u : 1u;
 	const unsigned k = (blockIdx.x - sc[lo].acc2_off) * (wide ? 32u : 256u) + (wide ? threadIdx.x >> 3 : threadIdx.x);

@@ -66,7 +66,7 @@ struct ScaleDesc {
 	unsigned use_lds;           // 1: forward transform by k_fwd_lds (fwd_lds.h), 0: k_fwd_poly
 	unsigned lds_off, lds_bps;  // first workgroup of this scale in k_fwd_lds, workgroups per split
 	unsigned acc2_off;          // first block of this scale in k_accumulate_parts (32 coefficients per block when split)
-	unsigned pad1;
+	unsigned fuse_ok;           // 1: k_fwd_lds<FUSE> keeps this scale's linear / phase stacks in registers (no partials)
 	unsigned long long part_off; // offset of this scale's [nsplit][Ns] partial block
 };
 
@@ -82,6 +82,9 @@ struct OctDesc;
 #define FL_WAVES 4
 #endif
 #define FL_PASSES_HOST FL_PASSES
+#ifndef FL_PASSES_FINE
+#define FL_PASSES_FINE 1
+#endif
 
 struct Chunk { // one streaming work item of the partial-stack kernel
 	unsigned long long t0; // first local trace
@@ -89,7 +92,7 @@ struct Chunk { // one streaming work item of the partial-stack kernel
 	unsigned row;          // destination row (group / class)
 };
 
-enum { SCR_Y = 0, SCR_PART, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_N };
+enum { SCR_Y = 0, SCR_PART, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_N };
 
 struct tspws_hip_plan {
 	int device = 0, type = -1;
@@ -101,6 +104,7 @@ struct tspws_hip_plan {
 	unsigned acc_blocks = 0;   // blocks of k_accumulate_masked (256 coefficients each)
 	unsigned acc2_blocks = 0;  // blocks of k_accumulate_parts
 	unsigned lds_blocks = 0;   // workgroups per trace slice of k_fwd_lds
+	unsigned n_fusable = 0;    // scales whose stacks the fused forward kernel keeps in registers
 	int fwd_kind = 1;          // 0: k_fwd_poly only, 1: k_fwd_lds (+poly), 3: k_fwd_mfma (opt-in)
 	std::vector<FwdGroup> pairs; // fwd_kind 3: work groups, their B tables and work items
 	FwdGroup *d_pairs = nullptr;
@@ -121,6 +125,10 @@ struct tspws_hip_plan {
 	hipStream_t aux = nullptr;
 	std::vector<hipEvent_t> ev_grp;
 	hipEvent_t ev_done = nullptr;
+	// forward transform: the direct kernel (coarse scales, latency-bound) runs beside the LDS kernel (FP64-bound) on a
+	// side stream, forked from and joined back into the caller's stream
+	hipStream_t side = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	// optional timing of the streaming stage inside tspws_hip_stack (bench.py roofline leg)
 	std::vector<hipEvent_t> prof_ev;
 	size_t prof_used = 0;
@@ -447,13 +455,18 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 			d.cps = std::min(cps, d.MC);
 			d.nsplit = (d.MC + d.cps - 1) / d.cps;
 			d.wave_off = woff; d.lds_off = boff; d.part_off = poff;
-			d.lds_bps = (NG + FL_SLOTS_HOST * GW - 1) / (FL_SLOTS_HOST * GW);
+			const unsigned slots = (d.D <= 4) ? FL_WAVES * FL_PASSES_FINE : FL_SLOTS_HOST; // as dispatched in k_fwd_lds
+			d.lds_bps = (NG + slots * GW - 1) / (slots * GW);
 			if (d.use_lds) boff += d.lds_bps * d.nsplit; else woff += d.ngw * d.nsplit;
 			poff += (unsigned long long)d.nsplit * d.Ns;
-			d.pad1 = 0;
+			d.fuse_ok = (kind == 1 && d.use_lds && d.nsplit == 1 && d.D >= 2) ? 1u : 0u;
 		}
 		p->fwd_waves = woff; p->lds_blocks = boff; p->npart = poff;
-		if (kind == 3 && !build_mfma_pairs(p)) { p->fwd_kind = 1; p->pairs.clear(); } // a filter too long for the matrix kernel: VALU kernels
+		for (unsigned s = 0; s < S; s++) p->n_fusable += p->sc[s].fuse_ok;
+		if (kind == 3 && !build_mfma_pairs(p)) { // a filter too long for the matrix kernel: VALU kernels
+			p->fwd_kind = 1; p->pairs.clear();
+			for (unsigned s = 0; s < S; s++) { p->sc[s].fuse_ok = (p->sc[s].use_lds && p->sc[s].nsplit == 1 && p->sc[s].D >= 2) ? 1u : 0u; p->n_fusable += p->sc[s].fuse_ok; }
+		}
 	}
 	for (unsigned s = 0; s < S; s++) {
 		p->sc[s].inv_fast = (N % p->sc[s].D == 0) ? 1u : 0u;
@@ -495,6 +508,9 @@ extern "C" void tspws_hip_plan_destroy(tspws_hip_plan *p)
 	for (hipEvent_t e : p->ev_grp) (void)hipEventDestroy(e);
 	for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
 	if (p->ev_done) (void)hipEventDestroy(p->ev_done);
+	if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+	if (p->side) (void)hipStreamDestroy(p->side);
 	if (p->aux) (void)hipStreamDestroy(p->aux);
 	if (p->d_oc) (void)hipFree(p->d_oc);
 	if (p->d_pairs) (void)hipFree(p->d_pairs);
@@ -921,6 +937,29 @@ static int forward_generic(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t
 	return 0;
 }
 
+// Output of the fused forward + phase-stack kernel: slice j of the launch (traces [j*tps, (j+1)*tps)) leaves the linear and
+// phase stacks of every fuse_ok scale in accST / accPS + j*stride ([ncoef] planes).
+struct FuseOut {
+	double2 *accST = nullptr, *accPS = nullptr;
+	size_t stride = 0;
+	unsigned tps = 1;
+	bool applied = false; // set by forward_parts when the fused kernel ran
+};
+
+static bool side_stream_enabled()
+{
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("TSPWS_SIDE_STREAM"); v = (e && *e == '0') ? 0 : 1; }
+	return v == 1;
+}
+
+static bool fuse_enabled()
+{
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("TSPWS_FUSE"); v = (e && *e == '0') ? 0 : 1; }
+	return v == 1;
+}
+
 #include "fwd_poly.h"
 #include "fwd_lds.h"
 #include "fwd_mfma.h"
@@ -952,8 +991,9 @@ static int upload_mfma_tables(tspws_hip_plan *p)
 }
 
 template <typename TIn>
-static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double2 *d_part, hipStream_t st)
+static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double2 *d_part, hipStream_t st, FuseOut *fz = nullptr)
 {
+	if (fz) fz->applied = false;
 	if (p->fwd_kind == 3) {
 		size_t per_launch = 1u << 20; // keeps the unit counters in 32 bits
 		for (const FwdGroup &d : p->pairs) per_launch = std::min<size_t>(per_launch, std::max<size_t>(1, 0x7fffffffu / std::max(1u, d.nob)));
@@ -1000,30 +1040,57 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 		HIP_TRY(hipGetLastError());
 		return 0;
 	}
-	if (p->lds_blocks) {
-		// traces per workgroup: enough slices to fill the GPU (>= ~2048 workgroups), at most 32 traces per slice
-		unsigned tps = (unsigned)std::min<size_t>(ntr, 32);
-		while (tps > 1 && (size_t)p->lds_blocks * ((ntr + tps - 1) / tps) < 2048) tps = (tps + 1) / 2;
-		if (const char *e = getenv("TSPWS_FWD_TPS")) tps = (unsigned)std::max(1, atoi(e));
-		const size_t per_launch = (size_t)tps * 65535;
-		for (size_t t0 = 0; t0 < ntr; t0 += per_launch) {
-			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, per_launch);
-			hipLaunchKernelGGL((k_fwd_lds<TIn>), dim3(p->lds_blocks, (nt + tps - 1) / tps), dim3(FL_NT), FL_LDS_BYTES, st, d_x + t0 * ld, ld, nt, tps,
-			                   p->N, p->d_sc, p->S, p->d_w, d_part + t0 * p->npart, p->npart);
-		}
+	const bool both = p->lds_blocks && p->fwd_waves && side_stream_enabled();
+	hipStream_t sp = st; // stream of the direct kernel
+	if (both) {
+		if (!p->side) HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+		if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+		if (!p->ev_join) HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+		HIP_TRY(hipEventRecord(p->ev_fork, st));
+		HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+		sp = p->side;
 	}
+	// the direct kernel first: its few hundred long, latency-bound workgroups (no LDS, 88 VGPRs) get their slots and the
+	// LDS kernel's workgroups fill in beside them
 	if (p->fwd_waves) {
 		const unsigned nb = (p->fwd_waves + 3) / 4;
 		if (ntr == 1) {
-			hipLaunchKernelGGL((k_fwd_poly<TIn, 1>), dim3(nb, 1), dim3(256), 0, st, d_x, ld, 1u, p->N, p->d_sc, p->S, p->d_w, d_part,
+			hipLaunchKernelGGL((k_fwd_poly<TIn, 1>), dim3(nb, 1), dim3(256), 0, sp, d_x, ld, 1u, p->N, p->d_sc, p->S, p->d_w, d_part,
 			                   p->npart, p->fwd_waves);
 		} else {
 			for (size_t t0 = 0; t0 < ntr; t0 += 2 * 32768) {
 				const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, 2 * 32768);
-				hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nb, (nt + 1) / 2), dim3(256), 0, st, d_x + t0 * ld, ld, nt, p->N, p->d_sc,
+				hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nb, (nt + 1) / 2), dim3(256), 0, sp, d_x + t0 * ld, ld, nt, p->N, p->d_sc,
 				                   p->S, p->d_w, d_part + t0 * p->npart, p->npart, p->fwd_waves);
 			}
 		}
+	}
+	if (p->lds_blocks) {
+		const bool fuse = fz && fz->accST && p->n_fusable;
+		// traces per workgroup: enough slices to fill the GPU (>= ~2048 workgroups), at most 32 traces per slice
+		unsigned tps = (unsigned)std::min<size_t>(ntr, 32);
+		while (tps > 1 && (size_t)p->lds_blocks * ((ntr + tps - 1) / tps) < 2048) tps = (tps + 1) / 2;
+		if (const char *e = getenv("TSPWS_FWD_TPS")) tps = (unsigned)std::max(1, atoi(e));
+		if (fuse) tps = fz->tps; // the caller sized the slice planes
+		static int rev_env = -1;
+		if (rev_env < 0) { const char *e = getenv("TSPWS_FWD_REV"); rev_env = (e && *e == '0') ? 0 : 1; }
+		const unsigned rev = (unsigned)rev_env;
+		const size_t per_launch = (size_t)tps * 65535;
+		for (size_t t0 = 0; t0 < ntr; t0 += per_launch) {
+			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, per_launch);
+			if (fuse)
+				hipLaunchKernelGGL((k_fwd_lds<TIn, true>), dim3(p->lds_blocks, (nt + tps - 1) / tps), dim3(FL_NT), FL_LDS_BYTES, st, d_x + t0 * ld, ld,
+				                   nt, tps, p->N, p->d_sc, p->S, p->d_w, d_part + t0 * p->npart, p->npart, fz->accST + (t0 / tps) * fz->stride,
+				                   fz->accPS + (t0 / tps) * fz->stride, fz->stride, rev);
+			else
+				hipLaunchKernelGGL((k_fwd_lds<TIn, false>), dim3(p->lds_blocks, (nt + tps - 1) / tps), dim3(FL_NT), FL_LDS_BYTES, st, d_x + t0 * ld, ld,
+				                   nt, tps, p->N, p->d_sc, p->S, p->d_w, d_part + t0 * p->npart, p->npart, (double2 *)nullptr, (double2 *)nullptr, (size_t)0, rev);
+		}
+		if (fuse) fz->applied = true;
+	}
+	if (both) {
+		HIP_TRY(hipEventRecord(p->ev_join, p->side));
+		HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
@@ -1106,6 +1173,27 @@ extern "C" int tspws_hip_accumulate(tspws_hip_plan *p, const double *d_Y, size_t
 	return 0;
 }
 
+// launches k_accumulate_parts for `nb` transformed traces; fz = what forward_parts left behind (may be NULL / not applied)
+static void launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb, double2 *ST, double2 *PS, int zero_first, const FuseOut *fz,
+                              unsigned nslices, hipStream_t st)
+{
+	const bool on = fz && fz->applied;
+	const bool direct = on && fz->accST == ST; // the single slice went straight into ST / PS
+	hipLaunchKernelGGL(k_accumulate_parts, dim3(p->acc2_blocks), dim3(256), 0, st, part, p->npart, p->d_sc, p->S, nb, ST, PS, zero_first,
+	                   on ? (direct ? 1 : 2) : 0, on ? (const double2 *)fz->accST : nullptr, on ? (const double2 *)fz->accPS : nullptr,
+	                   on ? fz->stride : (size_t)0, nslices);
+}
+
+// slice length of the fused forward kernel for a batch of nb traces: whole batch when it is small (two-stage: the K
+// partial stacks -> ONE slice that writes ST / PS directly), else 32 traces per slice
+static unsigned fuse_tps(size_t nb)
+{
+	static int forced = -1;
+	if (forced < 0) { const char *e = getenv("TSPWS_FUSE_TPS"); forced = e ? std::max(1, atoi(e)) : 0; }
+	if (forced) return (unsigned)std::min<size_t>(nb, (size_t)forced);
+	return (unsigned)std::min<size_t>(nb, 32);
+}
+
 template <typename TIn>
 static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, void *s, bool keep = false)
 { // keep: add to the stacks already in d_ST / d_PS instead of starting from zero
@@ -1129,11 +1217,26 @@ static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld,
 	const size_t batch = std::min<size_t>(ntr, std::max<size_t>(2, ((part_budget_bytes()) / (p->npart * sizeof(double2))) & ~(size_t)1));
 	void *v;
 	if ((rc = scratch(p, SCR_PART, batch * p->npart * sizeof(double2), &v))) return rc;
+	const bool fuse = fuse_enabled() && p->fwd_kind == 1 && p->n_fusable;
+	void *vz = nullptr;
+	if (fuse) { // slice planes of the largest batch (unused when the only slice writes ST / PS directly)
+		const unsigned tps = fuse_tps(batch);
+		const size_t nsl = (batch + tps - 1) / tps;
+		if (!(nsl == 1 && !keep && batch >= ntr) && (rc = scratch(p, SCR_FZ, nsl * 2 * p->ncoef * sizeof(double2), &vz))) return rc;
+	}
 	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
 		const size_t nb = std::min(batch, ntr - t0);
-		if ((rc = forward_parts<TIn>(p, d_x + t0 * ld, nb, ld, (double2 *)v, st))) return rc;
-		hipLaunchKernelGGL(k_accumulate_parts, dim3(p->acc2_blocks), dim3(256), 0, st, (const double2 *)v, p->npart, p->d_sc, p->S,
-		                   (unsigned)nb, (double2 *)d_ST, (double2 *)d_PS, (t0 == 0 && !keep) ? 1 : 0);
+		const int zero_first = (t0 == 0 && !keep) ? 1 : 0;
+		FuseOut fz;
+		unsigned nsl = 0;
+		if (fuse) {
+			fz.tps = fuse_tps(nb);
+			nsl = (unsigned)((nb + fz.tps - 1) / fz.tps);
+			if (nsl == 1 && zero_first) { fz.accST = (double2 *)d_ST; fz.accPS = (double2 *)d_PS; fz.stride = 0; }
+			else { fz.accST = (double2 *)vz; fz.accPS = (double2 *)vz + p->ncoef; fz.stride = 2 * p->ncoef; }
+		}
+		if ((rc = forward_parts<TIn>(p, d_x + t0 * ld, nb, ld, (double2 *)v, st, fuse ? &fz : nullptr))) return rc;
+		launch_accumulate(p, (const double2 *)v, (unsigned)nb, (double2 *)d_ST, (double2 *)d_PS, zero_first, &fz, nsl, st);
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
@@ -1577,8 +1680,7 @@ extern "C" int tspws_hip_stack(tspws_hip_plan *pl, const t_tsPWS *p, const float
 			HIP_TRY(hipEventRecord(pl->ev_grp[g], A));
 			HIP_TRY(hipStreamWaitEvent(Bq, pl->ev_grp[g], 0));
 			if ((rc = forward_parts<double>(pl, P + (size_t)gb * N, nb, N, part + (size_t)gb * pl->npart, Bq))) return rc;
-			hipLaunchKernelGGL(k_accumulate_parts, dim3(pl->acc2_blocks), dim3(256), 0, Bq, (const double2 *)(part + (size_t)gb * pl->npart),
-			                   pl->npart, pl->d_sc, pl->S, nb, (double2 *)ST, (double2 *)PS, gb == 0 ? 1 : 0);
+			launch_accumulate(pl, (const double2 *)(part + (size_t)gb * pl->npart), nb, (double2 *)ST, (double2 *)PS, gb == 0 ? 1 : 0, nullptr, 0, Bq);
 		}
 	}
 	if (prof) { HIP_TRY(hipEventRecord(pl->prof_ev[pl->prof_used + 1], A)); pl->prof_used += 2; }
@@ -1736,16 +1838,23 @@ static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d
 	if (RB > 1) RB &= ~1u; // pairs for the two-set inverse
 	if ((rc = scratch(pl, SCR_PART, (size_t)RB * KM * pl->npart * sizeof(double2), &v))) return rc;
 	double2 *part = (double2 *)v;
-	if ((rc = scratch(pl, SCR_JKOUT, ((size_t)RB * 2 * nc + 4 * nc + (size_t)RB * N) * sizeof(double), &v))) return rc;
-	double *OUT = (double *)v, *ST = OUT + (size_t)RB * 2 * nc, *PS = ST + 2 * nc, *xr = PS + 2 * nc;
+	// per replica of the batch: OUT (2 nc doubles) | ST | PS, then the reconstructions
+	if ((rc = scratch(pl, SCR_JKOUT, ((size_t)RB * 6 * nc + (size_t)RB * N) * sizeof(double), &v))) return rc;
+	double *OUT = (double *)v, *STr = OUT + (size_t)RB * 2 * nc, *xr = STr + (size_t)RB * 4 * nc;
+	const bool fuse = fuse_enabled() && pl->fwd_kind == 1 && pl->n_fusable;
 	for (unsigned c0 = 0; c0 < C; c0 += RB) {
 		const unsigned nr = std::min(RB, C - c0);
-		if ((rc = forward_parts<double>(pl, d_P + (size_t)c0 * KM * N, (size_t)nr * KM, N, part, st))) return rc;
+		// one slice of the fused forward kernel = the KM partial stacks of one replica: its stacks land in the replica's planes
+		FuseOut fz;
+		fz.accST = (double2 *)STr; fz.accPS = (double2 *)STr + nc; fz.stride = 2 * nc; fz.tps = KM;
+		if ((rc = forward_parts<double>(pl, d_P + (size_t)c0 * KM * N, (size_t)nr * KM, N, part, st, fuse ? &fz : nullptr))) return rc;
 		for (unsigned j = 0; j < nr; j++) {
 			const unsigned c = c0 + j;
 			h_mtr_out[c] = (unsigned)Kc[c];
-			hipLaunchKernelGGL(k_accumulate_parts, dim3(pl->acc2_blocks), dim3(256), 0, st, (const double2 *)(part + (size_t)j * KM * pl->npart),
-			                   pl->npart, pl->d_sc, pl->S, KM, (double2 *)ST, (double2 *)PS, 1);
+			double *ST = STr + (size_t)j * 4 * nc, *PS = ST + 2 * nc;
+			FuseOut fj = fz; // this replica's slice, written directly
+			fj.accST = (double2 *)ST; fj.accPS = (double2 *)PS;
+			launch_accumulate(pl, (const double2 *)(part + (size_t)j * KM * pl->npart), KM, (double2 *)ST, (double2 *)PS, 1, &fj, 1, st);
 			if ((rc = tspws_hip_weight(pl, OUT + (size_t)j * 2 * nc, ST, PS, KM, (unsigned)Kc[c], p->wu, p->unbiased, s))) return rc;
 			hipLaunchKernelGGL(k_jk_linear, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_P + (size_t)c * KM * N, KM, N, 1. / (double)Kc[c],
 			                   d_ls_out + (size_t)c * N);
@@ -1964,8 +2073,7 @@ extern "C" int tspws_hip_convergence(tspws_hip_plan *pl, const t_tsPWS *p, const
 		if (!p->Kmax || p->Kmax >= Tr) { // incremental single-stage step (tspws_stacks_float_1step, :835-863)
 			K = (unsigned)Tr;
 			if ((rc = forward_parts<float>(pl, d_x + i * ld, 1, ld, part, st))) return rc;
-			hipLaunchKernelGGL(k_accumulate_parts, dim3(pl->acc2_blocks), dim3(256), 0, st, (const double2 *)part, pl->npart, pl->d_sc, pl->S, 1u,
-			                   (double2 *)ST, (double2 *)PS, i == 0 ? 1 : 0);
+			launch_accumulate(pl, (const double2 *)part, 1u, (double2 *)ST, (double2 *)PS, i == 0 ? 1 : 0, nullptr, 0, st);
 		} else { // two-stage over the first Tr traces, recomputed from scratch like the reference (:266-268)
 			K = p->Kmax;
 			if ((rc = tspws_hip_partial_stacks(pl, d_x, ld, Tr, 0, Tr, K, P, N, s))) return rc;
