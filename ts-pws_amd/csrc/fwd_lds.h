@@ -48,10 +48,13 @@
 #define FL_PASSES 2                             /* group slots per wave (workgroup = FL_WAVES x FL_PASSES slots) */
 #endif
 #ifndef FL_BATCH
-#define FL_BATCH 4                              /* tap steps per burst: LDS reads issued together, then straight-line FMAs */
+#define FL_BATCH 2                              /* tap steps per burst: the next burst's LDS reads are requested before this burst's FMAs (FL_PREFETCH); 4 + prefetch spills */
 #endif
 #ifndef FL_PASSES_FINE
 #define FL_PASSES_FINE 1                        /* group slots per wave for D <= 4: the fused kernel keeps 8/D coefficients' stacks per lane and slot */
+#endif
+#ifndef FL_PREFETCH
+#define FL_PREFETCH 1                           /* 1: LDS operands of the next burst are requested before this burst's FMAs */
 #endif
 #define FL_NT (64 * FL_WAVES)                   /* threads per workgroup */
 #define FL_SLOTS (FL_WAVES * FL_PASSES)
@@ -71,6 +74,22 @@
 #define FL_MAX2(a, b) ((a) > (b) ? (a) : (b))
 #define FL_X_ALLOC (FL_MAX2(FL_MAX2(FL_XROWS * 64, FL_XSMALL * FL_XPAD), FL_WAVES * FL_SCR) + 64)
 #define FL_LDS_BYTES (FL_TAPS_BYTES + FL_X_ALLOC * 8)
+
+#ifndef FL_TIMING
+#define FL_TIMING 0                             /* 1: per-phase s_memtime totals per LOGD class (tools/fwd_timing.py) */
+#endif
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. every wave would wait at each
+// barrier for its global stores of the previous trace's partials (and any load in flight) to complete -- measured with
+// the FL_TIMING hooks: ~13 k of the ~26 k shader cycles per wave and trace of the D >= 64 workgroups.  Global memory
+// needs no ordering here: the prefetched window is consumed through registers (the compiler's own vmcnt waits).
+__device__ __forceinline__ void fl_lds_barrier()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#if FL_TIMING
+__device__ unsigned long long *fl_timing_out; // [7 classes][8]: set-up, barrier 1, stage, barrier 2, FMA, reduce, traces, waves
+#endif
 
 // FUSE: scales without phase splits (D <= 64) do not write per-trace coefficients at all: the workgroup owns its
 // coefficients for the whole trace slice, so it phase-normalises each one right after the lane reduction and keeps
@@ -108,19 +127,23 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 		return SMALL ? ((long long)g0 * R + qa) * DC - d.c : ((long long)g0 * R + qa) * D + m0 - d.c;
 	};
 	const bool full = SMALL ? true : (m0 + 63 < D);
-	auto load_x = [&](double (&xv)[NXV], const TIn *__restrict__ xt, unsigned qa) {
+	// The prefetched window stays RAW in registers (TIn: half the registers for float traces) and every load of a window
+	// is independent of the others: conversion to double and the idle-lane mask are applied when the window is written
+	// to LDS, one trace later -- nothing between the loads waits for memory.
+	const bool mok = SMALL ? true : (m < D);
+	auto load_x = [&](TIn (&xv)[NXV], const TIn *__restrict__ xt, unsigned qa) {
 		const long long base = x_base(qa);
 		if (SMALL) {
 			if (base >= 0 && base + NXV * FL_NT <= (long long)N) { // fast path: no circular wrap
 				const TIn *src = xt + (unsigned)base + tid;
 #pragma unroll
-				for (int i = 0; i < NXV; i++) xv[i] = (double)src[FL_NT * i];
+				for (int i = 0; i < NXV; i++) xv[i] = src[FL_NT * i];
 			} else {
 				unsigned idx = wrap_index(base + tid, N);
 				const unsigned step = (unsigned)FL_NT % N;
 #pragma unroll
 				for (int i = 0; i < NXV; i++) {
-					xv[i] = (double)xt[idx];
+					xv[i] = xt[idx];
 					idx += step; if (idx >= N) idx -= N;
 				}
 			}
@@ -130,28 +153,32 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 				const TIn *src = xt + (unsigned)(base + (long long)wv * D) + lane;
 				const unsigned stride = (unsigned)FL_WAVES * D;
 #pragma unroll
-				for (int i = 0; i < NXV; i++) xv[i] = (double)src[(size_t)stride * i];
-			} else {
-				const bool mok = m < D;
+				for (int i = 0; i < NXV; i++) xv[i] = src[(size_t)stride * i];
+			} else { // circular seam and / or a last chunk with idle phase lanes (they read a valid address, store_x zeroes them)
 				unsigned idx = wrap_index(base + (long long)wv * D + (mok ? lane : 0), N);
 				const unsigned step = (unsigned)(((unsigned long long)FL_WAVES * D) % N);
 #pragma unroll
 				for (int i = 0; i < NXV; i++) {
-					xv[i] = mok ? (double)xt[idx] : 0.0;
+					xv[i] = xt[idx];
 					idx += step; if (idx >= N) idx -= N;
 				}
 			}
 		}
 	};
-	auto store_x = [&](const double (&xv)[NXV]) {
+	auto store_x = [&](const TIn (&xv)[NXV]) {
 		if (SMALL) {
 			const unsigned pt = tid + ((tid >> (3 + LG)) << LG); // padded index of element tid; +FL_XPAD per FL_NT elements
 #pragma unroll
-			for (int i = 0; i < NXV; i++) xL[pt + FL_XPAD * i] = xv[i];
+			for (int i = 0; i < NXV; i++) xL[pt + FL_XPAD * i] = (double)xv[i];
 		} else {
 			double *xdst = xL + wv * 64 + lane;
+			if (full) {
 #pragma unroll
-			for (int i = 0; i < NXV; i++) xdst[FL_NT * i] = xv[i];
+				for (int i = 0; i < NXV; i++) xdst[FL_NT * i] = (double)xv[i];
+			} else {
+#pragma unroll
+				for (int i = 0; i < NXV; i++) xdst[FL_NT * i] = mok ? (double)xv[i] : 0.0;
+			}
 		}
 	};
 	auto stage_taps = [&](unsigned qa, unsigned qn) {
@@ -184,7 +211,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 	};
 
 	if (resident) stage_taps(0, d.Q); // made visible by the barrier in front of the first compute
-	double xv[NXV];
+	TIn xv[NXV];
 	if (resident) load_x(xv, x0, 0);
 
 	constexpr int NACC = FUSE ? (SMALL ? (LOGD <= 3 ? (8 >> LOGD) : 1) : 1) : 1; // complex coefficients per lane and pass
@@ -197,6 +224,13 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 			for (int i = 0; i < NACC; i++) { fst[p][i] = make_double2(0.0, 0.0); fps[p][i] = make_double2(0.0, 0.0); }
 	}
 
+#if FL_TIMING
+	unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter();
+#define FL_STAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); tm[i] += n_ - tc; tc = n_; } while (0)
+#else
+#define FL_STAMP(i) do { } while (0)
+#endif
+	FL_STAMP(0); // set-up: descriptor, tap staging, first x loads
 	for (unsigned t = 0; t < ntr; t++) {
 		const TIn *xt = x0 + (size_t)t * ld;
 		double ar[PASSES][R], ai[PASSES][R];
@@ -207,11 +241,14 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 
 		for (unsigned qa = 0; qa < d.Q; qa += qt) {
 			const unsigned qn = (d.Q - qa) < qt ? (d.Q - qa) : qt;
-			__syncthreads(); // everyone is done reading the previous image (x rows, reduction scratch, taps)
+			fl_lds_barrier(); // everyone is done reading the previous image (x rows, taps)
+			FL_STAMP(1); // barrier 1 (+ accumulator reset)
 			if (!resident) { stage_taps(qa, qn); load_x(xv, xt, qa); }
 			store_x(xv);
-			__syncthreads();
+			FL_STAMP(2); // wait for the prefetched x (vmcnt) + LDS stores
+			fl_lds_barrier();
 			if (resident && t + 1 < ntr) load_x(xv, xt + ld, 0); // next trace's window flies while this one is computed
+			FL_STAMP(3); // barrier 2 + issue of the next prefetch
 			// ------------------------------------------------------------------ compute: two passes (group slots) per wave
 #pragma unroll
 			for (int p = 0; p < PASSES; p++) {
@@ -231,6 +268,37 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 				double xw[R];
 #pragma unroll
 				for (int j = 0; j < R - 1; j++) xw[j] = xb[FL_XOFF(j)];
+#if FL_PREFETCH
+				// software pipeline: the operands of burst h+1 are requested before the FMAs of burst h, so a wave's own FMA
+				// stream covers its LDS latency (one wave per SIMD sustains ~85 % of the FP64 rate when its stream is dense:
+				// tools/fma64_issue.hip).  Prefetching past qn reads rows / taps that exist in LDS but are never used.
+				double xn[2][FL_BATCH];
+				double2 tn[2][FL_BATCH];
+#pragma unroll
+				for (int u = 0; u < FL_BATCH; u++) { xn[0][u] = xb[FL_XOFF(u + R - 1)]; tn[0][u] = tb[u * XS]; }
+#pragma unroll
+				for (int h = 0; h < FL_QT / FL_BATCH; h++) {
+					if ((unsigned)(h * FL_BATCH) < qn) {
+						if (h + 1 < FL_QT / FL_BATCH) {
+#pragma unroll
+							for (int u = 0; u < FL_BATCH; u++) {
+								xn[(h + 1) & 1][u] = xb[FL_XOFF((h + 1) * FL_BATCH + u + R - 1)];
+								tn[(h + 1) & 1][u] = tb[((h + 1) * FL_BATCH + u) * XS];
+							}
+						}
+#pragma unroll
+						for (int u = 0; u < FL_BATCH; u++) {
+							const int sidx = h * FL_BATCH + u; // compile-time after unrolling
+							xw[(sidx + R - 1) % R] = xn[h & 1][u];
+#pragma unroll
+							for (int r = 0; r < R; r++) {
+								ar[p][r] = fma(xw[(sidx + r) % R], tn[h & 1][u].x, ar[p][r]);
+								ai[p][r] = fma(xw[(sidx + r) % R], tn[h & 1][u].y, ai[p][r]);
+							}
+						}
+					}
+				}
+#else
 #pragma unroll
 				for (int h = 0; h < FL_QT / FL_BATCH; h++) { // LDS reads of FL_BATCH steps are issued together, then their FMAs
 					if ((unsigned)(h * FL_BATCH) < qn) {
@@ -256,10 +324,12 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 						}
 					}
 				}
+#endif
 #undef FL_XOFF
 			}
 		}
 
+		FL_STAMP(4); // FMA passes
 		// ------------------------------------------------------------------ combine the phase lanes
 		if (FUSE && fuse) { // keep the running stacks in registers
 #pragma unroll
@@ -286,6 +356,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 					add_unit_phasor(fps[p][0], y);
 				}
 			}
+			FL_STAMP(5); // lane reduction + phase normalisation
 			continue;
 		}
 		// ------------------------------------------------------------------ store the split partial
@@ -352,6 +423,16 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 			}
 		}
 	}
+#if FL_TIMING
+	FL_STAMP(5);
+	if (lane == 0 && fl_timing_out) {
+#pragma unroll
+		for (int i = 0; i < 6; i++) atomicAdd(&fl_timing_out[(SMALL ? LOGD : 6) * 8 + i], tm[i]);
+		atomicAdd(&fl_timing_out[(SMALL ? LOGD : 6) * 8 + 6], (unsigned long long)ntr);
+		atomicAdd(&fl_timing_out[(SMALL ? LOGD : 6) * 8 + 7], 1ull);
+	}
+#endif
+#undef FL_STAMP
 }
 
 // grid = (workgroups of all LDS scales, trace slices); a workgroup handles traces [slice*tps, min(ntr, (slice+1)*tps))

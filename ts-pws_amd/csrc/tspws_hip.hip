@@ -1096,6 +1096,23 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 	return 0;
 }
 
+#if FL_TIMING
+// debug build only: device buffer of the per-phase wave timers of k_fwd_lds
+extern "C" int tspws_hip_fwd_timing(unsigned long long *h_out, int reset)
+{
+	static unsigned long long *d_buf = nullptr;
+	if (!d_buf) {
+		HIP_TRY(hipMalloc(&d_buf, 56 * sizeof(unsigned long long)));
+		HIP_TRY(hipMemset(d_buf, 0, 56 * sizeof(unsigned long long)));
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(fl_timing_out), &d_buf, sizeof d_buf));
+	}
+	HIP_TRY(hipDeviceSynchronize());
+	if (h_out) HIP_TRY(hipMemcpy(h_out, d_buf, 56 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	if (reset) HIP_TRY(hipMemset(d_buf, 0, 56 * sizeof(unsigned long long)));
+	return 0;
+}
+#endif
+
 // scratch for the split partials of one batch of transformed traces (bigger batches = fewer, fuller launches)
 static size_t part_budget_bytes()
 {
