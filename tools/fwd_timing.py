@@ -19,6 +19,9 @@ which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 if which == "cfg2":
     N, mtr = 32768, 1024
     p = tspws.resolve(abi.default_params(w0=2 * np.pi), N)
+elif which == "cfg3f":  # the ten transforms of cfg3, but straight from float traces (single-stage call on 10 traces)
+    N, mtr = 131072, 10
+    p = tspws.resolve(abi.default_params(), N)
 else:
     N, mtr = 131072, 2000
     p = tspws.resolve(abi.default_params(Kmax=10, unbiased=1), N)

@@ -131,37 +131,33 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 	// is independent of the others: conversion to double and the idle-lane mask are applied when the window is written
 	// to LDS, one trace later -- nothing between the loads waits for memory.
 	const bool mok = SMALL ? true : (m < D);
+	// Addressing: uniform trace pointer + one 32-bit element offset per thread that walks the window; the empty asm keeps
+	// the compiler from hoisting all NXV offsets (trace-independent) out of the trace loop as 64-bit register pairs.
 	auto load_x = [&](TIn (&xv)[NXV], const TIn *__restrict__ xt, unsigned qa) {
 		const long long base = x_base(qa);
+		unsigned off, stp, mod;
 		if (SMALL) {
-			if (base >= 0 && base + NXV * FL_NT <= (long long)N) { // fast path: no circular wrap
-				const TIn *src = xt + (unsigned)base + tid;
-#pragma unroll
-				for (int i = 0; i < NXV; i++) xv[i] = src[FL_NT * i];
-			} else {
-				unsigned idx = wrap_index(base + tid, N);
-				const unsigned step = (unsigned)FL_NT % N;
-#pragma unroll
-				for (int i = 0; i < NXV; i++) {
-					xv[i] = xt[idx];
-					idx += step; if (idx >= N) idx -= N;
-				}
-			}
+			const bool nw = base >= 0 && base + NXV * FL_NT <= (long long)N; // no circular wrap
+			off = nw ? (unsigned)base + tid : wrap_index(base + tid, N);
+			stp = nw ? (unsigned)FL_NT : (unsigned)FL_NT % N;
+			mod = nw ? 0u : N;
 		} else {
 			const long long s_last = base + (long long)(XROWS - 1) * D + 63;
-			if (full && base >= 0 && s_last < (long long)N) { // fast path
-				const TIn *src = xt + (unsigned)(base + (long long)wv * D) + lane;
-				const unsigned stride = (unsigned)FL_WAVES * D;
+			const bool nw = full && base >= 0 && s_last < (long long)N;
+			// circular seam and / or a last chunk with idle phase lanes (they read a valid address, store_x zeroes them)
+			off = nw ? (unsigned)(base + (long long)wv * D) + lane : wrap_index(base + (long long)wv * D + (mok ? lane : 0), N);
+			stp = nw ? (unsigned)FL_WAVES * D : (unsigned)(((unsigned long long)FL_WAVES * D) % N);
+			mod = nw ? 0u : N;
+		}
+		asm volatile("" : "+v"(off));
+		if (mod == 0) {
 #pragma unroll
-				for (int i = 0; i < NXV; i++) xv[i] = src[(size_t)stride * i];
-			} else { // circular seam and / or a last chunk with idle phase lanes (they read a valid address, store_x zeroes them)
-				unsigned idx = wrap_index(base + (long long)wv * D + (mok ? lane : 0), N);
-				const unsigned step = (unsigned)(((unsigned long long)FL_WAVES * D) % N);
+			for (int i = 0; i < NXV; i++) { xv[i] = xt[off]; off += stp; }
+		} else {
 #pragma unroll
-				for (int i = 0; i < NXV; i++) {
-					xv[i] = xt[idx];
-					idx += step; if (idx >= N) idx -= N;
-				}
+			for (int i = 0; i < NXV; i++) {
+				xv[i] = xt[off];
+				off += stp; if (off >= mod) off -= mod;
 			}
 		}
 	};

@@ -67,6 +67,7 @@ struct ScaleDesc {
 	unsigned lds_off, lds_bps;  // first workgroup of this scale in k_fwd_lds, workgroups per split
 	unsigned acc2_off;          // first block of this scale in k_accumulate_parts (32 coefficients per block when split)
 	unsigned fuse_ok;           // 1: k_fwd_lds<FUSE> keeps this scale's linear / phase stacks in registers (no partials)
+	unsigned use_oct, pad2;     // 1: forward transform by k_fwd_oct (fwd_oct.h) together with the other voices of its octave
 	unsigned long long part_off; // offset of this scale's [nsplit][Ns] partial block
 };
 
@@ -74,6 +75,9 @@ struct ScaleDesc {
 #define FM_KQCAP_HOST FM_KQCAP
 #define FM_TAMAX_HOST FM_TAMAX
 struct OctDesc;
+struct OctFwd;
+static int build_oct_forward(tspws_hip_plan *p, std::vector<char> &is_oct); // defined next to the forward kernels
+static int upload_oct_forward(tspws_hip_plan *p);
 
 #ifndef FL_PASSES
 #define FL_PASSES 2
@@ -92,7 +96,7 @@ struct Chunk { // one streaming work item of the partial-stack kernel
 	unsigned row;          // destination row (group / class)
 };
 
-enum { SCR_Y = 0, SCR_PART, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_N };
+enum { SCR_Y = 0, SCR_PART, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_XCM, SCR_N };
 
 struct tspws_hip_plan {
 	int device = 0, type = -1;
@@ -105,6 +109,12 @@ struct tspws_hip_plan {
 	unsigned acc2_blocks = 0;  // blocks of k_accumulate_parts
 	unsigned lds_blocks = 0;   // workgroups per trace slice of k_fwd_lds
 	unsigned n_fusable = 0;    // scales whose stacks the fused forward kernel keeps in registers
+	unsigned oct_wgs = 0, oct_n = 0; // k_fwd_oct: workgroups per trace slice, octaves
+	size_t oct_lds = 0;
+	struct OctFwd *d_ofw = nullptr;
+	std::vector<unsigned char> ofw_host; // the OctFwd table (bytes; the struct is defined next to the kernel)
+	unsigned cm_n[2] = {0, 0}, cm_D[2][8] = {{0}}, cm_MC[2][8] = {{0}}; // chunk-major copies by input type [float, double]
+	size_t cm_per_trace[2] = {0, 0};                                    // elements per trace of all copies
 	int fwd_kind = 1;          // 0: k_fwd_poly only, 1: k_fwd_lds (+poly), 3: k_fwd_mfma (opt-in)
 	std::vector<FwdGroup> pairs; // fwd_kind 3: work groups, their B tables and work items
 	FwdGroup *d_pairs = nullptr;
@@ -127,8 +137,8 @@ struct tspws_hip_plan {
 	hipEvent_t ev_done = nullptr;
 	// forward transform: the direct kernel (coarse scales, latency-bound) runs beside the LDS kernel (FP64-bound) on a
 	// side stream, forked from and joined back into the caller's stream
-	hipStream_t side = nullptr;
-	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	hipStream_t side = nullptr, side2 = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
 	// optional timing of the streaming stage inside tspws_hip_stack (bench.py roofline leg)
 	std::vector<hipEvent_t> prof_ev;
 	size_t prof_used = 0;
@@ -436,8 +446,7 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 		if (const char *e = getenv("TSPWS_FWD_KERNEL")) kind = !strcmp(e, "poly") ? 0 : !strcmp(e, "mfma") ? 3 : 1;
 		if (getenv("TSPWS_FWD_NOLDS") && *getenv("TSPWS_FWD_NOLDS") == '1') kind = 0;
 		p->fwd_kind = kind;
-		unsigned woff = 0, boff = 0;
-		unsigned long long poff = 0;
+		// pass 1: per-scale geometry and the kernel that would take the scale on its own
 		for (unsigned s = 0; s < S; s++) {
 			ScaleDesc &d = p->sc[s];
 			d.Q = (d.L + d.D - 1) / d.D;
@@ -445,23 +454,36 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 			while (dl < d.D && dl < 64) { dl <<= 1; lg++; }
 			d.DL = dl; d.logDL = lg;
 			d.MC = d.D > 64 ? (d.D + 63) / 64 : 1;
-			const unsigned NG = (d.Ns + R - 1) / R, GW = 64 / d.DL;
+			const unsigned NG = (d.Ns + R - 1) / R;
 			const bool pow2 = (d.D & (d.D - 1)) == 0;
-			d.ngw = (NG + GW - 1) / GW;
 			d.use_lds = (kind != 0 && NG >= 8 && (d.D >= 64 || pow2)) ? 1u : 0u;
+			d.use_oct = 0; d.pad2 = 0;
+		}
+		// pass 2: octaves with D >= 64 whose voices all qualify go to the octave-fused kernel (one x window for all voices)
+		std::vector<char> is_oct(S, 0);
+		if (kind == 1) { if (int rc = build_oct_forward(p, is_oct)) { tspws_hip_plan_destroy(p); return rc; } }
+		// pass 3: work decomposition and offsets
+		unsigned woff = 0, boff = 0;
+		unsigned long long poff = 0;
+		for (unsigned s = 0; s < S; s++) {
+			ScaleDesc &d = p->sc[s];
+			const unsigned NG = (d.Ns + R - 1) / R, GW = 64 / d.DL;
+			d.ngw = (NG + GW - 1) / GW;
+			if (is_oct[s]) { d.use_oct = 1; d.use_lds = 0; }
 			unsigned cps;
-			if (d.use_lds) cps = 1; // one 64-phase chunk per workgroup: its taps stay resident in LDS
+			if (d.use_lds || d.use_oct) cps = 1; // one 64-phase chunk per workgroup: its taps stay resident in LDS
 			else cps = std::max(1u, (FWD_STEPS + d.Q / 2) / std::max(1u, d.Q));
 			d.cps = std::min(cps, d.MC);
 			d.nsplit = (d.MC + d.cps - 1) / d.cps;
 			d.wave_off = woff; d.lds_off = boff; d.part_off = poff;
 			const unsigned slots = (d.D <= 4) ? FL_WAVES * FL_PASSES_FINE : FL_SLOTS_HOST; // as dispatched in k_fwd_lds
 			d.lds_bps = (NG + slots * GW - 1) / (slots * GW);
-			if (d.use_lds) boff += d.lds_bps * d.nsplit; else woff += d.ngw * d.nsplit;
+			if (d.use_lds) boff += d.lds_bps * d.nsplit; else if (!d.use_oct) woff += d.ngw * d.nsplit;
 			poff += (unsigned long long)d.nsplit * d.Ns;
 			d.fuse_ok = (kind == 1 && d.use_lds && d.nsplit == 1 && d.D >= 2) ? 1u : 0u;
 		}
 		p->fwd_waves = woff; p->lds_blocks = boff; p->npart = poff;
+		if (int rc = upload_oct_forward(p)) { tspws_hip_plan_destroy(p); return rc; }
 		for (unsigned s = 0; s < S; s++) p->n_fusable += p->sc[s].fuse_ok;
 		if (kind == 3 && !build_mfma_pairs(p)) { // a filter too long for the matrix kernel: VALU kernels
 			p->fwd_kind = 1; p->pairs.clear();
@@ -510,9 +532,12 @@ extern "C" void tspws_hip_plan_destroy(tspws_hip_plan *p)
 	if (p->ev_done) (void)hipEventDestroy(p->ev_done);
 	if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
 	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+	if (p->ev_join2) (void)hipEventDestroy(p->ev_join2);
 	if (p->side) (void)hipStreamDestroy(p->side);
+	if (p->side2) (void)hipStreamDestroy(p->side2);
 	if (p->aux) (void)hipStreamDestroy(p->aux);
 	if (p->d_oc) (void)hipFree(p->d_oc);
+	if (p->d_ofw) (void)hipFree(p->d_ofw);
 	if (p->d_pairs) (void)hipFree(p->d_pairs);
 	if (p->d_bt) (void)hipFree(p->d_bt);
 	if (p->d_sc) (void)hipFree(p->d_sc);
@@ -965,6 +990,132 @@ static bool fuse_enabled()
 #include "fwd_mfma.h"
 static_assert(FM_KQCAP == FM_KQCAP_HOST, "tap-step cap");
 
+#include "fwd_oct.h"
+
+// Octaves (runs of scales with the same D and Ns) that the octave-fused kernel takes: D >= 64, every voice eligible for the
+// LDS kernel, tap images + x image within the LDS budget.  TSPWS_FWD_OCT=0 leaves them on k_fwd_lds.
+static int build_oct_forward(tspws_hip_plan *p, std::vector<char> &is_oct)
+{
+	p->ofw_host.clear(); p->oct_wgs = 0; p->oct_n = 0; p->oct_lds = 0;
+	if (const char *e = getenv("TSPWS_FWD_OCT")) if (*e == '0') return 0;
+	std::vector<OctFwd> tab;
+	unsigned wg = 0;
+	for (unsigned s = 0; s < p->S;) {
+		unsigned e = s + 1;
+		while (e < p->S && p->sc[e].D == p->sc[s].D && p->sc[e].Ns == p->sc[s].Ns) e++;
+		const unsigned D = p->sc[s].D, Ns = p->sc[s].Ns, nv = e - s;
+		bool ok = D >= 64;
+		for (unsigned v = s; v < e && ok; v++) ok = p->sc[v].use_lds != 0;
+		if (ok) {
+			// tap rows of every voice: c = a D + b, tap row q' holds taps (q' - 1) D + rho + b, rho < D
+			std::vector<unsigned> a(nv), b(nv), qr(nv);
+			for (unsigned v = 0; v < nv; v++) {
+				const ScaleDesc &d = p->sc[s + v];
+				a[v] = (unsigned)d.c / D; b[v] = (unsigned)d.c % D;
+				const long long num = (long long)d.L - 1 - (long long)b[v];
+				const long long fl = num >= 0 ? num / (long long)D : -1; // floor division: largest q' - 1 that holds a tap
+				qr[v] = ((unsigned)(fl + 2) + 3) & ~3u;
+				if (qr[v] > FO_QMAX || (unsigned long long)(a[v] + 1) * D > p->N) ok = false;
+			}
+			// voice subsets by first-fit-decreasing on the tap rows: an item takes a voice when its tap images plus the x image
+			// (whose height depends on the subset's spread of a_v) still fit the LDS budget -- e.g. 4 Morlet voices with
+			// 12 / 16 / 16 / 20 rows and 78 KB give {3, 0} and {1, 2}: 32 rows each
+			std::vector<unsigned> order(nv);
+			for (unsigned v = 0; v < nv; v++) order[v] = v;
+			std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return qr[x] > qr[y]; });
+			struct Bin { std::vector<unsigned> vs; unsigned rows = 0, amax = 0, amin = ~0u, qmax = 0, xr = 0; };
+			std::vector<Bin> bins;
+			for (unsigned oi = 0; oi < nv && ok; oi++) {
+				const unsigned v = order[oi];
+				bool placed = false;
+				for (size_t bi = 0; bi <= bins.size() && !placed; bi++) {
+					if (bi == bins.size()) bins.emplace_back();
+					Bin &bn = bins[bi];
+					const unsigned amax2 = std::max(bn.amax, a[v]), amin2 = std::min(bn.amin, a[v]), qmax2 = std::max(bn.qmax, qr[v]);
+					const unsigned xr = (63 + qmax2 + (amax2 - amin2) + 7) & ~7u;
+					const size_t lds = (size_t)(bn.rows + qr[v]) * 64 * sizeof(double2) + (size_t)xr * 64 * sizeof(double);
+					if (xr > FO_XRMAX || lds > FO_LDS_MAX || bn.vs.size() >= FO_VMAX) {
+						if (bn.vs.empty()) { ok = false; bins.pop_back(); break; } // does not even fit alone
+						continue;
+					}
+					bn.vs.push_back(v); bn.rows += qr[v]; bn.amax = amax2; bn.amin = amin2; bn.qmax = qmax2; bn.xr = xr;
+					placed = true;
+				}
+			}
+			std::vector<OctFwd> items;
+			for (const Bin &bn : bins) {
+				if (!ok) break;
+				OctFwd o;
+				memset(&o, 0, sizeof o);
+				o.D = D; o.Ns = Ns; o.MC = (D + 63) / 64; o.nob = (Ns + 63) / 64;
+				o.nv = (unsigned)bn.vs.size(); o.amax = bn.amax; o.trows = bn.rows; o.XR = bn.xr;
+				unsigned rows = 0;
+				for (unsigned n = 0; n < o.nv; n++) {
+					const unsigned v = bn.vs[n];
+					o.sc[n] = s + v; o.QR[n] = qr[v]; o.trow[n] = rows; o.a[n] = a[v]; o.b[n] = b[v];
+					o.L[n] = p->sc[s + v].L; o.tap_off[n] = p->sc[s + v].tap_off;
+					rows += qr[v];
+				}
+				items.push_back(o);
+			}
+			if (ok) {
+				for (OctFwd &o : items) {
+					o.wg_off = wg; wg += o.MC * o.nob;
+					p->oct_lds = std::max(p->oct_lds, (size_t)o.trows * 64 * sizeof(double2) + (size_t)o.XR * 64 * sizeof(double));
+					tab.push_back(o);
+				}
+				for (unsigned v = s; v < e; v++) is_oct[v] = 1;
+			}
+		}
+		s = e;
+	}
+	// chunk-major copies: decimations whose rows are more than 4 KB apart for the input type (and divide N: the circular
+	// wrap is then a wrap of the row index)
+	for (int ti = 0; ti < 2; ti++) {
+		p->cm_n[ti] = 0; p->cm_per_trace[ti] = 0;
+		const size_t esz = ti ? sizeof(double) : sizeof(float);
+		static int cm_on = -1;
+		if (cm_on < 0) { const char *e = getenv("TSPWS_FWD_CM"); cm_on = (e && *e == '0') ? 0 : 1; }
+		for (OctFwd &o : tab) {
+			o.cm_slot[ti] = ~0u; o.cm_pre[ti] = 0;
+			if (!cm_on || (size_t)o.D * esz <= 4096 || p->N % o.D != 0) continue;
+			unsigned slot = ~0u;
+			size_t pre = 0;
+			for (unsigned k = 0; k < p->cm_n[ti]; k++) {
+				if (p->cm_D[ti][k] == o.D) { slot = k; break; }
+				pre += (size_t)p->cm_MC[ti][k] * (p->N / p->cm_D[ti][k]) * 64;
+			}
+			if (slot == ~0u) {
+				if (p->cm_n[ti] >= FO_CMMAX) continue;
+				slot = p->cm_n[ti]++;
+				p->cm_D[ti][slot] = o.D; p->cm_MC[ti][slot] = o.MC;
+				p->cm_per_trace[ti] += (size_t)o.MC * (p->N / o.D) * 64;
+			}
+			o.cm_slot[ti] = slot; o.cm_pre[ti] = pre;
+		}
+	}
+	p->oct_wgs = wg; p->oct_n = (unsigned)tab.size();
+	p->ofw_host.resize(tab.size() * sizeof(OctFwd));
+	if (!tab.empty()) memcpy(p->ofw_host.data(), tab.data(), p->ofw_host.size());
+	if (getenv("TSPWS_DEBUG"))
+		for (const OctFwd &o : tab) fprintf(stderr, "oct sc0=%u nv=%u D=%u Ns=%u MC=%u nob=%u rows=%u XR=%u amax=%u wg_off=%u\n", o.sc[0], o.nv, o.D, o.Ns, o.MC, o.nob, o.trows, o.XR, o.amax, o.wg_off);
+	return 0;
+}
+
+// the partial-block offsets are known only after the work decomposition: complete the table and upload it
+static int upload_oct_forward(tspws_hip_plan *p)
+{
+	if (!p->oct_n) return 0;
+	OctFwd *tab = (OctFwd *)p->ofw_host.data();
+	for (unsigned i = 0; i < p->oct_n; i++)
+		for (unsigned v = 0; v < tab[i].nv; v++) tab[i].part_off[v] = p->sc[tab[i].sc[v]].part_off;
+	HIP_TRY(hipMalloc(&p->d_ofw, p->ofw_host.size()));
+	HIP_TRY(hipMemcpy(p->d_ofw, tab, p->ofw_host.size(), hipMemcpyHostToDevice));
+	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_oct<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FO_LDS_MAX));
+	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_oct<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FO_LDS_MAX));
+	return 0;
+}
+
 static int upload_mfma_tables(tspws_hip_plan *p)
 {
 	const size_t np = p->pairs.size();
@@ -1040,15 +1191,52 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 		HIP_TRY(hipGetLastError());
 		return 0;
 	}
-	const bool both = p->lds_blocks && p->fwd_waves && side_stream_enabled();
-	hipStream_t sp = st; // stream of the direct kernel
+	// Up to three independent kernels transform disjoint sets of scales: the octave-fused kernel (D >= 64), the LDS kernel
+	// (D < 64) and the direct kernel (coarse scales, latency-bound).  They run side by side: two side streams are forked
+	// from and joined back into the caller's stream.
+	const int nk = (p->lds_blocks ? 1 : 0) + (p->fwd_waves ? 1 : 0) + (p->oct_wgs ? 1 : 0);
+	const bool both = nk > 1 && side_stream_enabled();
+	hipStream_t sp = st, so = st; // streams of the direct and of the octave kernel
 	if (both) {
+		const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence; // device-local ordering only
 		if (!p->side) HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-		if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-		if (!p->ev_join) HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+		if (!p->side2) HIP_TRY(hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking));
+		if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, evf));
+		if (!p->ev_join) HIP_TRY(hipEventCreateWithFlags(&p->ev_join, evf));
+		if (!p->ev_join2) HIP_TRY(hipEventCreateWithFlags(&p->ev_join2, evf));
 		HIP_TRY(hipEventRecord(p->ev_fork, st));
-		HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
-		sp = p->side;
+		if (p->fwd_waves && nk > 1) { HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0)); sp = p->side; }
+		if (p->oct_wgs && p->lds_blocks) { HIP_TRY(hipStreamWaitEvent(p->side2, p->ev_fork, 0)); so = p->side2; }
+	}
+	if (p->oct_wgs) {
+		unsigned tps = (unsigned)std::min<size_t>(ntr, 32);
+		while (tps > 1 && (size_t)p->oct_wgs * ((ntr + tps - 1) / tps) < 256) tps = (tps + 1) / 2; // at least one workgroup per CU
+		if (const char *e = getenv("TSPWS_OCT_TPS")) tps = (unsigned)std::max(1, atoi(e));
+		const size_t per_launch = std::min<size_t>((size_t)tps * 65535, 65535);
+		constexpr int TI = sizeof(TIn) == 8 ? 1 : 0;
+		TIn *xcm = nullptr;
+		if (p->cm_n[TI]) { // chunk-major copies of the batch for the far-strided decimations
+			void *vx;
+			int rcx = scratch(p, SCR_XCM, std::min(ntr, per_launch) * p->cm_per_trace[TI] * sizeof(TIn), &vx);
+			if (rcx) return rcx;
+			xcm = (TIn *)vx;
+		}
+		for (size_t t0 = 0; t0 < ntr; t0 += per_launch) {
+			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, per_launch);
+			if (xcm) {
+				ChunkMajor cmj;
+				memset(&cmj, 0, sizeof cmj);
+				cmj.n = p->cm_n[TI];
+				size_t big = 0;
+				for (unsigned k = 0; k < cmj.n; k++) {
+					cmj.D[k] = p->cm_D[TI][k]; cmj.MC[k] = p->cm_MC[TI][k];
+					big = std::max(big, (size_t)cmj.MC[k] * (p->N / cmj.D[k]) * 64);
+				}
+				hipLaunchKernelGGL((k_chunk_major<TIn>), dim3((unsigned)((big + 255) / 256), nt, cmj.n), dim3(256), 0, so, d_x + t0 * ld, ld, nt, p->N, cmj, xcm);
+			}
+			hipLaunchKernelGGL((k_fwd_oct<TIn>), dim3(p->oct_wgs, (nt + tps - 1) / tps), dim3(FO_NT), p->oct_lds, so, d_x + t0 * ld, ld, nt, tps, p->N,
+			                   p->d_ofw, p->oct_n, p->d_w, d_part + t0 * p->npart, p->npart, (const TIn *)xcm, nt);
+		}
 	}
 	// the direct kernel first: its few hundred long, latency-bound workgroups (no LDS, 88 VGPRs) get their slots and the
 	// LDS kernel's workgroups fill in beside them
@@ -1088,9 +1276,13 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 		}
 		if (fuse) fz->applied = true;
 	}
-	if (both) {
-		HIP_TRY(hipEventRecord(p->ev_join, p->side));
+	if (sp != st) {
+		HIP_TRY(hipEventRecord(p->ev_join, sp));
 		HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
+	}
+	if (so != st) {
+		HIP_TRY(hipEventRecord(p->ev_join2, so));
+		HIP_TRY(hipStreamWaitEvent(st, p->ev_join2, 0));
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
