@@ -618,3 +618,34 @@ def test_reduce_buffer_survives_growth(lib, torch):
     ls, ts = pl.stack(X)
     want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(Kmax=2), X.cpu().numpy())
     assert abi.relerr(ts.cpu().numpy(), want["tsPWS"]) < TOL32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("kw,N,ntr", [
+    (dict(), 16384, 3), (dict(), 16501, 5), (dict(type=-3), 32768, 2), (dict(w0=2 * np.pi), 32768, 9),
+    (dict(s0=3.7, J=8), 30010, 2), (dict(), 131072, 2), (dict(b0=4.0), 65536, 2),
+])
+def test_forward_octave_fused_kernels(lib, torch, kw, N, ntr, mode, monkeypatch):
+    """Opt-in octave-fused forward kernels for D >= 64 (csrc/fwd_oct.h, TSPWS_FWD_OCT=1): mode 1 = voice subsets, two workgroups
+    per CU; mode 2 = two-team software pipeline.  Same coefficients as the oracle for float and double inputs (strided and
+    chunk-major windows, circular seams, decimations that do not divide N, partially filled residue chunks), and the whole
+    two-stage call on top."""
+    monkeypatch.setenv("TSPWS_FWD_OCT", "1")
+    monkeypatch.setenv("TSPWS_OCT_MODE", mode)
+    p = abi.resolve(abi.default_params(**kw), N)
+    f = abi.OracleFrame.from_params(p, N)
+    pl = tspws.Plan(p, N)
+    X = abi.synth_traces(ntr, N, seed=35)
+    Y = dev_forward(torch, pl, X.astype(np.float64))
+    Y32 = dev_forward(torch, pl, X)
+    for t in range(ntr):
+        Yo = f.forward(X[t].astype(np.float64))
+        assert abi.relerr(Y[t], Yo) < TOL64
+        assert abi.relerr(Y32[t], Yo) < TOL64
+    pk = tspws.resolve(abi.default_params(Kmax=2, unbiased=1, **kw), N)
+    plk = tspws.Plan(pk, N)
+    ls, ts = plk.stack(torch.as_tensor(X, device="cuda"))
+    torch.cuda.synchronize()
+    b = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(Kmax=2, unbiased=1, **kw), X)
+    assert abi.relerr(ts.cpu().numpy(), b["tsPWS"]) < TOL32 and abi.relerr(ls.cpu().numpy(), b["ls"]) < TOL32

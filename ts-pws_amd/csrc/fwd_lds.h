@@ -281,6 +281,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 								xn[(h + 1) & 1][u] = xb[FL_XOFF((h + 1) * FL_BATCH + u + R - 1)];
 								tn[(h + 1) & 1][u] = tb[((h + 1) * FL_BATCH + u) * XS];
 							}
+							asm volatile("" ::: "memory"); // the scheduler otherwise sinks these reads to just in front of their FMAs
 						}
 #pragma unroll
 						for (int u = 0; u < FL_BATCH; u++) {
@@ -406,6 +407,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 			if (LOGD >= 3) first += (lane & 4) ? (LOGD == 5 ? 2u : LOGD == 4 ? 4u : 8u) : 0u;
 			if (LOGD >= 2 && LOGD <= 4) first += (lane & 2) ? (LOGD == 4 ? 2u : LOGD == 3 ? 4u : 8u) : 0u;
 			if (LOGD >= 1 && LOGD <= 3) first += (lane & 1) ? (LOGD == 3 ? 2u : LOGD == 2 ? 4u : 8u) : 0u;
+			// LOGD == 0: no exchange at all, the lane keeps its 16 values (first = 0)
 		} else first = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2;
 		if (!(lane & dup_mask)) {
 #pragma unroll
@@ -463,7 +465,7 @@ __global__ void __launch_bounds__(FL_NT, 2) k_fwd_lds(const TIn *__restrict__ x,
 	double2 *aS = FUSE ? accST + (size_t)blockIdx.y * acc_stride : nullptr, *aP = FUSE ? accPS + (size_t)blockIdx.y * acc_stride : nullptr;
 	if (d.D >= 64) { fwd_lds_body<TIn, 6, FUSE, FL_PASSES>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); return; }
 	switch (d.logDL) {
-	case 0: fwd_lds_body<TIn, 0, false, FL_PASSES_FINE>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break; // D = 1: 8 coefficients per lane and pass would not fit in registers -> stays on the partial path (fuse_ok = 0)
+	case 0: fwd_lds_body<TIn, 0, FUSE, FL_PASSES_FINE>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break; // D = 1 (Mexican hat, uni): 8 coefficients per lane
 	case 1: fwd_lds_body<TIn, 1, FUSE, FL_PASSES_FINE>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
 	case 2: fwd_lds_body<TIn, 2, FUSE, FL_PASSES_FINE>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
 	case 3: fwd_lds_body<TIn, 3, FUSE, FL_PASSES>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;

@@ -286,6 +286,213 @@ __global__ void __launch_bounds__(FO_NT, 2) k_fwd_oct(const TIn *__restrict__ x,
 #undef FO_STAMP
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_fwd_oct2: the same octave-fused transform as a two-team software pipeline.
+//
+// Why: with FL_TIMING the window load turned out to be bound by what one CU pulls in (~16 B/cycle: 90 KB for the two
+// workgroups of a CU = 5-6 k cycles per trace), as long as the FMA passes of a trace (5 k cycles per wave), and every
+// wave of both workgroups did it at the same moment -- the FP64 pipe idled through the loads, then two waves per SIMD
+// shared it.  Here ONE 512-thread workgroup per CU is split into two TEAMS of four waves (32 outputs each, own x image,
+// all tap images shared).  Workgroup barriers cut the time into intervals; in every interval one team COMPUTES its
+// trace (one FMA-ing wave per SIMD: a dense v_fma_f64 stream of a single wave sustains ~85 % of the pipe,
+// tools/fma64_issue.hip) while the other STAGES its next window (LDS writes, then the loads of the window after that,
+// which have two intervals to arrive):
+//
+//     interval      0        1        2        3        4     ...
+//     team 0     stage t0  comp t0  stage t1  comp t1  stage t2
+//     team 1        -      stage t0  comp t0  stage t1  comp t1
+//
+// All voices of the octave share one window (3.6x fewer window bytes per FMA than the per-scale kernel) and the loads
+// of one team run beside the FMAs of the other.
+#define FT_NT 512
+#define FT_XRMAX 64        /* rows of a team image (multiple of 4) */
+#define FT_NXV (FT_XRMAX / 4)
+#define FT_LDS_MAX (156 * 1024)
+#define FT_XPAD 8          /* rows past an image that the operand prefetch may touch */
+
+template <typename TIn>
+__global__ void __launch_bounds__(FT_NT, 2) k_fwd_oct2(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
+                                                       const OctFwd *__restrict__ oc, unsigned noct, const double2 *__restrict__ w,
+                                                       double2 *__restrict__ part, size_t npart, const TIn *__restrict__ xcm,
+                                                       unsigned ntr_all)
+{
+	constexpr int R = 8;
+	constexpr int TI = sizeof(TIn) == 8 ? 1 : 0;
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	unsigned lo = 0, hi = noct;
+	while (hi - lo > 1) {
+		const unsigned mid = (lo + hi) >> 1;
+		if (oc[mid].wg_off <= blockIdx.x) lo = mid; else hi = mid;
+	}
+	const OctFwd *__restrict__ o = oc + lo;
+	const unsigned D = o->D, Ns = o->Ns, nv = o->nv, XR = o->XR, amax = o->amax, trows = o->trows;
+	const unsigned wl = blockIdx.x - o->wg_off;
+	const unsigned ci = wl / o->nob, ob = wl - ci * o->nob;
+	const unsigned tid = threadIdx.x, lane = tid & 63;
+	const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const unsigned team = wv >> 2, tw = wv & 3;
+	const unsigned rho0 = ci * 64u;
+	const bool mok = rho0 + lane < D;
+	const bool full = rho0 + 63u < D;
+	const unsigned kt0 = ob * 64u + team * 32u; // first output of the team
+	double2 *tL = (double2 *)smem;                                                            // [trows][64]
+	double *xLt = (double *)(smem + (size_t)trows * 64 * sizeof(double2)) + (size_t)team * (XR + FT_XPAD) * 64; // this team's [XR][64]
+
+	const unsigned t0 = blockIdx.y * tps;
+	const unsigned nt = (ntr - t0) < tps ? (ntr - t0) : tps;
+	const TIn *x0 = x + (size_t)t0 * ld;
+
+	for (unsigned idx = tid; idx < trows * 64u; idx += FT_NT) { // tap images, zero outside the filter / for idle residue lanes
+		const unsigned row = idx >> 6, ln = idx & 63u;
+		unsigned v = 0;
+		while (v + 1 < nv && o->trow[v + 1] <= row) v++;
+		const unsigned q = row - o->trow[v];
+		const long long l = ((long long)q - 1) * D + rho0 + ln + o->b[v];
+		const bool ok = (rho0 + ln < D) && l >= 0 && l < (long long)o->L[v];
+		tL[idx] = ok ? w[o->tap_off[v] + (unsigned long long)l] : make_double2(0.0, 0.0);
+	}
+
+	// ---- window of the team: image row i <-> sample (kt0 - amax - 1 + i) D + rho; wave tw owns rows tw, tw + 4, ... ------
+	const unsigned nxr = XR / 4;
+	const long long j0w = (long long)kt0 - (long long)amax - 1 + (long long)tw;
+	const long long base = j0w * D + rho0;
+	const unsigned idx0 = wrap_index(base + (mok ? lane : 0), N);
+	const unsigned step = (unsigned)((4ull * D) % N);
+	const bool nowrap = base >= 0 && base + (long long)(nxr - 1) * 4 * D + 63 < (long long)N;
+	const bool cm = xcm != nullptr && o->cm_slot[TI] != ~0u;
+	const unsigned NJ = Ns;
+	unsigned jw = 0;
+	bool cm_nowrap = false;
+	if (cm) {
+		long long jj = j0w % (long long)NJ; if (jj < 0) jj += NJ;
+		jw = (unsigned)jj;
+		cm_nowrap = jw + (nxr - 1) * 4 < NJ;
+	}
+	auto load_x = [&](TIn (&xv)[FT_NXV], const unsigned t) {
+		const TIn *row0;
+		unsigned off, stp, mod;
+		if (cm) {
+			row0 = xcm + (size_t)ntr_all * o->cm_pre[TI] + ((size_t)(t0 + t) * o->MC + ci) * (size_t)NJ * 64;
+			off = jw * 64u + lane; stp = 4u * 64u; mod = cm_nowrap ? 0u : NJ * 64u;
+		} else {
+			row0 = x0 + (size_t)t * ld;
+			off = idx0; stp = nowrap ? 4u * D : step; mod = nowrap ? 0u : N;
+		}
+		asm volatile("" : "+v"(off)); // see k_fwd_oct
+#pragma unroll
+		for (int i = 0; i < FT_NXV; i++) {
+			xv[i] = row0[off];
+			off += (unsigned)(i + 1) < nxr ? stp : 0u;
+			if (mod && off >= mod) off -= mod;
+		}
+	};
+	auto store_x = [&](const TIn (&xv)[FT_NXV]) {
+		double *xdst = xLt + tw * 64 + lane;
+#pragma unroll
+		for (int i = 0; i < FT_NXV; i++) {
+			const unsigned ii = (unsigned)i < nxr ? (unsigned)i : nxr - 1;
+			xdst[256 * ii] = (full || mok) ? (double)xv[i] : 0.0;
+		}
+	};
+
+	const unsigned o16 = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1); // element left by valu_reduce16
+	const unsigned kout = kt0 + tw * R + (o16 >> 1);
+	const bool writer = (lane & 3) == 0 && kout < Ns;
+	const bool group_live = kt0 + tw * R < Ns;
+	const bool team_live = kt0 < Ns; // a team past the last outputs neither stages nor computes
+
+	auto compute = [&](const unsigned t) {
+		for (unsigned v = 0; v < nv; v++) {
+			const unsigned QR = o->QR[v];
+			const double *xb = xLt + ((size_t)tw * R + (amax - o->a[v])) * 64 + lane;
+			const double2 *tb = tL + (size_t)o->trow[v] * 64 + lane;
+			double ar[R], ai[R];
+#pragma unroll
+			for (int r = 0; r < R; r++) { ar[r] = 0; ai[r] = 0; }
+			double xw[R];
+#pragma unroll
+			for (int j = 0; j < R - 1; j++) xw[j] = xb[j * 64];
+			// operands of the next burst are requested before the FMAs of this one: the only computing wave of its SIMD
+			// must cover its own LDS latency.  Reads past QR touch rows that exist in LDS and are never used.
+			double xn[2][4];
+			double2 tn[2][4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) { xn[0][u] = xb[(u + R - 1) * 64]; tn[0][u] = tb[u * 64]; }
+			for (unsigned sb = 0; sb < QR; sb += R) { // QR is a multiple of 4
+#pragma unroll
+				for (int u = 0; u < 4; u++) { xn[1][u] = xb[(4 + u + R - 1) * 64]; tn[1][u] = tb[(4 + u) * 64]; }
+				asm volatile("" ::: "memory"); // the scheduler otherwise sinks these reads to just in front of their FMAs
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					xw[(u + R - 1) % R] = xn[0][u];
+#pragma unroll
+					for (int r = 0; r < R; r++) {
+						ar[r] = fma(xw[(u + r) % R], tn[0][u].x, ar[r]);
+						ai[r] = fma(xw[(u + r) % R], tn[0][u].y, ai[r]);
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < 4; u++) { xn[0][u] = xb[(8 + u + R - 1) * 64]; tn[0][u] = tb[(8 + u) * 64]; }
+				asm volatile("" ::: "memory");
+				if (sb + 4u < QR) {
+#pragma unroll
+					for (int u = 0; u < 4; u++) {
+						const int sidx = 4 + u;
+						xw[(sidx + R - 1) % R] = xn[1][u];
+#pragma unroll
+						for (int r = 0; r < R; r++) {
+							ar[r] = fma(xw[(sidx + r) % R], tn[1][u].x, ar[r]);
+							ai[r] = fma(xw[(sidx + r) % R], tn[1][u].y, ai[r]);
+						}
+					}
+				}
+				xb += R * 64; tb += R * 64;
+			}
+			double v16[2 * R];
+#pragma unroll
+			for (int r = 0; r < R; r++) { v16[2 * r] = ar[r]; v16[2 * r + 1] = ai[r]; }
+			const double sum = valu_reduce16(v16, lane);
+			if (writer) {
+				double *pout = (double *)(part + (size_t)(t0 + t) * npart + o->part_off[v] + (size_t)ci * Ns);
+				pout[(size_t)kout * 2 + (o16 & 1)] = (o16 & 1) ? -sum : sum; // conj
+			}
+		}
+	};
+
+	TIn xv[FT_NXV];
+	if (team_live) load_x(xv, 0);
+	const int nint = 2 * (int)nt + 1;
+#if FL_TIMING
+	unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter();
+#define FT_STAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); tm[i] += n_ - tc; tc = n_; } while (0)
+#else
+#define FT_STAMP(i) do { } while (0)
+#endif
+	for (int it = 0; it < nint; it++) {
+		fl_lds_barrier();
+		FT_STAMP(1); // barrier wait (= the rest of the other team's interval)
+		const int rel = it - (int)team; // team 1 runs one interval behind
+		if (rel < 0 || !team_live) continue;
+		const unsigned t = (unsigned)rel >> 1;
+		if (t >= nt) continue;
+		if ((rel & 1) == 0) { // stage: the window requested two intervals ago goes to LDS, the next one is requested
+			store_x(xv);
+			FT_STAMP(2); // wait for the window + LDS stores
+			if (t + 1 < nt) load_x(xv, t + 1);
+			FT_STAMP(3); // issue of the next window's loads
+		} else if (group_live) { compute(t); FT_STAMP(4); }
+	}
+#if FL_TIMING
+	if (lane == 0 && fl_timing_out && group_live) {
+#pragma unroll
+		for (int i = 0; i < 6; i++) atomicAdd(&fl_timing_out[i], tm[i]);
+		atomicAdd(&fl_timing_out[6], (unsigned long long)nt);
+		atomicAdd(&fl_timing_out[7], 1ull);
+	}
+#endif
+#undef FT_STAMP
+}
+
 // Chunk-major copies of a batch of traces for the decimations whose rows are far apart (see load_x above):
 //   dst[slot][trace][ci][j][lane] = x[trace][j D + 64 ci + lane]   (0 where 64 ci + lane >= D), D | N, j < N / D.
 // One thread per destination element group: reads are 256-byte runs, writes fully coalesced.

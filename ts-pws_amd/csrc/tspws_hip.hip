@@ -109,7 +109,8 @@ struct tspws_hip_plan {
 	unsigned acc2_blocks = 0;  // blocks of k_accumulate_parts
 	unsigned lds_blocks = 0;   // workgroups per trace slice of k_fwd_lds
 	unsigned n_fusable = 0;    // scales whose stacks the fused forward kernel keeps in registers
-	unsigned oct_wgs = 0, oct_n = 0; // k_fwd_oct: workgroups per trace slice, octaves
+	unsigned oct_wgs = 0, oct_n = 0; // k_fwd_oct / k_fwd_oct2: workgroups per trace slice, table entries
+	int oct_mode = 2;                // 1: k_fwd_oct (256 threads, voice subsets, two workgroups per CU), 2: k_fwd_oct2 (two-team pipeline)
 	size_t oct_lds = 0;
 	struct OctFwd *d_ofw = nullptr;
 	std::vector<unsigned char> ofw_host; // the OctFwd table (bytes; the struct is defined next to the kernel)
@@ -480,14 +481,14 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 			d.lds_bps = (NG + slots * GW - 1) / (slots * GW);
 			if (d.use_lds) boff += d.lds_bps * d.nsplit; else if (!d.use_oct) woff += d.ngw * d.nsplit;
 			poff += (unsigned long long)d.nsplit * d.Ns;
-			d.fuse_ok = (kind == 1 && d.use_lds && d.nsplit == 1 && d.D >= 2) ? 1u : 0u;
+			d.fuse_ok = (kind == 1 && d.use_lds && d.nsplit == 1) ? 1u : 0u;
 		}
 		p->fwd_waves = woff; p->lds_blocks = boff; p->npart = poff;
 		if (int rc = upload_oct_forward(p)) { tspws_hip_plan_destroy(p); return rc; }
 		for (unsigned s = 0; s < S; s++) p->n_fusable += p->sc[s].fuse_ok;
 		if (kind == 3 && !build_mfma_pairs(p)) { // a filter too long for the matrix kernel: VALU kernels
 			p->fwd_kind = 1; p->pairs.clear();
-			for (unsigned s = 0; s < S; s++) { p->sc[s].fuse_ok = (p->sc[s].use_lds && p->sc[s].nsplit == 1 && p->sc[s].D >= 2) ? 1u : 0u; p->n_fusable += p->sc[s].fuse_ok; }
+			for (unsigned s = 0; s < S; s++) { p->sc[s].fuse_ok = (p->sc[s].use_lds && p->sc[s].nsplit == 1) ? 1u : 0u; p->n_fusable += p->sc[s].fuse_ok; }
 		}
 	}
 	for (unsigned s = 0; s < S; s++) {
@@ -997,7 +998,19 @@ static_assert(FM_KQCAP == FM_KQCAP_HOST, "tap-step cap");
 static int build_oct_forward(tspws_hip_plan *p, std::vector<char> &is_oct)
 {
 	p->ofw_host.clear(); p->oct_wgs = 0; p->oct_n = 0; p->oct_lds = 0;
-	if (const char *e = getenv("TSPWS_FWD_OCT")) if (*e == '0') return 0;
+	// opt-in: measured on MI355X the octave-fused kernels do not beat k_fwd_lds yet (forward-transform notes)
+	{ const char *e = getenv("TSPWS_FWD_OCT"); if (!e || *e != '1') return 0; }
+	p->oct_mode = 2;
+	if (const char *e = getenv("TSPWS_OCT_MODE")) p->oct_mode = atoi(e) == 1 ? 1 : 2;
+	const bool m2 = p->oct_mode == 2;
+	// LDS of a work item with `rows` tap rows, tallest voice qmax, spread of a_v da: mode 1 one image of 64 outputs, mode 2 two
+	// team images of 32 outputs (+ pad rows for the operand prefetch)
+	auto x_rows = [&](unsigned qmax, unsigned da) { return m2 ? ((31 + qmax + da + 3) & ~3u) : ((63 + qmax + da + 7) & ~7u); };
+	auto lds_of = [&](unsigned rows, unsigned xr) {
+		return (size_t)rows * 64 * sizeof(double2) + (m2 ? 2 * (size_t)(xr + FT_XPAD) : (size_t)xr) * 64 * sizeof(double);
+	};
+	const unsigned xr_max = m2 ? FT_XRMAX : FO_XRMAX;
+	const size_t lds_max = m2 ? FT_LDS_MAX : FO_LDS_MAX;
 	std::vector<OctFwd> tab;
 	unsigned wg = 0;
 	for (unsigned s = 0; s < p->S;) {
@@ -1032,9 +1045,9 @@ static int build_oct_forward(tspws_hip_plan *p, std::vector<char> &is_oct)
 					if (bi == bins.size()) bins.emplace_back();
 					Bin &bn = bins[bi];
 					const unsigned amax2 = std::max(bn.amax, a[v]), amin2 = std::min(bn.amin, a[v]), qmax2 = std::max(bn.qmax, qr[v]);
-					const unsigned xr = (63 + qmax2 + (amax2 - amin2) + 7) & ~7u;
-					const size_t lds = (size_t)(bn.rows + qr[v]) * 64 * sizeof(double2) + (size_t)xr * 64 * sizeof(double);
-					if (xr > FO_XRMAX || lds > FO_LDS_MAX || bn.vs.size() >= FO_VMAX) {
+					const unsigned xr = x_rows(qmax2, amax2 - amin2);
+					const size_t lds = lds_of(bn.rows + qr[v], xr);
+					if (xr > xr_max || lds > lds_max || bn.vs.size() >= FO_VMAX) {
 						if (bn.vs.empty()) { ok = false; bins.pop_back(); break; } // does not even fit alone
 						continue;
 					}
@@ -1061,7 +1074,7 @@ static int build_oct_forward(tspws_hip_plan *p, std::vector<char> &is_oct)
 			if (ok) {
 				for (OctFwd &o : items) {
 					o.wg_off = wg; wg += o.MC * o.nob;
-					p->oct_lds = std::max(p->oct_lds, (size_t)o.trows * 64 * sizeof(double2) + (size_t)o.XR * 64 * sizeof(double));
+					p->oct_lds = std::max(p->oct_lds, lds_of(o.trows, o.XR));
 					tab.push_back(o);
 				}
 				for (unsigned v = s; v < e; v++) is_oct[v] = 1;
@@ -1113,6 +1126,8 @@ static int upload_oct_forward(tspws_hip_plan *p)
 	HIP_TRY(hipMemcpy(p->d_ofw, tab, p->ofw_host.size(), hipMemcpyHostToDevice));
 	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_oct<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FO_LDS_MAX));
 	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_oct<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FO_LDS_MAX));
+	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_oct2<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS_MAX));
+	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_oct2<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS_MAX));
 	return 0;
 }
 
@@ -1210,7 +1225,9 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 	}
 	if (p->oct_wgs) {
 		unsigned tps = (unsigned)std::min<size_t>(ntr, 32);
-		while (tps > 1 && (size_t)p->oct_wgs * ((ntr + tps - 1) / tps) < 256) tps = (tps + 1) / 2; // at least one workgroup per CU
+		// mode 2: one workgroup per CU, so a single slice is best once half the CUs have work; mode 1: two per CU
+		const size_t want = p->oct_mode == 2 ? 128 : 256;
+		while (tps > 1 && (size_t)p->oct_wgs * ((ntr + tps - 1) / tps) < want) tps = (tps + 1) / 2;
 		if (const char *e = getenv("TSPWS_OCT_TPS")) tps = (unsigned)std::max(1, atoi(e));
 		const size_t per_launch = std::min<size_t>((size_t)tps * 65535, 65535);
 		constexpr int TI = sizeof(TIn) == 8 ? 1 : 0;
@@ -1234,8 +1251,12 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 				}
 				hipLaunchKernelGGL((k_chunk_major<TIn>), dim3((unsigned)((big + 255) / 256), nt, cmj.n), dim3(256), 0, so, d_x + t0 * ld, ld, nt, p->N, cmj, xcm);
 			}
-			hipLaunchKernelGGL((k_fwd_oct<TIn>), dim3(p->oct_wgs, (nt + tps - 1) / tps), dim3(FO_NT), p->oct_lds, so, d_x + t0 * ld, ld, nt, tps, p->N,
-			                   p->d_ofw, p->oct_n, p->d_w, d_part + t0 * p->npart, p->npart, (const TIn *)xcm, nt);
+			if (p->oct_mode == 2)
+				hipLaunchKernelGGL((k_fwd_oct2<TIn>), dim3(p->oct_wgs, (nt + tps - 1) / tps), dim3(FT_NT), p->oct_lds, so, d_x + t0 * ld, ld, nt, tps, p->N,
+				                   p->d_ofw, p->oct_n, p->d_w, d_part + t0 * p->npart, p->npart, (const TIn *)xcm, nt);
+			else
+				hipLaunchKernelGGL((k_fwd_oct<TIn>), dim3(p->oct_wgs, (nt + tps - 1) / tps), dim3(FO_NT), p->oct_lds, so, d_x + t0 * ld, ld, nt, tps, p->N,
+				                   p->d_ofw, p->oct_n, p->d_w, d_part + t0 * p->npart, p->npart, (const TIn *)xcm, nt);
 		}
 	}
 	// the direct kernel first: its few hundred long, latency-bound workgroups (no LDS, 88 VGPRs) get their slots and the
