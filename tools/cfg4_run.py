@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""BASELINE configs[3]: 10k x 131072, Mexican hat, two-stage K=10 + jackknife n=10 d=1; a few calls, for rocprofv3."""
+import ctypes as C
+import importlib
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np
+import torch
+import abi
+
+tspws = importlib.import_module("ts-pws_amd")
+lib = tspws.load()
+N, mtr = 131072, int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+p = tspws.resolve(abi.default_params(type=-3, Kmax=10, jackknife_n=10, jackknife_d=1), N)
+pl = tspws.Plan(p, N)
+X = tspws.synth(mtr, N, seed=1)
+times = (1262304000 + 86400 * np.arange(mtr)).astype(np.int64)
+Cn = 10
+sel = np.zeros((Cn, mtr), np.int8)
+assert lib.tspws_jackknife_plan(sel.ctypes.data, times.ctypes.data, mtr, 1, 10, Cn) == 0
+jl = torch.empty((Cn, N), dtype=torch.float32, device="cuda")
+jt = torch.empty((Cn, N), dtype=torch.float32, device="cuda")
+jm = np.zeros(Cn, np.uint32)
+
+
+def jk():
+    pl.stack(X)
+    tspws.check(lib.tspws_hip_jackknife(pl.h, C.byref(pl.params), X.data_ptr(), N, mtr, sel.ctypes.data, Cn, jl.data_ptr(), jt.data_ptr(),
+                                        jm.ctypes.data, None))
+
+
+jk()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3):
+    jk()
+torch.cuda.synchronize()
+print("cfg4 ms/call", (time.perf_counter() - t0) / 3 * 1e3)

@@ -409,8 +409,12 @@ __global__ void __launch_bounds__(256) k_gather_parts(const double2 *__restrict_
 __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restrict__ part, size_t npart, const ScaleDesc *__restrict__ sc,
                                                           unsigned S, unsigned ntr, double2 *__restrict__ ST, double2 *__restrict__ PS,
                                                           int zero_first, int fused, const double2 *__restrict__ fzST,
-                                                          const double2 *__restrict__ fzPS, size_t fz_stride, unsigned nslices)
+                                                          const double2 *__restrict__ fzPS, size_t fz_stride, unsigned nslices,
+                                                          size_t y_part, size_t y_stack)
 {
+	// blockIdx.y = independent stack (jackknife replica): its ntr transformed traces start y_part further in `part`, its
+	// ST / PS y_stack further (the fused forward kernel wrote the fuse_ok scales there directly: fused == 1)
+	part += (size_t)blockIdx.y * y_part; ST += (size_t)blockIdx.y * y_stack; PS += (size_t)blockIdx.y * y_stack;
 	unsigned lo = 0, hi = S;
 	while (hi - lo > 1) {
 		const unsigned mid = (lo + hi) >> 1;

@@ -42,8 +42,10 @@ struct OctDesc {
 template <int NREC>
 __global__ void __launch_bounds__(256) k_inv_poly(const double2 *__restrict__ Y, size_t ncoef, unsigned N, const ScaleDesc *__restrict__ sc,
                                                   const OctDesc *__restrict__ oc, unsigned noct, const double2 *__restrict__ wd,
-                                                  double *__restrict__ obuf, size_t slot_stride, unsigned total_waves)
+                                                  double *__restrict__ obuf, size_t slot_stride, unsigned total_waves, size_t y_coef,
+                                                  size_t y_obuf)
 {
+	Y += (size_t)blockIdx.y * y_coef; obuf += (size_t)blockIdx.y * y_obuf; // blockIdx.y = independent reconstruction set
 	constexpr int R = INV_R;
 	const unsigned lane = threadIdx.x & 63;
 	const unsigned wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -142,10 +144,11 @@ __global__ void __launch_bounds__(256) k_inv_poly(const double2 *__restrict__ Y,
 
 // x^[rec][n] = sum of the obuf rows (fixed order)
 __global__ void __launch_bounds__(256) k_inv_combine(const double *__restrict__ obuf, size_t slot_stride, unsigned nslots, size_t total,
-                                                     double *__restrict__ xout)
+                                                     double *__restrict__ xout, size_t y_obuf, size_t y_out)
 {
 	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= total) return;
+	obuf += (size_t)blockIdx.y * y_obuf; xout += (size_t)blockIdx.y * y_out;
 	double a = obuf[i];
 	for (unsigned s = 1; s < nslots; s++) a += obuf[(size_t)s * slot_stride + i];
 	xout[i] = a;

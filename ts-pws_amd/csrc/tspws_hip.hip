@@ -1405,13 +1405,13 @@ extern "C" int tspws_hip_accumulate(tspws_hip_plan *p, const double *d_Y, size_t
 
 // launches k_accumulate_parts for `nb` transformed traces; fz = what forward_parts left behind (may be NULL / not applied)
 static void launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb, double2 *ST, double2 *PS, int zero_first, const FuseOut *fz,
-                              unsigned nslices, hipStream_t st)
+                              unsigned nslices, hipStream_t st, unsigned nbatch = 1, size_t y_part = 0, size_t y_stack = 0)
 {
 	const bool on = fz && fz->applied;
 	const bool direct = on && fz->accST == ST; // the single slice went straight into ST / PS
-	hipLaunchKernelGGL(k_accumulate_parts, dim3(p->acc2_blocks), dim3(256), 0, st, part, p->npart, p->d_sc, p->S, nb, ST, PS, zero_first,
+	hipLaunchKernelGGL(k_accumulate_parts, dim3(p->acc2_blocks, nbatch), dim3(256), 0, st, part, p->npart, p->d_sc, p->S, nb, ST, PS, zero_first,
 	                   on ? (direct ? 1 : 2) : 0, on ? (const double2 *)fz->accST : nullptr, on ? (const double2 *)fz->accPS : nullptr,
-	                   on ? fz->stride : (size_t)0, nslices);
+	                   on ? fz->stride : (size_t)0, nslices, y_part, y_stack);
 }
 
 // slice length of the fused forward kernel for a batch of nb traces: whole batch when it is small (two-stage: the K
@@ -1489,10 +1489,14 @@ extern "C" int tspws_hip_stacks_float(tspws_hip_plan *p, const float *d_x, size_
 // mode 0: wu==2 biased, 1: wu==1, 2: general power, 3: unbiased (K>1)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_weight(double2 *__restrict__ OUT, const double2 *__restrict__ ST, const double2 *__restrict__ PS,
-                                                size_t ncoef, int mode, double K, double M, double wu)
+                                                size_t ncoef, int mode, double K, double M, double wu, const double *__restrict__ Mv,
+                                                size_t y_out, size_t y_stack)
 {
 	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= ncoef) return;
+	// blockIdx.y = independent stack (jackknife replica) with its own trace count M
+	OUT += (size_t)blockIdx.y * y_out; ST += (size_t)blockIdx.y * y_stack; PS += (size_t)blockIdx.y * y_stack;
+	if (Mv) M = Mv[blockIdx.y];
 	const double2 st = ST[i], ps = PS[i];
 	double a;
 	if (mode == 0) {
@@ -1527,9 +1531,17 @@ extern "C" int tspws_hip_weight(tspws_hip_plan *p, double *d_OUT, const double *
 	else if (wu == 1) mode = 1;
 	else mode = 2;
 	hipLaunchKernelGGL(k_weight, dim3((unsigned)((p->ncoef + 255) / 256)), dim3(256), 0, S_(s), (double2 *)d_OUT, (const double2 *)d_ST,
-	                   (const double2 *)d_PS, p->ncoef, mode, (double)K, (double)M, wu);
+	                   (const double2 *)d_PS, p->ncoef, mode, (double)K, (double)M, wu, (const double *)nullptr, (size_t)0, (size_t)0);
 	HIP_TRY(hipGetLastError());
 	return 0;
+}
+
+static int weight_mode(double wu, int unbiased, unsigned K)
+{
+	if (wu == 2 && unbiased && K != 1) return 3; // selection rule ts_pws1f_lib.c:226-228, K==1 falls back :972
+	if (wu == 2) return 0;
+	if (wu == 1) return 1;
+	return 2;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1540,10 +1552,12 @@ extern "C" int tspws_hip_weight(tspws_hip_plan *p, double *d_OUT, const double *
 // ------------------------------------------------------------------------------------------
 template <int NREC>
 __global__ void __launch_bounds__(256) k_inverse_generic(const double2 *__restrict__ Y, size_t ncoef, unsigned N, const ScaleDesc *__restrict__ sc,
-                                                         unsigned S, const double2 *__restrict__ wd, double *__restrict__ xout, int only_slow)
+                                                         unsigned S, const double2 *__restrict__ wd, double *__restrict__ xout, int only_slow,
+                                                         size_t y_coef, size_t y_out)
 {
 	const unsigned n = blockIdx.x * 256 + threadIdx.x;
 	if (n >= N) return;
+	Y += (size_t)blockIdx.y * y_coef; xout += (size_t)blockIdx.y * y_out; // blockIdx.y = independent reconstruction set
 	double tot[NREC];
 #pragma unroll
 	for (int r = 0; r < NREC; r++) tot[r] = 0;
@@ -1648,26 +1662,29 @@ static bool use_generic_inverse()
 	return v == 1;
 }
 
+// nb independent NREC-set reconstructions in one launch (grid.y): set j reads Y + j NREC ncoef, writes x + j NREC N
 template <int NREC>
-static int inverse_launch(tspws_hip_plan *p, const double2 *Y, double *x, hipStream_t st)
+static int inverse_launch(tspws_hip_plan *p, const double2 *Y, double *x, hipStream_t st, unsigned nb = 1)
 {
-	const unsigned nb = (p->N + 255) / 256;
+	const unsigned nbx = (p->N + 255) / 256;
+	const size_t slot = (size_t)NREC * p->N;
 	if (use_generic_inverse() || p->inv_noct == 0) {
-		hipLaunchKernelGGL(k_inverse_generic<NREC>, dim3(nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->S, p->d_wd, x, 0);
+		hipLaunchKernelGGL(k_inverse_generic<NREC>, dim3(nbx, nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->S, p->d_wd, x, 0,
+		                   (size_t)NREC * p->ncoef, slot);
 		return 0;
 	}
 	const unsigned nslots = p->inv_noct + (p->inv_ngeneric ? 1 : 0);
-	const size_t slot = (size_t)NREC * p->N;
 	void *v;
-	int rc = scratch(p, SCR_OBUF, (size_t)nslots * slot * sizeof(double), &v);
+	int rc = scratch(p, SCR_OBUF, (size_t)nb * nslots * slot * sizeof(double), &v);
 	if (rc) return rc;
 	double *obuf = (double *)v;
-	hipLaunchKernelGGL(k_inv_poly<NREC>, dim3((p->inv_waves + 3) / 4), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->d_oc, p->inv_noct,
-	                   p->d_wd, obuf, slot, p->inv_waves);
+	hipLaunchKernelGGL(k_inv_poly<NREC>, dim3((p->inv_waves + 3) / 4, nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->d_oc, p->inv_noct,
+	                   p->d_wd, obuf, slot, p->inv_waves, (size_t)NREC * p->ncoef, (size_t)nslots * slot);
 	if (p->inv_ngeneric)
-		hipLaunchKernelGGL(k_inverse_generic<NREC>, dim3(nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->S, p->d_wd,
-		                   obuf + (size_t)p->inv_noct * slot, 1);
-	hipLaunchKernelGGL(k_inv_combine, dim3((unsigned)((slot + 255) / 256)), dim3(256), 0, st, obuf, slot, nslots, slot, x);
+		hipLaunchKernelGGL(k_inverse_generic<NREC>, dim3(nbx, nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->S, p->d_wd,
+		                   obuf + (size_t)p->inv_noct * slot, 1, (size_t)NREC * p->ncoef, (size_t)nslots * slot);
+	hipLaunchKernelGGL(k_inv_combine, dim3((unsigned)((slot + 255) / 256), nb), dim3(256), 0, st, obuf, slot, nslots, slot, x,
+	                   (size_t)nslots * slot, slot);
 	return 0;
 }
 
@@ -1675,12 +1692,14 @@ extern "C" int tspws_hip_inverse(tspws_hip_plan *p, const double *d_Y, size_t nr
 {
 	if (!p || !d_Y || !d_x) return fail(TSPWS_E_ARG, "inverse: NULL");
 	HIP_TRY(hipSetDevice(p->device));
-	size_t r = 0;
 	int rc;
-	for (; r + 2 <= nrec; r += 2)
-		if ((rc = inverse_launch<2>(p, (const double2 *)d_Y + r * p->ncoef, d_x + r * p->N, S_(s)))) return rc;
-	if (r < nrec)
-		if ((rc = inverse_launch<1>(p, (const double2 *)d_Y + r * p->ncoef, d_x + r * p->N, S_(s)))) return rc;
+	const size_t pairs = nrec / 2;
+	for (size_t r = 0; r < pairs; r += 32768) { // pairs of coefficient sets share the tap reads; all pairs in one launch
+		const unsigned nb = (unsigned)std::min<size_t>(pairs - r, 32768);
+		if ((rc = inverse_launch<2>(p, (const double2 *)d_Y + 2 * r * p->ncoef, d_x + 2 * r * p->N, S_(s), nb))) return rc;
+	}
+	if (nrec & 1)
+		if ((rc = inverse_launch<1>(p, (const double2 *)d_Y + (nrec - 1) * p->ncoef, d_x + (nrec - 1) * p->N, S_(s)))) return rc;
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -1691,8 +1710,9 @@ __global__ void __launch_bounds__(256) k_epilogue(float *__restrict__ ls, float 
 {
 	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (n >= N) return;
-	if (ls) ls[n] = (float)xst[n] / mtr;
-	if (ts) ts[n] = (float)xout[n];
+	const size_t o = (size_t)blockIdx.y * N; // blockIdx.y = row of a batch of outputs
+	if (ls) ls[o + n] = (float)xst[o + n] / mtr;
+	if (ts) ts[o + n] = (float)xout[o + n];
 }
 
 extern "C" int tspws_hip_epilogue(float *d_ls, float *d_ts, const double *d_xst, const double *d_xout, size_t N, unsigned mtr, void *s)
@@ -1968,10 +1988,13 @@ __global__ void __launch_bounds__(256) k_combine_classes(const double *__restric
 }
 
 // replica linear stack in the time domain, :799-811: (sum_g P[g]) * (1/K)
-__global__ void __launch_bounds__(256) k_jk_linear(const double *__restrict__ P, unsigned Kmax, size_t N, double invK, float *__restrict__ out)
+__global__ void __launch_bounds__(256) k_jk_linear(const double *__restrict__ P, unsigned Kmax, size_t N, const double *__restrict__ Mv,
+                                                   float *__restrict__ out)
 {
 	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (n >= N) return;
+	P += (size_t)blockIdx.y * Kmax * N; out += (size_t)blockIdx.y * N; // blockIdx.y = replica
+	const double invK = 1. / Mv[blockIdx.y];
 	double acc = P[n];
 	for (unsigned g = 1; g < Kmax; g++) acc += P[(size_t)g * N + n];
 	out[n] = (float)(acc * invK);
@@ -2049,9 +2072,12 @@ static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d
 			for (unsigned id = 0; id < ncls; id++) if (cls_sig[id][c] == g) cols.push_back(id);
 		}
 	rp[(size_t)C * KM] = (unsigned)cols.size();
-	if ((rc = scratch(pl, SCR_JKP, (size_t)C * KM * N * sizeof(double) + (rp.size() + cols.size() + 1) * sizeof(unsigned), &v))) return rc;
-	double *d_P = (double *)v;
-	unsigned *d_rp = (unsigned *)(d_P + (size_t)C * KM * N), *d_cols = d_rp + rp.size();
+	if ((rc = scratch(pl, SCR_JKP, ((size_t)C * KM * N + C) * sizeof(double) + (rp.size() + cols.size() + 1) * sizeof(unsigned), &v))) return rc;
+	double *d_P = (double *)v, *d_Mv = d_P + (size_t)C * KM * N; // partial stacks of every replica, then the replicas' trace counts
+	unsigned *d_rp = (unsigned *)(d_Mv + C), *d_cols = d_rp + rp.size();
+	std::vector<double> h_Mv(C);
+	for (unsigned c = 0; c < C; c++) h_Mv[c] = (double)Kc[c];
+	HIP_TRY(hipMemcpyAsync(d_Mv, h_Mv.data(), C * sizeof(double), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(d_rp, rp.data(), rp.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
 	if (!cols.empty()) HIP_TRY(hipMemcpyAsync(d_cols, cols.data(), cols.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
 	for (unsigned r0 = 0; r0 < C * KM; r0 += 65535) {
@@ -2078,20 +2104,18 @@ static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d
 		FuseOut fz;
 		fz.accST = (double2 *)STr; fz.accPS = (double2 *)STr + nc; fz.stride = 2 * nc; fz.tps = KM;
 		if ((rc = forward_parts<double>(pl, d_P + (size_t)c0 * KM * N, (size_t)nr * KM, N, part, st, fuse ? &fz : nullptr))) return rc;
-		for (unsigned j = 0; j < nr; j++) {
-			const unsigned c = c0 + j;
-			h_mtr_out[c] = (unsigned)Kc[c];
-			double *ST = STr + (size_t)j * 4 * nc, *PS = ST + 2 * nc;
-			FuseOut fj = fz; // this replica's slice, written directly
-			fj.accST = (double2 *)ST; fj.accPS = (double2 *)PS;
-			launch_accumulate(pl, (const double2 *)(part + (size_t)j * KM * pl->npart), KM, (double2 *)ST, (double2 *)PS, 1, &fj, 1, st);
-			if ((rc = tspws_hip_weight(pl, OUT + (size_t)j * 2 * nc, ST, PS, KM, (unsigned)Kc[c], p->wu, p->unbiased, s))) return rc;
-			hipLaunchKernelGGL(k_jk_linear, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_P + (size_t)c * KM * N, KM, N, 1. / (double)Kc[c],
-			                   d_ls_out + (size_t)c * N);
-		}
+		for (unsigned j = 0; j < nr; j++) h_mtr_out[c0 + j] = (unsigned)Kc[c0 + j];
+		// the replicas of the batch side by side in every launch (grid.y): stacks of the scales the fused kernel left out,
+		// weights with each replica's trace count, time-domain linear stacks, inverses two replicas per tap read, outputs
+		FuseOut fj = fz; // replica j's slice went straight into its ST / PS planes
+		launch_accumulate(pl, (const double2 *)part, KM, (double2 *)STr, (double2 *)STr + nc, 1, &fj, 1, st, nr, (size_t)KM * pl->npart, 2 * nc);
+		hipLaunchKernelGGL(k_weight, dim3((unsigned)((nc + 255) / 256), nr), dim3(256), 0, st, (double2 *)OUT, (const double2 *)STr,
+		                   (const double2 *)STr + nc, nc, weight_mode(p->wu, p->unbiased, KM), (double)KM, 0.0, p->wu, (const double *)(d_Mv + c0), nc, 2 * nc);
+		hipLaunchKernelGGL(k_jk_linear, dim3((unsigned)((N + 255) / 256), nr), dim3(256), 0, st, d_P + (size_t)c0 * KM * N, KM, N, (const double *)(d_Mv + c0),
+		                   d_ls_out + (size_t)c0 * N);
 		if ((rc = tspws_hip_inverse(pl, OUT, nr, xr, s))) return rc;
-		for (unsigned j = 0; j < nr; j++)
-			if ((rc = tspws_hip_epilogue(nullptr, d_ts_out + (size_t)(c0 + j) * N, nullptr, xr + (size_t)j * N, N, 1, s))) return rc;
+		hipLaunchKernelGGL(k_epilogue, dim3((unsigned)((N + 255) / 256), nr), dim3(256), 0, st, (float *)nullptr, d_ts_out + (size_t)c0 * N, (const double *)nullptr,
+		                   (const double *)xr, N, 1.0f);
 	}
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st)); // host tables above go out of scope
