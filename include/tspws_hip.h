@@ -171,6 +171,12 @@ int  tspws_hip_jackknife(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_
                          size_t mtr, const char *h_sel, unsigned C,
                          float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *stream);
 
+/* Optional: announce, BEFORE the two-stage tspws_hip_stack_local of the whole ensemble, the jackknife that will follow on
+ * the same device-resident traces.  That stack_local then streams the traces ONCE for its own groups and for every
+ * replica (the reference walks them 1 + C times, :719-831), and tspws_hip_jackknife with the same selection reuses the
+ * class sums.  The traces must not change between the two calls.  No-op for single-stage parameters. */
+int  tspws_hip_jackknife_prepare(tspws_hip_plan *plan, const t_tsPWS *p, const char *h_sel, unsigned C, size_t mtr);
+
 /* ---- random subsampling ---------------------------------------------------------------------- */
 /* Host: keep K of J traces at random with libc rand(), flipping whichever symbol is rarer.
  * SubsamplingPlan, ts_pws1f_lib.c:355-383 (same rand() call order, so the same masks from the same state). */

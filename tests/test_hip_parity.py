@@ -649,3 +649,46 @@ def test_forward_octave_fused_kernels(lib, torch, kw, N, ntr, mode, monkeypatch)
     torch.cuda.synchronize()
     b = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(Kmax=2, unbiased=1, **kw), X)
     assert abi.relerr(ts.cpu().numpy(), b["tsPWS"]) < TOL32 and abi.relerr(ls.cpu().numpy(), b["ls"]) < TOL32
+
+
+@pytest.mark.gpu
+def test_prepared_jackknife_shares_the_streaming_pass(lib, torch):
+    """tspws_hip_jackknife_prepare: the two-stage stack streams the traces once for its own groups and for every replica; the
+    jackknife that follows reuses the class sums.  Same replicas as the stand-alone jackknife (which streams again), same
+    main outputs as the plain call, and a selection that does not match falls back to its own pass."""
+    mtr, N, K, n = 300, 4096, 6, 5
+    p = tspws.resolve(abi.default_params(Kmax=K, unbiased=1, jackknife_n=n, jackknife_d=1), N)
+    pl = tspws.Plan(p, N)
+    Xd = tspws.synth(mtr, N, seed=13)
+    rng = np.random.default_rng(5)
+    times = (1262304000 + 86400 * np.sort(rng.integers(0, 2 * 365, mtr))).astype(np.int64)
+    Cn = n
+    sel = np.zeros((Cn, mtr), np.int8)
+    assert lib.tspws_jackknife_plan(sel.ctypes.data, times.ctypes.data, mtr, 1, n, Cn) == 0
+
+    def jack(selection):
+        jl = torch.empty((Cn, N), dtype=torch.float32, device="cuda")
+        jt = torch.empty((Cn, N), dtype=torch.float32, device="cuda")
+        jm = np.zeros(Cn, np.uint32)
+        tspws.check(lib.tspws_hip_jackknife(pl.h, C.byref(pl.params), Xd.data_ptr(), N, mtr, selection.ctypes.data, Cn, jl.data_ptr(), jt.data_ptr(),
+                                            jm.ctypes.data, None), "jackknife")
+        torch.cuda.synchronize()
+        return jl.cpu().numpy(), jt.cpu().numpy(), jm
+
+    ls0, ts0 = [t.cpu().numpy() for t in pl.stack(Xd)]       # plain call, stand-alone jackknife
+    l0, t0, m0 = jack(sel)
+    tspws.check(lib.tspws_hip_jackknife_prepare(pl.h, C.byref(pl.params), sel.ctypes.data, Cn, mtr), "prepare")
+    ls1, ts1 = [t.cpu().numpy() for t in pl.stack(Xd)]       # prepared: one pass for groups + replicas
+    l1, t1, m1 = jack(sel)
+    np.testing.assert_array_equal(m0, m1)
+    assert abi.relerr(ls1, ls0) < 1e-6 and abi.relerr(ts1, ts0) < 1e-6   # class sums instead of chunk sums: rounding only
+    np.testing.assert_array_equal(l1, l0)                                  # replicas: the same class sums either way
+    np.testing.assert_array_equal(t1, t0)
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(Kmax=K, unbiased=1, jackknife_n=n, jackknife_d=1), Xd.cpu().numpy(), times=times)
+    assert abi.relerr(ts1, want["tsPWS"]) < TOL32 and max(abi.relerr(t1[c], want["jk_ts"][c]) for c in range(Cn)) < TOL32
+    # a different selection after a prepared stack: not the cached classes
+    sel2 = sel[::-1].copy()
+    tspws.check(lib.tspws_hip_jackknife_prepare(pl.h, C.byref(pl.params), sel.ctypes.data, Cn, mtr), "prepare")
+    pl.stack(Xd)
+    l2, t2, m2 = jack(sel2)
+    np.testing.assert_array_equal(t2, t0[::-1])

@@ -53,6 +53,8 @@ jm = np.zeros(Cn, np.uint32)
 
 
 def jk():
+    # announce the replicas first: the stack then streams the traces once for its groups and all replicas
+    tspws.check(lib.tspws_hip_jackknife_prepare(pl.h, C.byref(pl.params), sel.ctypes.data, Cn, mtr), "jackknife_prepare")
     pl.stack(X)
     tspws.check(lib.tspws_hip_jackknife(pl.h, C.byref(pl.params), X.data_ptr(), N, mtr, sel.ctypes.data, Cn, jl.data_ptr(), jt.data_ptr(),
                                         jm.ctypes.data, None))

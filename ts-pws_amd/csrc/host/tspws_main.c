@@ -100,6 +100,19 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 	if (tspws->lrm) TRY(tspws_hip_remove_mean(d_sig, mtr, (size_t)max, ld, NULL));
 	if (do_fold || tspws->lrm) TRY(tspws_hip_download(in->sigall, d_sig, mtr * ld * sizeof(float), NULL));
 
+	/* jackknife masks first (host, :385-430): announced to the engine, the stack below streams the traces once for its own
+	 * groups and for every replica */
+	int jk_ready = 0;
+	if (tspws->jackknife_n > 0 && tspws->jackknife_d > 0 && tspws->Kmax && tspws->Kmax <= mtr && out->M && out->ls_subsmpl &&
+	    out->tsPWS_subsmpl && out->mtr_subsmpl) {
+		sel = (char *)malloc((size_t)out->M * mtr);
+		if (!sel) { rc = TSPWS_E_NOMEM; goto done; }
+		if (tspws_jackknife_plan(sel, in->time, mtr, tspws->jackknife_d, tspws->jackknife_n, out->M) == 0) {
+			jk_ready = 1;
+			TRY(tspws_hip_jackknife_prepare(plan, tspws, sel, out->M, mtr));
+		}
+	}
+
 	TRY(tspws_hip_stack_local(plan, tspws, d_sig, ld, mtr, 0, mtr, NULL));
 	TRY(tspws_hip_stack_finish(plan, tspws, mtr, d_out, d_out + ld, NULL));
 	TRY(tspws_hip_download(out->ls, d_out, ld * sizeof(float), NULL));
@@ -140,10 +153,7 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 	if (tspws->jackknife_n > 0 && tspws->jackknife_d > 0 && tspws->Kmax && tspws->Kmax <= mtr) {
 		const unsigned C = out->M;
 		if (C && out->ls_subsmpl && out->tsPWS_subsmpl && out->mtr_subsmpl) {
-			sel = (char *)malloc((size_t)C * mtr);
-			if (!sel) { rc = TSPWS_E_NOMEM; goto done; }
-			const int pr = tspws_jackknife_plan(sel, in->time, mtr, tspws->jackknife_d, tspws->jackknife_n, C);
-			if (pr == 0) {
+			if (jk_ready) {
 				TRY(tspws_hip_alloc((void **)&d_jk, 2 * (size_t)C * ld * sizeof(float), dev));
 				TRY(tspws_hip_jackknife(plan, tspws, d_sig, ld, mtr, sel, C, d_jk, d_jk + (size_t)C * ld, out->mtr_subsmpl, NULL));
 				stage = (float *)malloc(2 * (size_t)C * ld * sizeof(float));

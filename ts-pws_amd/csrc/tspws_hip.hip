@@ -96,7 +96,7 @@ struct Chunk { // one streaming work item of the partial-stack kernel
 	unsigned row;          // destination row (group / class)
 };
 
-enum { SCR_Y = 0, SCR_PART, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_XCM, SCR_N };
+enum { SCR_Y = 0, SCR_PART, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_XCM, SCR_JKTAB, SCR_N };
 
 struct tspws_hip_plan {
 	int device = 0, type = -1;
@@ -152,6 +152,24 @@ struct tspws_hip_plan {
 	bool ck_valid = false, ck_dev = false;
 	hipEvent_t ck_ev = nullptr;
 	hipStream_t ck_stream = nullptr;
+	// class sums of the last masked pass over the traces (jackknife / two-stage subsampling) and, when a jackknife was
+	// announced with tspws_hip_jackknife_prepare, of the plain two-stage groups as well: ONE streaming pass then serves
+	// the stack and all its replicas
+	struct ClassSums {
+		bool valid = false, has_main = false;
+		const float *d_x = nullptr;
+		size_t ld = 0, mtr = 0;
+		unsigned C = 0, KM = 0, ncls = 0;
+		std::vector<char> sel;                          // the selection the classes were built from
+		std::vector<std::vector<unsigned short>> sig;   // per class: group in each replica (0xFFFF = deleted) [+ plain group]
+		std::vector<size_t> Kc;                         // traces per replica
+		std::vector<Chunk> chunks;                      // host tables stay alive while copies may be in flight
+		std::vector<unsigned> row_first, rp, cols;
+	} cs;
+	bool jk_prepared = false;
+	std::vector<char> jk_sel;
+	unsigned jk_C = 0, jk_KM = 0;
+	size_t jk_mtr = 0;
 	// blocks of exported slots (tspws_hip_reduce_buffer hands out SCR_P / SCR_STPS) that were outgrown: a caller may
 	// still hold the old pointer (e.g. as the buffer of an in-flight collective), so they live until plan_destroy
 	std::vector<void *> retired;
@@ -1727,6 +1745,9 @@ extern "C" int tspws_hip_epilogue(float *d_ls, float *d_ts, const double *d_xst,
 // whole call on device-resident traces
 // ------------------------------------------------------------------------------------------
 static bool is_two_stage(const t_tsPWS *p, size_t mtr_global) { return !(!p->Kmax || p->Kmax > mtr_global); }
+static int class_sums(tspws_hip_plan *pl, unsigned KM, const float *d_x, size_t ld, size_t mtr, const char *h_sel, unsigned C, bool with_main,
+                      hipStream_t st);
+static int combine_classes(tspws_hip_plan *pl, unsigned col0, unsigned col1, double *d_P, hipStream_t st);
 
 extern "C" int tspws_hip_reduce_buffer(tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, double **d_buf, size_t *nd)
 {
@@ -1753,6 +1774,16 @@ extern "C" int tspws_hip_stack_local(tspws_hip_plan *pl, const t_tsPWS *p, const
 	if ((rc = tspws_hip_reduce_buffer(pl, p, mtr_global, &buf, &nd))) return rc;
 	if (is_two_stage(p, mtr_global)) {
 		if (!mtr_local) { HIP_TRY(hipMemsetAsync(buf, 0, nd * sizeof(double), S_(s))); return 0; }
+		if (pl->jk_prepared) { // a jackknife of these traces follows: one pass for the groups and all replicas
+			const bool fits = first == 0 && mtr_local == mtr_global && mtr_local == pl->jk_mtr && p->Kmax == pl->jk_KM;
+			pl->jk_prepared = false;
+			if (fits) {
+				HIP_TRY(hipSetDevice(pl->device));
+				if ((rc = class_sums(pl, p->Kmax, d_x, ld, mtr_local, pl->jk_sel.data(), pl->jk_C, true, S_(s)))) return rc;
+				return combine_classes(pl, pl->jk_C, pl->jk_C + 1, buf, S_(s));
+			}
+		}
+		pl->cs.valid = false; // class sums of an earlier prepared call are no longer vouched for
 		return tspws_hip_partial_stacks(pl, d_x, ld, mtr_local, first, mtr_global, p->Kmax, buf, pl->N, s);
 	}
 	if (!mtr_local) { HIP_TRY(hipMemsetAsync(buf, 0, nd * sizeof(double), S_(s))); return 0; }
@@ -2000,6 +2031,107 @@ __global__ void __launch_bounds__(256) k_jk_linear(const double *__restrict__ P,
 	out[n] = (float)(acc * invK);
 }
 
+// ONE pass over the traces for any number of masked two-stage replicas: traces with the same destination group in every
+// replica form a class (maximal runs of consecutive traces; equal signatures of separate runs share a class), the
+// streaming kernel sums every class once, and each (replica, group) partial stack is a sum of class sums.
+// with_main: the plain two-stage groups of ALL traces (ts_pws1f_lib.c:876) are one more signature column.
+static int class_sums(tspws_hip_plan *pl, unsigned KM, const float *d_x, size_t ld, size_t mtr, const char *h_sel, unsigned C, bool with_main,
+                      hipStream_t st)
+{
+	tspws_hip_plan::ClassSums &cs = pl->cs;
+	cs.valid = false;
+	const size_t N = pl->N;
+	const unsigned W = C + (with_main ? 1u : 0u);
+	// signature of trace i: group index in every replica (0xFFFF = deleted)
+	cs.Kc.assign(C, 0);
+	for (unsigned c = 0; c < C; c++) for (size_t i = 0; i < mtr; i++) if (h_sel[(size_t)c * mtr + i] == 1) cs.Kc[c]++;
+	std::vector<unsigned short> sig((size_t)mtr * W);
+	for (unsigned c = 0; c < C; c++) {
+		size_t k = 0;
+		for (size_t i = 0; i < mtr; i++) {
+			if (h_sel[(size_t)c * mtr + i] == 1) {
+				sig[i * W + c] = (unsigned short)floor((double)(k * KM) / (double)cs.Kc[c]); // :766
+				k++;
+			} else sig[i * W + c] = 0xFFFF;
+		}
+	}
+	if (with_main) for (size_t i = 0; i < mtr; i++) sig[i * W + C] = (unsigned short)std::min<size_t>((size_t)floor((double)(i * KM) / (double)mtr), KM - 1);
+	cs.sig.clear(); cs.chunks.clear();
+	std::vector<std::vector<Chunk>> cls_chunks;
+	const unsigned clen = chunk_len_for(N, mtr);
+	for (size_t i = 0; i < mtr;) {
+		size_t j = i + 1;
+		while (j < mtr && !memcmp(&sig[i * W], &sig[j * W], W * sizeof(unsigned short))) j++;
+		std::vector<unsigned short> sg(sig.begin() + i * W, sig.begin() + (i + 1) * W);
+		size_t id = 0;
+		for (; id < cs.sig.size(); id++) if (cs.sig[id] == sg) break;
+		if (id == cs.sig.size()) { cs.sig.push_back(sg); cls_chunks.emplace_back(); }
+		for (size_t t = i; t < j; t += clen) {
+			Chunk c; c.t0 = t; c.count = (unsigned)std::min<size_t>(clen, j - t); c.row = (unsigned)id;
+			cls_chunks[id].push_back(c);
+		}
+		i = j;
+	}
+	const unsigned ncls = (unsigned)cs.sig.size();
+	cs.row_first.assign(ncls + 1, 0);
+	for (unsigned id = 0; id < ncls; id++) {
+		cs.row_first[id] = (unsigned)cs.chunks.size();
+		cs.chunks.insert(cs.chunks.end(), cls_chunks[id].begin(), cls_chunks[id].end());
+	}
+	cs.row_first[ncls] = (unsigned)cs.chunks.size();
+	int rc;
+	void *v;
+	if ((rc = scratch(pl, SCR_CLS, (size_t)ncls * N * sizeof(double), &v))) return rc;
+	if ((rc = run_chunks(pl, d_x, ld, N, cs.chunks, cs.row_first, ncls, (double *)v, N, st, false))) return rc; // own table: not the cached one
+	cs.d_x = d_x; cs.ld = ld; cs.mtr = mtr; cs.C = C; cs.KM = KM; cs.ncls = ncls; cs.has_main = with_main;
+	cs.sel.assign(h_sel, h_sel + (size_t)C * mtr);
+	cs.valid = true;
+	return 0;
+}
+
+// d_P[(col - col0) * KM + g][n] = sum of the class sums whose signature column `col` is g, for col in [col0, col1)
+static int combine_classes(tspws_hip_plan *pl, unsigned col0, unsigned col1, double *d_P, hipStream_t st)
+{
+	tspws_hip_plan::ClassSums &cs = pl->cs;
+	const unsigned KM = cs.KM, nrow = (col1 - col0) * KM;
+	const size_t N = pl->N;
+	cs.rp.assign((size_t)nrow + 1, 0); cs.cols.clear();
+	for (unsigned c = col0; c < col1; c++)
+		for (unsigned g = 0; g < KM; g++) {
+			cs.rp[(size_t)(c - col0) * KM + g] = (unsigned)cs.cols.size();
+			for (unsigned id = 0; id < cs.ncls; id++) if (cs.sig[id][c] == g) cs.cols.push_back(id);
+		}
+	cs.rp[nrow] = (unsigned)cs.cols.size();
+	void *v;
+	int rc;
+	if ((rc = scratch(pl, SCR_JKTAB, (cs.rp.size() + cs.cols.size() + 1) * sizeof(unsigned), &v))) return rc;
+	unsigned *d_rp = (unsigned *)v, *d_cols = d_rp + cs.rp.size();
+	HIP_TRY(hipMemcpyAsync(d_rp, cs.rp.data(), cs.rp.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+	if (!cs.cols.empty()) HIP_TRY(hipMemcpyAsync(d_cols, cs.cols.data(), cs.cols.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+	for (unsigned r0 = 0; r0 < nrow; r0 += 65535) {
+		const unsigned ny = std::min(nrow - r0, 65535u);
+		hipLaunchKernelGGL(k_combine_classes, dim3((unsigned)((N + 255) / 256), ny), dim3(256), 0, st, (const double *)pl->scr[SCR_CLS], N, d_rp + r0, d_cols,
+		                   d_P + (size_t)r0 * N, N);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// Announce the jackknife that will follow the next two-stage tspws_hip_stack_local of the SAME traces (whole ensemble on this
+// device): that call then streams the traces once for its own groups and for every replica, and tspws_hip_jackknife with the
+// same selection reuses the class sums instead of streaming the traces again.  The caller must not change the traces
+// between the two calls (tspws_main does not).
+extern "C" int tspws_hip_jackknife_prepare(tspws_hip_plan *pl, const t_tsPWS *p, const char *h_sel, unsigned C, size_t mtr)
+{
+	if (!pl || !p) return fail(TSPWS_E_ARG, "jackknife_prepare: NULL");
+	pl->jk_prepared = false;
+	if (!h_sel || !C || !is_two_stage(p, mtr)) return 0; // nothing to share
+	pl->jk_sel.assign(h_sel, h_sel + (size_t)C * mtr);
+	pl->jk_C = C; pl->jk_KM = p->Kmax; pl->jk_mtr = mtr;
+	pl->jk_prepared = true;
+	return 0;
+}
+
 static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, const char *h_sel, unsigned C,
                             float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s);
 
@@ -2020,71 +2152,21 @@ static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d
 	hipStream_t st = S_(s);
 	const unsigned KM = p->Kmax;
 	const size_t N = pl->N;
-	// signature of trace i: group index in every replica (0xFFFF = deleted)
-	std::vector<size_t> Kc(C, 0);
-	for (unsigned c = 0; c < C; c++) for (size_t i = 0; i < mtr; i++) if (h_sel[(size_t)c * mtr + i] == 1) Kc[c]++;
-	std::vector<unsigned short> sig((size_t)mtr * C);
-	for (unsigned c = 0; c < C; c++) {
-		size_t k = 0;
-		for (size_t i = 0; i < mtr; i++) {
-			if (h_sel[(size_t)c * mtr + i] == 1) {
-				sig[i * C + c] = (unsigned short)floor((double)(k * KM) / (double)Kc[c]); // :766
-				k++;
-			} else sig[i * C + c] = 0xFFFF;
-		}
-	}
-	// classes = maximal runs of consecutive traces with identical signature; identical signatures
-	// of separate runs are merged into one class.
-	std::vector<Chunk> chunks;
-	std::vector<std::vector<unsigned short>> cls_sig;
-	std::vector<std::vector<Chunk>> cls_chunks;
-	const unsigned clen = chunk_len_for(N, mtr);
-	for (size_t i = 0; i < mtr;) {
-		size_t j = i + 1;
-		while (j < mtr && !memcmp(&sig[i * C], &sig[j * C], C * sizeof(unsigned short))) j++;
-		std::vector<unsigned short> sg(sig.begin() + i * C, sig.begin() + (i + 1) * C);
-		size_t id = 0;
-		for (; id < cls_sig.size(); id++) if (cls_sig[id] == sg) break;
-		if (id == cls_sig.size()) { cls_sig.push_back(sg); cls_chunks.emplace_back(); }
-		for (size_t t = i; t < j; t += clen) {
-			Chunk c; c.t0 = t; c.count = (unsigned)std::min<size_t>(clen, j - t); c.row = (unsigned)id;
-			cls_chunks[id].push_back(c);
-		}
-		i = j;
-	}
-	const unsigned ncls = (unsigned)cls_sig.size();
-	std::vector<unsigned> row_first(ncls + 1, 0);
-	for (unsigned id = 0; id < ncls; id++) {
-		row_first[id] = (unsigned)chunks.size();
-		chunks.insert(chunks.end(), cls_chunks[id].begin(), cls_chunks[id].end());
-	}
-	row_first[ncls] = (unsigned)chunks.size();
 	int rc;
 	void *v;
-	if ((rc = scratch(pl, SCR_CLS, (size_t)ncls * N * sizeof(double), &v))) return rc;
-	double *d_cls = (double *)v;
-	if ((rc = run_chunks(pl, d_x, ld, N, chunks, row_first, ncls, d_cls, N, st, false))) return rc; // own table: not the cached one
-	// CSR: (replica, group) -> classes
-	std::vector<unsigned> rp((size_t)C * KM + 1, 0), cols;
-	for (unsigned c = 0; c < C; c++)
-		for (unsigned g = 0; g < KM; g++) {
-			rp[(size_t)c * KM + g] = (unsigned)cols.size();
-			for (unsigned id = 0; id < ncls; id++) if (cls_sig[id][c] == g) cols.push_back(id);
-		}
-	rp[(size_t)C * KM] = (unsigned)cols.size();
-	if ((rc = scratch(pl, SCR_JKP, ((size_t)C * KM * N + C) * sizeof(double) + (rp.size() + cols.size() + 1) * sizeof(unsigned), &v))) return rc;
+	// class sums: left behind by a prepared tspws_hip_stack_local of these traces with this selection, else streamed now
+	tspws_hip_plan::ClassSums &cs = pl->cs;
+	const bool reuse = cs.valid && cs.d_x == d_x && cs.ld == ld && cs.mtr == mtr && cs.C == C && cs.KM == KM &&
+	                   cs.sel.size() == (size_t)C * mtr && !memcmp(cs.sel.data(), h_sel, (size_t)C * mtr);
+	if (!reuse && (rc = class_sums(pl, KM, d_x, ld, mtr, h_sel, C, false, st))) return rc;
+	const std::vector<size_t> Kc = cs.Kc;
+	if ((rc = scratch(pl, SCR_JKP, ((size_t)C * KM * N + C) * sizeof(double), &v))) return rc;
 	double *d_P = (double *)v, *d_Mv = d_P + (size_t)C * KM * N; // partial stacks of every replica, then the replicas' trace counts
-	unsigned *d_rp = (unsigned *)(d_Mv + C), *d_cols = d_rp + rp.size();
 	std::vector<double> h_Mv(C);
 	for (unsigned c = 0; c < C; c++) h_Mv[c] = (double)Kc[c];
 	HIP_TRY(hipMemcpyAsync(d_Mv, h_Mv.data(), C * sizeof(double), hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemcpyAsync(d_rp, rp.data(), rp.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
-	if (!cols.empty()) HIP_TRY(hipMemcpyAsync(d_cols, cols.data(), cols.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
-	for (unsigned r0 = 0; r0 < C * KM; r0 += 65535) {
-		const unsigned ny = std::min(C * KM - r0, 65535u);
-		hipLaunchKernelGGL(k_combine_classes, dim3((unsigned)((N + 255) / 256), ny), dim3(256), 0, st, d_cls, N, d_rp + r0, d_cols,
-		                   d_P + (size_t)r0 * N, N);
-	}
+	if ((rc = combine_classes(pl, 0, C, d_P, st))) return rc;
+	cs.valid = false; // one use: the traces may change after this call
 	HIP_TRY(hipGetLastError());
 	// Replicas are processed in batches: ONE forward launch transforms the KM partials of a whole batch of replicas (the
 	// kernels fill the GPU far better with 100 traces than with 10), then per replica the phase accumulation and the
