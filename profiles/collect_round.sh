@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage (GPU box, repo root): bash profiles/collect_round.sh rNN
+# Everything the round's numbers come from, into gpurun_out/ (copy the summaries you keep into profiles/):
+#   bench line with the CPU baseline, rocprofv3 kernel stats + timeline of the same command, PMC traffic passes.
+TAG=${1:-rXX}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+mkdir -p $R/gpurun_out
+python3 $R/bench.py > $R/gpurun_out/${TAG}_bench_line.json 2> $R/gpurun_out/${TAG}_bench.err
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o b -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu > $R/gpurun_out/${TAG}_bench_prof.log 2>&1
+cd $R
+python3 profiles/summarize_rocpd.py gpurun_out/prof_$TAG/b_results.db > gpurun_out/${TAG}_stats.txt 2>&1
+python3 profiles/timeline_rocpd.py gpurun_out/prof_$TAG/b_results.db 14 > gpurun_out/${TAG}_timeline.txt 2>&1
+bash profiles/collect_pmc.sh $TAG > /dev/null 2>&1
+python3 tools/bench_configs.py > gpurun_out/${TAG}_configs.json 2>/dev/null
+python3 tools/cfg1_run.py 2>/dev/null | grep cfg1 > gpurun_out/${TAG}_cfg1.txt
+tail -c 2500 gpurun_out/${TAG}_bench_line.json; cat gpurun_out/${TAG}_stats.txt gpurun_out/${TAG}_timeline.txt gpurun_out/${TAG}_configs.json gpurun_out/${TAG}_cfg1.txt; grep -A30 "k_partial" gpurun_out/pmc_$TAG.txt | head -40

@@ -2172,7 +2172,7 @@ static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d
 	// kernels fill the GPU far better with 100 traces than with 10), then per replica the phase accumulation and the
 	// weight (KM, K_c), and the inverses two replicas at a time.
 	const size_t nc = pl->ncoef;
-	unsigned RB = (unsigned)std::max<size_t>(1, std::min<size_t>(C, ((size_t)1 << 30) / std::max<size_t>(1, (size_t)KM * pl->npart * sizeof(double2))));
+	unsigned RB = (unsigned)std::max<size_t>(1, std::min<size_t>(C, part_budget_bytes() / std::max<size_t>(1, (size_t)KM * pl->npart * sizeof(double2))));
 	if (RB > 1) RB &= ~1u; // pairs for the two-set inverse
 	if ((rc = scratch(pl, SCR_PART, (size_t)RB * KM * pl->npart * sizeof(double2), &v))) return rc;
 	double2 *part = (double2 *)v;
