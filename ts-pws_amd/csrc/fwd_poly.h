@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
                                                           unsigned S, unsigned ntr, double2 *__restrict__ ST, double2 *__restrict__ PS,
                                                           int zero_first, int fused, const double2 *__restrict__ fzST,
                                                           const double2 *__restrict__ fzPS, size_t fz_stride, unsigned nslices,
-                                                          size_t y_part, size_t y_stack)
+                                                          size_t y_part, size_t y_stack, int many)
 {
 	// blockIdx.y = independent stack (jackknife replica): its ntr transformed traces start y_part further in `part`, its
 	// ST / PS y_stack further (the fused forward kernel wrote the fuse_ok scales there directly: fused == 1)
@@ -438,6 +438,29 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 		return;
 	}
 	const bool wide = nsplit > 1;
+	if (wide && many) {
+		// many traces, few coefficients (coarse / residue-split scales of a single-stage batch; table geometry: 4 coefficients
+		// per block): a wave per coefficient, its 64 lanes take every 64th TRACE (all splits of it), then a wave reduction --
+		// the dependent-load chain is ntr / 64 long and there are Ns / 4 blocks instead of Ns / 32
+		const unsigned k = (blockIdx.x - sc[lo].acc2_off) * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+		if (k >= Ns) return;
+		const size_t i = sc[lo].coef_off + k;
+		const double2 *p0 = part + sc[lo].part_off + k;
+		double2 st = make_double2(0, 0), ps = make_double2(0, 0);
+		for (unsigned b = lane; b < ntr; b += 64) {
+			const double2 *p = p0 + (size_t)b * npart;
+			double2 v = make_double2(0.0, 0.0);
+			for (unsigned sp = 0; sp < nsplit; sp++) { const double2 t = p[(size_t)sp * Ns]; v.x += t.x; v.y += t.y; }
+			st.x += v.x; st.y += v.y;
+			add_unit_phasor(ps, v);
+		}
+		st.x = wave_sum(st.x); st.y = wave_sum(st.y); ps.x = wave_sum(ps.x); ps.y = wave_sum(ps.y);
+		if (lane == 0) {
+			if (!zero_first) { const double2 a = ST[i], b = PS[i]; st.x += a.x; st.y += a.y; ps.x += b.x; ps.y += b.y; }
+			ST[i] = st; PS[i] = ps;
+		}
+		return;
+	}
 	const unsigned sub = wide ? (threadIdx.x & 7) : 0, stride = wide ? 8u : 1u;
 	const unsigned k = (blockIdx.x - sc[lo].acc2_off) * (wide ? 32u : 256u) + (wide ? threadIdx.x >> 3 : threadIdx.x);
 	const bool live = k < Ns;

@@ -78,6 +78,7 @@ struct OctDesc;
 struct OctFwd;
 static int build_oct_forward(tspws_hip_plan *p, std::vector<char> &is_oct); // defined next to the forward kernels
 static int upload_oct_forward(tspws_hip_plan *p);
+static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS);
 
 #ifndef FL_PASSES
 #define FL_PASSES 2
@@ -96,7 +97,7 @@ struct Chunk { // one streaming work item of the partial-stack kernel
 	unsigned row;          // destination row (group / class)
 };
 
-enum { SCR_Y = 0, SCR_PART, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_XCM, SCR_JKTAB, SCR_N };
+enum { SCR_Y = 0, SCR_PART, SCR_XT, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_XCM, SCR_JKTAB, SCR_N };
 
 struct tspws_hip_plan {
 	int device = 0, type = -1;
@@ -113,6 +114,12 @@ struct tspws_hip_plan {
 	int oct_mode = 2;                // 1: k_fwd_oct (256 threads, voice subsets, two workgroups per CU), 2: k_fwd_oct2 (two-team pipeline)
 	size_t oct_lds = 0;
 	struct OctFwd *d_ofw = nullptr;
+	// many-trace decomposition (fwd_tl.h): second scale table, trace-lane work items
+	std::vector<ScaleDesc> sc_tl;
+	ScaleDesc *d_sc_tl = nullptr;
+	struct TLItem *d_tl = nullptr;
+	unsigned tl_n = 0, tl_wgs = 0, tl_waves = 0, tl_acc2_blocks = 0; // items, workgroups per trace block, direct-kernel waves, accumulate blocks
+	size_t tl_npart = 0, tl_lds = 0;
 	std::vector<unsigned char> ofw_host; // the OctFwd table (bytes; the struct is defined next to the kernel)
 	unsigned cm_n[2] = {0, 0}, cm_D[2][8] = {{0}}, cm_MC[2][8] = {{0}}; // chunk-major copies by input type [float, double]
 	size_t cm_per_trace[2] = {0, 0};                                    // elements per trace of all copies
@@ -503,6 +510,7 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 		}
 		p->fwd_waves = woff; p->lds_blocks = boff; p->npart = poff;
 		if (int rc = upload_oct_forward(p)) { tspws_hip_plan_destroy(p); return rc; }
+		if (kind == 1) { if (int rc = build_tl_forward(p, FWD_STEPS)) { tspws_hip_plan_destroy(p); return rc; } }
 		for (unsigned s = 0; s < S; s++) p->n_fusable += p->sc[s].fuse_ok;
 		if (kind == 3 && !build_mfma_pairs(p)) { // a filter too long for the matrix kernel: VALU kernels
 			p->fwd_kind = 1; p->pairs.clear();
@@ -557,6 +565,8 @@ extern "C" void tspws_hip_plan_destroy(tspws_hip_plan *p)
 	if (p->aux) (void)hipStreamDestroy(p->aux);
 	if (p->d_oc) (void)hipFree(p->d_oc);
 	if (p->d_ofw) (void)hipFree(p->d_ofw);
+	if (p->d_sc_tl) (void)hipFree(p->d_sc_tl);
+	if (p->d_tl) (void)hipFree(p->d_tl);
 	if (p->d_pairs) (void)hipFree(p->d_pairs);
 	if (p->d_bt) (void)hipFree(p->d_bt);
 	if (p->d_sc) (void)hipFree(p->d_sc);
@@ -1149,6 +1159,118 @@ static int upload_oct_forward(tspws_hip_plan *p)
 	return 0;
 }
 
+#include "fwd_tl.h"
+
+static size_t tl_min_traces()
+{
+	static long v = -1;
+	if (v < 0) { const char *e = getenv("TSPWS_TL_MIN"); v = e ? std::max(1, atoi(e)) : 64; }
+	return (size_t)v;
+}
+
+static bool tl_enabled()
+{
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("TSPWS_FWD_TL"); v = (e && *e == '0') ? 0 : 1; }
+	return v == 1;
+}
+
+// Decomposition for many-trace batches (fwd_tl.h): octaves (runs of scales with the same D and Ns) with at least TL_MINNS
+// outputs become trace-lane work items (voice subsets of <= TL_VMAX voices), the rest stays on the direct kernel; sc_tl is
+// the scale table of that decomposition (partial layout, fused flags, accumulate geometry).
+static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS)
+{
+	unsigned MINNS = 16, TLSTEPS = 64;
+	if (const char *e = getenv("TSPWS_TL_MINNS")) MINNS = (unsigned)std::max(1, atoi(e));
+	if (const char *e = getenv("TSPWS_TL_STEPS")) TLSTEPS = (unsigned)std::max(1, atoi(e));
+	p->sc_tl = p->sc;
+	std::vector<TLItem> items;
+	std::vector<char> is_tl(p->S, 0);
+	unsigned wg = 0;
+	for (unsigned s = 0; s < p->S;) {
+		unsigned e = s + 1;
+		while (e < p->S && p->sc[e].D == p->sc[s].D && p->sc[e].Ns == p->sc[s].Ns) e++;
+		const unsigned D = p->sc[s].D, Ns = p->sc[s].Ns, nv = e - s;
+		bool ok = Ns >= MINNS;
+		std::vector<unsigned> a(nv), b(nv), qr(nv);
+		for (unsigned v = 0; v < nv && ok; v++) {
+			const ScaleDesc &d = p->sc[s + v];
+			a[v] = (unsigned)d.c / D; b[v] = (unsigned)d.c % D;
+			const long long num = (long long)d.L - 1 - (long long)b[v];
+			const long long fl = num >= 0 ? num / (long long)D : -1;
+			qr[v] = ((unsigned)(fl + 2) + 3) & ~3u;
+			if (qr[v] > TL_QMAX) ok = false;
+		}
+		if (ok) {
+			const unsigned nsub = (nv + TL_VMAX - 1) / TL_VMAX, per = (nv + nsub - 1) / nsub;
+			std::vector<TLItem> sub;
+			for (unsigned v0 = 0; v0 < nv && ok; v0 += per) {
+				const unsigned n = std::min(per, nv - v0);
+				TLItem o;
+				memset(&o, 0, sizeof o);
+				o.nv = n; o.D = D; o.Ns = Ns; o.nkb = (Ns + 31) / 32;
+				o.nsplit = (D + TL_PMAX - 1) / TL_PMAX; o.pps = (D + o.nsplit - 1) / o.nsplit; o.fused = o.nsplit == 1;
+				unsigned amax = 0, amin = ~0u, qmax = 0, rows = 0;
+				for (unsigned i = 0; i < n; i++) {
+					const unsigned v = v0 + i;
+					o.sc[i] = s + v; o.QR[i] = qr[v]; o.trow[i] = rows; o.a[i] = a[v]; o.b[i] = b[v]; o.L[i] = p->sc[s + v].L;
+					o.tap_off[i] = p->sc[s + v].tap_off; o.coef_off[i] = p->sc[s + v].coef_off;
+					rows += qr[v]; amax = std::max(amax, a[v]); amin = std::min(amin, a[v]); qmax = std::max(qmax, qr[v]);
+				}
+				o.amax = amax; o.trows = rows;
+				o.XR = (31 + qmax + (amax - amin) + 3) & ~3u;
+				if (o.XR > TL_XRMAX || rows > TL_NT) ok = false;
+				sub.push_back(o);
+			}
+			if (ok) {
+				for (TLItem &o : sub) {
+					// a workgroup should walk >= ~64 residue steps: with few residues per output block it takes several blocks
+					o.kbw = std::max(1u, std::min(o.nkb, TLSTEPS / std::max(1u, o.pps)));
+					o.wg_off = wg; wg += ((o.nkb + o.kbw - 1) / o.kbw) * o.nsplit;
+					p->tl_lds = std::max(p->tl_lds, 2 * ((size_t)o.XR * 64 * sizeof(double) + (size_t)o.trows * sizeof(double2)));
+					items.push_back(o);
+				}
+				for (unsigned v = s; v < e; v++) is_tl[v] = 1;
+			}
+		}
+		s = e;
+	}
+	// scale table of the decomposition: partial layout, direct-kernel waves, accumulate geometry
+	unsigned woff = 0, ablk = 0;
+	unsigned long long poff = 0;
+	for (unsigned s = 0; s < p->S; s++) {
+		ScaleDesc &d = p->sc_tl[s];
+		d.use_lds = 0; d.use_oct = 0; d.lds_off = 0;
+		if (is_tl[s]) {
+			d.nsplit = (d.D + TL_PMAX - 1) / TL_PMAX; d.cps = 1;
+			d.fuse_ok = d.nsplit == 1 ? 1u : 0u;
+		} else { // direct kernel, as in the few-trace table
+			const unsigned cps = std::max(1u, (FWD_STEPS + d.Q / 2) / std::max(1u, d.Q));
+			d.cps = std::min(cps, d.MC);
+			d.nsplit = (d.MC + d.cps - 1) / d.cps;
+			d.fuse_ok = 0;
+		}
+		d.wave_off = woff;
+		if (!is_tl[s]) woff += d.ngw * d.nsplit;
+		d.part_off = poff;
+		if (!(is_tl[s] && d.fuse_ok)) poff += (unsigned long long)d.nsplit * d.Ns; // fused scales never write partials
+		d.acc2_off = ablk;
+		ablk += d.nsplit > 1 ? (d.Ns + 3) / 4 : (d.Ns + 255) / 256; // split scales: 4 coefficients per block (k_accumulate_parts, many)
+	}
+	for (TLItem &o : items) for (unsigned i = 0; i < o.nv; i++) o.part_off[i] = p->sc_tl[o.sc[i]].part_off;
+	p->tl_n = (unsigned)items.size(); p->tl_wgs = wg; p->tl_waves = woff; p->tl_acc2_blocks = ablk; p->tl_npart = poff;
+	if (!p->tl_n) return 0;
+	HIP_TRY(hipMalloc(&p->d_sc_tl, p->S * sizeof(ScaleDesc)));
+	HIP_TRY(hipMemcpy(p->d_sc_tl, p->sc_tl.data(), p->S * sizeof(ScaleDesc), hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc(&p->d_tl, items.size() * sizeof(TLItem)));
+	HIP_TRY(hipMemcpy(p->d_tl, items.data(), items.size() * sizeof(TLItem), hipMemcpyHostToDevice));
+	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_tl<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_tl<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	if (getenv("TSPWS_DEBUG"))
+		for (const TLItem &o : items) fprintf(stderr, "tl sc0=%u nv=%u D=%u Ns=%u nkb=%u nsplit=%u pps=%u XR=%u rows=%u fused=%u wg_off=%u\n", o.sc[0], o.nv, o.D, o.Ns, o.nkb, o.nsplit, o.pps, o.XR, o.trows, o.fused, o.wg_off);
+	return 0;
+}
+
 static int upload_mfma_tables(tspws_hip_plan *p)
 {
 	const size_t np = p->pairs.size();
@@ -1423,13 +1545,15 @@ extern "C" int tspws_hip_accumulate(tspws_hip_plan *p, const double *d_Y, size_t
 
 // launches k_accumulate_parts for `nb` transformed traces; fz = what forward_parts left behind (may be NULL / not applied)
 static void launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb, double2 *ST, double2 *PS, int zero_first, const FuseOut *fz,
-                              unsigned nslices, hipStream_t st, unsigned nbatch = 1, size_t y_part = 0, size_t y_stack = 0)
+                              unsigned nslices, hipStream_t st, unsigned nbatch = 1, size_t y_part = 0, size_t y_stack = 0, bool tl = false)
 {
 	const bool on = fz && fz->applied;
 	const bool direct = on && fz->accST == ST; // the single slice went straight into ST / PS
-	hipLaunchKernelGGL(k_accumulate_parts, dim3(p->acc2_blocks, nbatch), dim3(256), 0, st, part, p->npart, p->d_sc, p->S, nb, ST, PS, zero_first,
+	// tl: the many-trace decomposition's scale table (partial layout, fused flags, block geometry)
+	hipLaunchKernelGGL(k_accumulate_parts, dim3(tl ? p->tl_acc2_blocks : p->acc2_blocks, nbatch), dim3(256), 0, st, part, tl ? p->tl_npart : p->npart,
+	                   tl ? p->d_sc_tl : p->d_sc, p->S, nb, ST, PS, zero_first,
 	                   on ? (direct ? 1 : 2) : 0, on ? (const double2 *)fz->accST : nullptr, on ? (const double2 *)fz->accPS : nullptr,
-	                   on ? fz->stride : (size_t)0, nslices, y_part, y_stack);
+	                   on ? fz->stride : (size_t)0, nslices, y_part, y_stack, tl ? 1 : 0);
 }
 
 // slice length of the fused forward kernel for a batch of nb traces: whole batch when it is small (two-stage: the K
@@ -1442,11 +1566,53 @@ static unsigned fuse_tps(size_t nb)
 	return (unsigned)std::min<size_t>(nb, 32);
 }
 
+// Many traces (single-stage stacks): trace-lane kernel on the transposed batch (fwd_tl.h); the stacks of the fused scales
+// come back as one plane pair per 64-trace block, the split / coarse scales as per-trace partials in the tl layout.
+template <typename TIn>
+static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, hipStream_t st, bool keep)
+{
+	int rc;
+	void *v;
+	// traces per batch: transposed copy <= 1 GiB, at most 4096 (64 plane pairs), a multiple of 64
+	size_t batch = std::min<size_t>(4096, std::max<size_t>(64, (((size_t)1 << 30) / ((size_t)p->N * sizeof(TIn))) & ~(size_t)63));
+	if (p->tl_npart) batch = std::min(batch, std::max<size_t>(64, (part_budget_bytes() / (p->tl_npart * sizeof(double2))) & ~(size_t)63));
+	batch = std::min(batch, (ntr + 63) & ~(size_t)63);
+	const size_t nblk_max = batch / 64;
+	if ((rc = scratch(p, SCR_XT, (size_t)p->N * batch * sizeof(TIn), &v))) return rc;
+	TIn *xT = (TIn *)v;
+	if ((rc = scratch(p, SCR_FZ, nblk_max * 2 * p->ncoef * sizeof(double2), &v))) return rc;
+	double2 *planes = (double2 *)v;
+	double2 *part = nullptr;
+	if (p->tl_npart) { if ((rc = scratch(p, SCR_PART, batch * p->tl_npart * sizeof(double2), &v))) return rc; part = (double2 *)v; }
+	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
+		const unsigned nb = (unsigned)std::min(batch, ntr - t0), nblk = (nb + 63) / 64, TP = nblk * 64;
+		const TIn *xb = d_x + t0 * ld;
+		hipLaunchKernelGGL((k_transpose_traces<TIn>), dim3((p->N + 63) / 64, nblk), dim3(256), 0, st, xb, ld, nb, p->N, TP, xT);
+		hipLaunchKernelGGL((k_fwd_tl<TIn>), dim3(p->tl_wgs, nblk), dim3(TL_NT), p->tl_lds, st, (const TIn *)xT, TP, nb, p->N, p->d_tl, p->tl_n, p->d_w,
+		                   planes, planes + p->ncoef, 2 * p->ncoef, part, p->tl_npart);
+		if (p->tl_waves) { // scales with too few outputs for the trace-lane kernel: direct kernel, tl partial layout
+			const unsigned nbw = (p->tl_waves + 3) / 4;
+			for (size_t u0 = 0; u0 < nb; u0 += 2 * 32768) {
+				const unsigned nt = (unsigned)std::min<size_t>(nb - u0, 2 * 32768);
+				hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nbw, (nt + 1) / 2), dim3(256), 0, st, xb + u0 * ld, ld, nt, p->N, p->d_sc_tl, p->S, p->d_w,
+				                   part + u0 * p->tl_npart, p->tl_npart, p->tl_waves);
+			}
+		}
+		FuseOut fz;
+		fz.accST = planes; fz.accPS = planes + p->ncoef; fz.stride = 2 * p->ncoef; fz.tps = 64; fz.applied = true;
+		launch_accumulate(p, part, nb, (double2 *)d_ST, (double2 *)d_PS, (t0 == 0 && !keep) ? 1 : 0, &fz, nblk, st, 1, 0, 0, true);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
 template <typename TIn>
 static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, void *s, bool keep = false)
 { // keep: add to the stacks already in d_ST / d_PS instead of starting from zero
 	HIP_TRY(hipSetDevice(p->device));
 	hipStream_t st = S_(s);
+	if (ntr >= tl_min_traces() && tl_enabled() && fuse_enabled() && p->fwd_kind == 1 && p->tl_n && !use_generic_forward())
+		return stacks_tl<TIn>(p, d_x, ntr, ld, d_ST, d_PS, st, keep);
 	if (!ntr) { if (!keep) { HIP_TRY(hipMemsetAsync(d_ST, 0, p->ncoef * 16, st)); HIP_TRY(hipMemsetAsync(d_PS, 0, p->ncoef * 16, st)); } return 0; }
 	int rc;
 	if (use_generic_forward()) {
