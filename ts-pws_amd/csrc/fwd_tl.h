@@ -145,6 +145,13 @@ __global__ void __launch_bounds__(TL_NT, 2) k_fwd_tl(const TIn *__restrict__ xT,
 		if (tap_thread) tbuf(b)[tid] = tp;
 	};
 
+	// per-voice descriptors in registers: read once, not in every residue step
+	unsigned vQR[TL_VMAX], vrow[TL_VMAX]; // (the tap images are packed: trow[v + 1] = trow[v] + QR[v])
+#pragma unroll
+	for (int v = 0; v < TL_VMAX; v++) {
+		const bool on = (unsigned)v < nv;
+		vQR[v] = on ? o->QR[v] : 0u; vrow[v] = on ? amax - o->a[v] : 0u;
+	}
 	double ar[TL_VMAX][R], ai[TL_VMAX][R];
 	const unsigned t = tb * 64 + lane;            // this lane's trace
 	const bool tlive = t < ntr;
@@ -222,13 +229,14 @@ __global__ void __launch_bounds__(TL_NT, 2) k_fwd_tl(const TIn *__restrict__ xT,
 #endif
 			if (group_live) {
 				const double *xi = xbuf(cur) + (size_t)wv * R * 64 + lane;
-				const double2 *ti = tbuf(cur);
+				const double2 *tbv0 = tbuf(cur);
 #pragma unroll
 				for (int v = 0; v < TL_VMAX; v++) {
 					if ((unsigned)v < nv) {
-						const unsigned QR = o->QR[v];
-						const double *xb = xi + (size_t)(amax - o->a[v]) * 64;
-						const double2 *tbv = ti + o->trow[v];
+						const unsigned QR = vQR[v];
+						const double *xb = xi + (size_t)vrow[v] * 64;
+						const double2 *tbv = tbv0;
+						tbv0 += QR;
 						double xw[R];
 #pragma unroll
 						for (int j = 0; j < R - 1; j++) xw[j] = xb[j * 64];
