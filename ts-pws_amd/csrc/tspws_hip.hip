@@ -1180,7 +1180,7 @@ static bool tl_enabled()
 // the scale table of that decomposition (partial layout, fused flags, accumulate geometry).
 static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS)
 {
-	unsigned MINNS = 16, TLSTEPS = 64;
+	unsigned MINNS = 17, TLSTEPS = 96; // >= 3 of the 4 waves of an output block busy; ~96 residue steps per workgroup (sweeps on 1024 x 32768 and 499 x 16501)
 	if (const char *e = getenv("TSPWS_TL_MINNS")) MINNS = (unsigned)std::max(1, atoi(e));
 	if (const char *e = getenv("TSPWS_TL_STEPS")) TLSTEPS = (unsigned)std::max(1, atoi(e));
 	p->sc_tl = p->sc;
