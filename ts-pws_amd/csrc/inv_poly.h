@@ -3,8 +3,8 @@
 //   x^[n] = sum_s gain_s D_s sum_{l : D_s | (n - cd_s + l)} Re( conj(wd_s[l]) Y_s[(n - cd_s + l)/D_s] )
 //                                                   (wavelet_v7.c:138-147, cdotx.c:305-340 / :176-211)
 //
-// Fast path: scales whose decimation divides N (then the zero-stuffed grid is circular and the seam
-// restart of cdotx.c:331-332 coincides with plain mod-N_s indexing).  Write n - cd = a D + rho; only taps
+// Decimations that divide N: the zero-stuffed grid is circular and the seam restart of cdotx.c:331-332 coincides with
+// plain mod-N_s indexing.  Other decimations: the three-frame form in the kernel (same thread mapping).  Write n - cd = a D + rho; only taps
 // l = q D + mu, mu = (-rho) mod D, land on the grid and hit coefficient a + q + (rho > 0).  For a fixed
 // output phase the inverse is therefore a stride-1 correlation between the coefficient row and a Q-tap
 // sub-filter -- the same sliding-window structure as the forward kernel, but with NO reduction across
@@ -36,7 +36,7 @@ struct OctDesc {
 	unsigned ngw;           // group-blocks per chunk
 	unsigned wave_off;
 	unsigned slot;          // row of obuf
-	unsigned pad0, pad1;
+	unsigned gen, pad1;     // gen: D does not divide N (three-frame form, see k_inv_poly)
 };
 
 template <int NREC>
@@ -70,6 +70,62 @@ __global__ void __launch_bounds__(256) k_inv_poly(const double2 *__restrict__ Y,
 #pragma unroll
 		for (int r = 0; r < R; r++) acc[c][r] = 0;
 
+	if (o.gen) {
+		// D does not divide N (cdotx.c:313-337: the zero-stuffed grid restarts at the circular seam).  With the raw position
+		// P = n - cd + l in (-N, 2N), frame f = floor(P / N) and in-frame position p = P - f N, a tap is on the grid iff
+		// D | p and then meets coefficient p / D.  Per frame this is the ordinary polyphase correlation for the shifted
+		// output position n - f N, WITHOUT any wrap of the coefficient index: indices outside [0, Ns) belong to another frame
+		// and are masked.  Frames -1 / +1 only matter next to the seam: a wave skips a frame none of its lanes can reach.
+		for (unsigned v = 0; v < o.nv; v++) {
+			const ScaleDesc d = sc[o.s0 + v];
+			const double2 *ws = wd + d.tap_off;
+			const double2 *ys = Y + d.coef_off;
+			const double gD = d.gain * (double)D;
+			for (int f = -1; f <= 1; f++) {
+				const long long t = (long long)n0c - d.cd - (long long)f * (long long)N;
+				long long a = t >= 0 ? t / D : -((-t + D - 1) / D);
+				const unsigned rho = (unsigned)(t - a * (long long)D);
+				const unsigned mu = rho ? D - rho : 0;
+				a += (long long)g * R + (rho ? 1 : 0);          // coefficient index of output r at step q: a + q + r
+				// steps that can meet a coefficient of this frame: 0 <= a + q + r < Ns for some r, and tap mu + q D < L
+				const long long qlo = a + (R - 1) < 0 ? -(a + (R - 1)) : 0;
+				const long long qhi_c = (long long)Ns - 1 - a;   // last step with a + q <= Ns - 1
+				const long long qhi_t = mu < d.L ? (long long)((d.L - 1 - mu) / D) : -1;
+				const bool any = live && qlo <= qhi_c && qlo <= qhi_t;
+				if (!__any(any)) continue;
+				long long idx = a;                               // coefficient index of window slot 0
+				double2 yw[NREC][R];
+#pragma unroll
+				for (int j = 0; j < R - 1; j++) {
+					const bool in = idx >= 0 && idx < (long long)Ns;
+#pragma unroll
+					for (int c = 0; c < NREC; c++) yw[c][j] = in ? ys[(size_t)c * ncoef + (size_t)(in ? idx : 0)] : make_double2(0.0, 0.0);
+					idx++;
+				}
+				unsigned l = mu;
+				for (unsigned q = 0; q < d.Q + 1; q += R) {
+#pragma unroll
+					for (int u = 0; u < R; u++) {
+						const bool in = idx >= 0 && idx < (long long)Ns;
+#pragma unroll
+						for (int c = 0; c < NREC; c++)
+							yw[c][(u + R - 1) % R] = in ? ys[(size_t)c * ncoef + (size_t)(in ? idx : 0)] : make_double2(0.0, 0.0);
+						idx++;
+						double2 tp = ws[l < d.L ? l : d.L - 1];
+						if (l < d.L) {
+							tp.x *= gD; tp.y *= gD;
+#pragma unroll
+							for (int c = 0; c < NREC; c++)
+#pragma unroll
+								for (int r = 0; r < R; r++)
+									acc[c][r] = fma(tp.x, yw[c][(u + r) % R].x, fma(tp.y, yw[c][(u + r) % R].y, acc[c][r]));
+						}
+						l += D;
+					}
+				}
+			}
+		}
+	} else
 	for (unsigned v = 0; v < o.nv; v++) {
 		const ScaleDesc d = sc[o.s0 + v];
 		const double2 *ws = wd + d.tap_off;
@@ -134,8 +190,8 @@ __global__ void __launch_bounds__(256) k_inv_poly(const double2 *__restrict__ Y,
 #pragma unroll
 	for (int r = 0; r < R; r++) {
 		const unsigned k = g * R + r;
-		if (k < Ns) {
-			const size_t n = (size_t)n0 + (size_t)k * D;
+		const size_t n = (size_t)n0 + (size_t)k * D;
+		if (k < Ns && n < N) { // (n < N matters only when D does not divide N: the last row is partial)
 #pragma unroll
 			for (int c = 0; c < NREC; c++) dst[(size_t)c * N + n] = acc[c][r];
 		}

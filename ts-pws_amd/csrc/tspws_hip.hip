@@ -1816,9 +1816,12 @@ static int build_inverse_items(tspws_hip_plan *p)
 	for (unsigned s = 0; s < p->S;) {
 		unsigned e = s + 1;
 		while (e < p->S && p->sc[e].D == p->sc[s].D) e++;
-		if (!p->sc[s].inv_fast) { p->inv_ngeneric += e - s; s = e; continue; }
+		static int gen_on = -1; // TSPWS_INV_GEN=0: decimations that do not divide N go to the one-thread-per-sample kernel
+		if (gen_on < 0) { const char *ev = getenv("TSPWS_INV_GEN"); gen_on = (ev && *ev == '0') ? 0 : 1; }
+		if (!p->sc[s].inv_fast && !gen_on) { p->inv_ngeneric += e - s; s = e; continue; }
 		OctDesc o;
 		memset(&o, 0, sizeof o);
+		o.gen = p->sc[s].inv_fast ? 0u : 1u;
 		o.s0 = s; o.nv = e - s; o.D = p->sc[s].D; o.Ns = p->sc[s].Ns;
 		unsigned dl = 1, lg = 0;
 		while (dl < o.D && dl < 64) { dl <<= 1; lg++; }
