@@ -716,6 +716,21 @@ def test_many_trace_single_stage_vs_oracle(lib, torch, kw, N, mtr):
 
 
 @pytest.mark.gpu
+def test_many_trace_batches(lib, torch, monkeypatch):
+    """The trace-lane path walks large ensembles in batches (transposed copy <= 1 GiB): forced here to 64 / 128 traces per batch,
+    the later batches add to the stacks of the first, the last one is partial."""
+    mtr, N = 200, 2048
+    X = abi.synth_traces(mtr, N, seed=47)
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(), X)
+    for b in ("64", "128"):
+        monkeypatch.setenv("TSPWS_TL_BATCH", b)
+        pl = tspws.Plan(tspws.resolve(abi.default_params(), N), N)
+        ls, ts = pl.stack(torch.as_tensor(X, device="cuda"))
+        torch.cuda.synchronize()
+        assert abi.relerr(ls.cpu().numpy(), want["ls"]) < TOL32 and abi.relerr(ts.cpu().numpy(), want["tsPWS"]) < TOL32
+
+
+@pytest.mark.gpu
 def test_many_trace_path_matches_the_few_trace_kernels(lib, torch):
     """Same ensemble through the trace-lane decomposition (stack_local on 192 traces: the single-stage all-reduce payload
     ST || PS) and through the per-trace forward API (k_fwd_lds / k_fwd_poly, coefficients of every trace) with the stacks

@@ -1576,6 +1576,7 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 	// traces per batch: transposed copy <= 1 GiB, at most 4096 (64 plane pairs), a multiple of 64
 	size_t batch = std::min<size_t>(4096, std::max<size_t>(64, (((size_t)1 << 30) / ((size_t)p->N * sizeof(TIn))) & ~(size_t)63));
 	if (p->tl_npart) batch = std::min(batch, std::max<size_t>(64, (part_budget_bytes() / (p->tl_npart * sizeof(double2))) & ~(size_t)63));
+	if (const char *e = getenv("TSPWS_TL_BATCH")) batch = std::max<size_t>(64, (size_t)atoi(e) & ~(size_t)63); // tests: force several batches
 	batch = std::min(batch, (ntr + 63) & ~(size_t)63);
 	const size_t nblk_max = batch / 64;
 	if ((rc = scratch(p, SCR_XT, (size_t)p->N * batch * sizeof(TIn), &v))) return rc;
