@@ -332,9 +332,11 @@ def _as_tensor(ptr, count, dtype, device):
     return torch.as_tensor(_Holder(), device=f"cuda:{device}")
 
 
-def synth(mtr, N, seed=0, first=0, device=0):
-    """Seeded synthetic ensemble generated on the device (float32 [mtr][N])."""
+def synth(mtr, N, seed=0, first=0, device=0, pad=0):
+    """Seeded synthetic ensemble generated on the device: float32 [mtr][N] view of rows `N + pad` samples apart (pad > 0:
+    the trace rows do not all start at the same offset of the memory interleave)."""
     import torch
-    x = torch.empty((mtr, N), dtype=torch.float32, device=f"cuda:{device}")
-    check(load().tspws_hip_synth(x.data_ptr(), mtr, N, N, seed, first, Plan._stream()), "synth")
-    return x
+    ld = N + pad
+    buf = torch.empty((mtr, ld), dtype=torch.float32, device=f"cuda:{device}")
+    check(load().tspws_hip_synth(buf.data_ptr(), mtr, N, ld, seed, first, Plan._stream()), "synth")
+    return buf[:, :N] if pad else buf
