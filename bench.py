@@ -153,7 +153,7 @@ def main():
         "config": {"workload": f"{mtr_local} traces/GPU x {N} samples, Morlet w0=pi*sqrt(2/ln2) V=4 J={params.J}, "
                                f"two-stage K={K} + unbiased phase coherence (BASELINE configs[2]); HBM-resident float32 traces",
                    "traces_total": mtr_global, "plan_create_ms": round(t_plan * 1e3, 3), "parallelism": f"trace-sharded x{world}, fp64 all-reduce of P[K][N] in two halves: the first overlaps the streaming of the second, the second the transforms of the first"},
-        "roofline": {"bound": "hbm", "kernel": "k_partial (+k_reduce_chunks)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_partial", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": stream_ms,
                      "note": "HIP events on the launch stream around the streaming stage of every timed call (one k_partial launch "

@@ -838,6 +838,19 @@ static int run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, 
 	const unsigned bx = (unsigned)((N + 1023) / 1024);
 	const bool vec = (N % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x & 15) == 0);
 	const size_t ck0 = row_first[row_begin], ck1 = row_first[row_end]; // chunks are sorted by destination row
+	// every destination row fed by exactly ONE chunk: the streaming kernel writes the rows themselves, no chunk reduction
+	bool direct = ck1 - ck0 == (size_t)(row_end - row_begin) && ck1 - ck0 <= 65535 && (!vec || ldP % 2 == 0);
+	for (unsigned r = row_begin; r < row_end && direct; r++) direct = row_first[r + 1] - row_first[r] == 1;
+	if (direct) {
+		double *dst = d_P + (size_t)row_begin * ldP;
+		const unsigned ny = (unsigned)(ck1 - ck0);
+		if (ny) {
+			if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + ck0, dst, ldP);
+			else hipLaunchKernelGGL(k_partial<false>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + ck0, dst, ldP);
+		}
+		HIP_TRY(hipGetLastError());
+		return 0;
+	}
 	for (size_t c0 = ck0; c0 < ck1; c0 += 65535) {
 		const unsigned ny = (unsigned)std::min<size_t>(ck1 - c0, 65535);
 		if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, (double *)d_pc + c0 * ldpc, ldpc);
@@ -852,11 +865,14 @@ static int run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, 
 	return 0;
 }
 
-// target number of workgroups in flight for the streaming pass: 256 CUs x 8
+// Chunk length of the streaming pass.  Round-2 sweep (10 000 x 131 072, K = 10): one 1000-trace chunk per group (1280
+// workgroups, 5 per CU) streams at 0.795-0.80 ms, steadily; 2 / 3-4 chunks per group (2560 / 5120 workgroups) at 0.79-0.83 /
+// 0.81-0.89 ms from one process to the next -- long runs per workgroup beat a full complement of waves.  Target: ~1024
+// workgroups in all; a group that fits one chunk is written by the streaming kernel directly (no chunk reduction).
 static unsigned chunk_len_for(size_t N, size_t mtr)
 {
 	const size_t colblocks = (N + 1023) / 1024;
-	const size_t want = std::max<size_t>(1, 4096 / std::max<size_t>(colblocks, 1));
+	const size_t want = std::max<size_t>(1, 1024 / std::max<size_t>(colblocks, 1));
 	size_t len = (mtr + want - 1) / want;
 	len = std::max<size_t>(len, 8);
 	return (unsigned)std::min<size_t>(len, 1u << 20);
