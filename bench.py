@@ -82,7 +82,7 @@ def main():
             return
         # N > 1: the streaming stage in two halves of the groups; the all-reduce of the first half (RCCL, its own
         # stream) overlaps the streaming of the second -- one logical fp64 reduction of P[Kmax][N] (ts-pws_amd.stack_sharded)
-        half = K // 2
+        half = tspws.split_groups(K)
         buf = red.view(K, N)
         if i is not None:
             ev[i][0].record()

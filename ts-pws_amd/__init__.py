@@ -293,7 +293,7 @@ def stack_sharded(plan, traces, first=0, mtr_global=None, group=None):
     if distributed and callable(getattr(plan, "partial_stacks_range", None)) and K >= 2 and K <= mtr_global:
         # two-stage: the sum is row-separable, so the all-reduce of the first half of the groups runs (on the collective's
         # own stream) while the second half is still being streamed -- still one logical reduction of P[Kmax][N]
-        half = K // 2
+        half = split_groups(K)
         buf = plan.reduce_buffer(mtr_global).view(K, plan.N)
         plan.partial_stacks_range(traces, first, mtr_global, 0, half)
         w1 = dist.all_reduce(buf[:half], op=dist.ReduceOp.SUM, group=group, async_op=True)
@@ -319,6 +319,16 @@ def stack_sharded(plan, traces, first=0, mtr_global=None, group=None):
     ts = torch.empty(plan.N, dtype=torch.float32, device=traces.device)
     plan.stack_finish(mtr_global, ls, ts)
     return ls, ts
+
+
+def split_groups(K):
+    """First piece of the two-piece streaming / reduction schedule: about half the groups, EVEN when possible -- the streaming
+    pass launches the groups two at a time (one workgroup per CU at N = 131072), so an odd piece would end on a launch that
+    fills half the CUs."""
+    half = K // 2
+    if half >= 2 and half % 2:
+        half -= 1
+    return half
 
 
 def _as_tensor(ptr, count, dtype, device):

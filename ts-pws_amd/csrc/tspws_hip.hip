@@ -842,11 +842,23 @@ static int run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, 
 	bool direct = ck1 - ck0 == (size_t)(row_end - row_begin) && ck1 - ck0 <= 65535 && (!vec || ldP % 2 == 0);
 	for (unsigned r = row_begin; r < row_end && direct; r++) direct = row_first[r + 1] - row_first[r] == 1;
 	if (direct) {
-		double *dst = d_P + (size_t)row_begin * ldP;
-		const unsigned ny = (unsigned)(ck1 - ck0);
-		if (ny) {
-			if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + ck0, dst, ldP);
-			else hipLaunchKernelGGL(k_partial<false>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + ck0, dst, ldP);
+		// Rows per launch.  The HBM streams fastest when exactly ONE workgroup per CU marches down the traces and all of them
+		// start together: 256 workgroups per launch 0.730 ms (7.2 TB/s), 384 / 640 / 1280 per launch 0.80 / 0.80 / 0.79 ms,
+		// 128 (half the CUs) 1.05 ms; a persistent 256-workgroup kernel walking the same items without launch boundaries
+		// 0.76 ms -- the boundaries keep the column blocks of a trace row in step, so the chip reads whole 512-KB rows
+		// (gpurun_out/sweep_s12.txt, sweep_s13.txt).  Short chunks (class sums of masked replicas) stay in one launch:
+		// there the extra launch boundaries would cost more than the rate gains.
+		static int wg_target = -1;
+		if (wg_target < 0) { const char *e = getenv("TSPWS_STREAM_WGS"); wg_target = e ? std::max(1, atoi(e)) : 256; }
+		size_t rows_total = 0;
+		for (size_t c = ck0; c < ck1; c++) rows_total += chunks[c].count;
+		const bool long_runs = ck1 > ck0 && rows_total / (ck1 - ck0) >= 256;
+		const unsigned rpl = long_runs ? std::max(1u, (unsigned)wg_target / std::max(1u, bx)) : 65535u;
+		for (size_t c0 = ck0; c0 < ck1; c0 += rpl) {
+			const unsigned ny = (unsigned)std::min<size_t>(ck1 - c0, rpl);
+			double *dst = d_P + (size_t)(row_begin + (c0 - ck0)) * ldP;
+			if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, dst, ldP);
+			else hipLaunchKernelGGL(k_partial<false>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, dst, ldP);
 		}
 		HIP_TRY(hipGetLastError());
 		return 0;
