@@ -160,6 +160,9 @@ int  tspws_hip_stack(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_siga
  * launches of up to max_calls calls); _end synchronises the device and returns the mean per call. */
 int  tspws_hip_profile_begin(tspws_hip_plan *plan, size_t max_calls);
 int  tspws_hip_profile_end(tspws_hip_plan *plan, double *mean_ms, size_t *ncalls);
+/* Number of streaming-kernel (k_partial) launches the last partial-stack / stack_local call issued: the traces are walked a
+ * few groups at a time so that every launch puts one workgroup on every CU. */
+int  tspws_hip_stream_launches(const tspws_hip_plan *plan);
 
 /* ---- jackknife (two-stage only, like the reference) ------------------------------------- */
 /* Host: deletion masks sel[C][mtr] (1 = kept) from start times.  JackknifePlans, :385-430.

@@ -103,6 +103,7 @@ SYMBOLS = {
     "tspws_hip_stack": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "tspws_hip_profile_begin": (_i, [_vp, _sz]),
     "tspws_hip_profile_end": (_i, [_vp, C.POINTER(_d), C.POINTER(_sz)]),
+    "tspws_hip_stream_launches": (_i, [_vp]),
     "tspws_jackknife_plan": (_i, [_vp, _vp, _sz, _u, _u, _u]),
     "tspws_hip_jackknife": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _u, _vp, _vp, _vp, _vp]),
     "tspws_hip_jackknife_prepare": (_i, [_vp, _vp, _vp, _u, _sz]),

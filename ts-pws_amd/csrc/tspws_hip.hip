@@ -173,6 +173,7 @@ struct tspws_hip_plan {
 		std::vector<Chunk> chunks;                      // host tables stay alive while copies may be in flight
 		std::vector<unsigned> row_first, rp, cols;
 	} cs;
+	unsigned last_stream_launches = 0; // k_partial launches of the last streaming pass (bench.py: per-launch roofline figures)
 	bool jk_prepared = false;
 	std::vector<char> jk_sel;
 	unsigned jk_C = 0, jk_KM = 0;
@@ -854,7 +855,9 @@ static int run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, 
 		for (size_t c = ck0; c < ck1; c++) rows_total += chunks[c].count;
 		const bool long_runs = ck1 > ck0 && rows_total / (ck1 - ck0) >= 256;
 		const unsigned rpl = long_runs ? std::max(1u, (unsigned)wg_target / std::max(1u, bx)) : 65535u;
+		p->last_stream_launches = 0;
 		for (size_t c0 = ck0; c0 < ck1; c0 += rpl) {
+			p->last_stream_launches++;
 			const unsigned ny = (unsigned)std::min<size_t>(ck1 - c0, rpl);
 			double *dst = d_P + (size_t)(row_begin + (c0 - ck0)) * ldP;
 			if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, dst, ldP);
@@ -863,7 +866,9 @@ static int run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, 
 		HIP_TRY(hipGetLastError());
 		return 0;
 	}
+	p->last_stream_launches = 0;
 	for (size_t c0 = ck0; c0 < ck1; c0 += 65535) {
+		p->last_stream_launches++;
 		const unsigned ny = (unsigned)std::min<size_t>(ck1 - c0, 65535);
 		if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, (double *)d_pc + c0 * ldpc, ldpc);
 		else hipLaunchKernelGGL(k_partial<false>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, (double *)d_pc + c0 * ldpc, ldpc);
@@ -2074,6 +2079,8 @@ extern "C" int tspws_hip_profile_begin(tspws_hip_plan *pl, size_t max_calls)
 	pl->prof_used = 0;
 	return 0;
 }
+
+extern "C" int tspws_hip_stream_launches(const tspws_hip_plan *pl) { return pl ? (int)pl->last_stream_launches : 0; }
 
 extern "C" int tspws_hip_profile_end(tspws_hip_plan *pl, double *mean_ms, size_t *ncalls)
 {
