@@ -39,16 +39,18 @@ struct OctDesc {
 	unsigned gen, pad1;     // gen: D does not divide N (three-frame form, see k_inv_poly)
 };
 
-template <int NREC>
+// GEN = the three-frame form for octaves whose D does not divide N (its own instantiation: the masked loads and 64-bit
+// index arithmetic would otherwise cost the common case registers and time; the host launches the two classes separately)
+template <int NREC, bool GEN>
 __global__ void __launch_bounds__(256) k_inv_poly(const double2 *__restrict__ Y, size_t ncoef, unsigned N, const ScaleDesc *__restrict__ sc,
                                                   const OctDesc *__restrict__ oc, unsigned noct, const double2 *__restrict__ wd,
                                                   double *__restrict__ obuf, size_t slot_stride, unsigned total_waves, size_t y_coef,
-                                                  size_t y_obuf)
+                                                  size_t y_obuf, unsigned wave_base)
 {
 	Y += (size_t)blockIdx.y * y_coef; obuf += (size_t)blockIdx.y * y_obuf; // blockIdx.y = independent reconstruction set
 	constexpr int R = INV_R;
 	const unsigned lane = threadIdx.x & 63;
-	const unsigned wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const unsigned wid = wave_base + blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	if (wid >= total_waves) return;
 	unsigned lo = 0, hi = noct;
 	while (hi - lo > 1) {
@@ -70,7 +72,7 @@ __global__ void __launch_bounds__(256) k_inv_poly(const double2 *__restrict__ Y,
 #pragma unroll
 		for (int r = 0; r < R; r++) acc[c][r] = 0;
 
-	if (o.gen) {
+	if constexpr (GEN) {
 		// D does not divide N (cdotx.c:313-337: the zero-stuffed grid restarts at the circular seam).  With the raw position
 		// P = n - cd + l in (-N, 2N), frame f = floor(P / N) and in-frame position p = P - f N, a tap is on the grid iff
 		// D | p and then meets coefficient p / D.  Per frame this is the ordinary polyphase correlation for the shifted
@@ -125,7 +127,7 @@ __global__ void __launch_bounds__(256) k_inv_poly(const double2 *__restrict__ Y,
 				}
 			}
 		}
-	} else
+	} else {
 	for (unsigned v = 0; v < o.nv; v++) {
 		const ScaleDesc d = sc[o.s0 + v];
 		const double2 *ws = wd + d.tap_off;
@@ -184,6 +186,7 @@ __global__ void __launch_bounds__(256) k_inv_poly(const double2 *__restrict__ Y,
 				for (int r = 0; r < R - 1; r++) yw[c][r] = yw[c][r + 1];
 			l += D;
 		}
+	}
 	}
 	if (!live) return;
 	double *dst = obuf + (size_t)o.slot * slot_stride;

@@ -128,7 +128,7 @@ struct tspws_hip_plan {
 	FwdGroup *d_pairs = nullptr;
 	double *d_bt = nullptr;
 	size_t mfma_lds = 0;
-	unsigned inv_waves = 0, inv_noct = 0, inv_ngeneric = 0; // polyphase inverse: waves, octave items, scales left to the generic kernel
+	unsigned inv_waves = 0, inv_waves_fast = 0, inv_noct = 0, inv_ngeneric = 0; // polyphase inverse: waves (of the octaves whose D divides N first), octave items, scales left to the generic kernel
 	struct OctDesc *d_oc = nullptr;
 	std::vector<ScaleDesc> sc;
 	ScaleDesc *d_sc = nullptr;
@@ -1863,10 +1863,16 @@ static int build_inverse_items(tspws_hip_plan *p)
 		o.MC = o.D > 64 ? (o.D + 63) / 64 : 1;
 		const unsigned NG = (o.Ns + INV_R - 1) / INV_R, GW = 64 / o.DL;
 		o.ngw = (NG + GW - 1) / GW;
-		o.wave_off = woff; o.slot = (unsigned)oc.size();
-		woff += o.MC * o.ngw;
 		oc.push_back(o);
 		s = e;
+	}
+	// octaves whose decimation divides N first: the two classes are launched separately (k_inv_poly<., GEN>)
+	std::stable_sort(oc.begin(), oc.end(), [](const OctDesc &x, const OctDesc &y) { return x.gen < y.gen; });
+	p->inv_waves_fast = 0;
+	for (size_t i = 0; i < oc.size(); i++) {
+		oc[i].wave_off = woff; oc[i].slot = (unsigned)i;
+		woff += oc[i].MC * oc[i].ngw;
+		if (!oc[i].gen) p->inv_waves_fast = woff;
 	}
 	p->inv_waves = woff; p->inv_noct = (unsigned)oc.size();
 	if (!oc.empty()) {
@@ -1899,8 +1905,12 @@ static int inverse_launch(tspws_hip_plan *p, const double2 *Y, double *x, hipStr
 	int rc = scratch(p, SCR_OBUF, (size_t)nb * nslots * slot * sizeof(double), &v);
 	if (rc) return rc;
 	double *obuf = (double *)v;
-	hipLaunchKernelGGL(k_inv_poly<NREC>, dim3((p->inv_waves + 3) / 4, nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->d_oc, p->inv_noct,
-	                   p->d_wd, obuf, slot, p->inv_waves, (size_t)NREC * p->ncoef, (size_t)nslots * slot);
+	if (p->inv_waves_fast)
+		hipLaunchKernelGGL((k_inv_poly<NREC, false>), dim3((p->inv_waves_fast + 3) / 4, nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->d_oc, p->inv_noct,
+		                   p->d_wd, obuf, slot, p->inv_waves_fast, (size_t)NREC * p->ncoef, (size_t)nslots * slot, 0u);
+	if (p->inv_waves > p->inv_waves_fast)
+		hipLaunchKernelGGL((k_inv_poly<NREC, true>), dim3((p->inv_waves - p->inv_waves_fast + 3) / 4, nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc,
+		                   p->d_oc, p->inv_noct, p->d_wd, obuf, slot, p->inv_waves, (size_t)NREC * p->ncoef, (size_t)nslots * slot, p->inv_waves_fast);
 	if (p->inv_ngeneric)
 		hipLaunchKernelGGL(k_inverse_generic<NREC>, dim3(nbx, nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->S, p->d_wd,
 		                   obuf + (size_t)p->inv_noct * slot, 1, (size_t)NREC * p->ncoef, (size_t)nslots * slot);
