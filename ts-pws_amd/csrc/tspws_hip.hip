@@ -2126,58 +2126,47 @@ extern "C" int tspws_hip_stack(tspws_hip_plan *pl, const t_tsPWS *p, const float
 	hipStream_t A = S_(s);
 	const unsigned K = p->Kmax;
 	const size_t N = pl->N, nc = pl->ncoef;
-	// ---- everything that may allocate happens before the first launch ----
-	if (!pl->aux) HIP_TRY(hipStreamCreateWithFlags(&pl->aux, hipStreamNonBlocking));
-	if (!pl->ev_done) HIP_TRY(hipEventCreateWithFlags(&pl->ev_done, hipEventDisableTiming));
+	if (!pl->aux) {
+		int lo = 0, hi = 0; // numerically larger = lower priority
+		(void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+		const char *e = getenv("TSPWS_AUX_PRIO");
+		const int pr = e ? (atoi(e) > 0 ? lo : atoi(e) < 0 ? hi : 0) : 0; // >0: lowest, <0: highest, 0: default
+		HIP_TRY(hipStreamCreateWithPriority(&pl->aux, hipStreamNonBlocking, pr));
+	}
+	if (!pl->ev_done) HIP_TRY(hipEventCreateWithFlags(&pl->ev_done, hipEventDisableTiming | hipEventDisableSystemFence));
 	while (pl->ev_grp.size() < (size_t)K + 1) {
 		hipEvent_t e;
-		HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
 		pl->ev_grp.push_back(e);
 	}
 	hipStream_t Bq = pl->aux;
-	build_group_chunks(pl, mtr, 0, mtr, K);
-	const size_t nck = pl->chunks.size(), ldpc = (N + 3) & ~(size_t)3;
 	void *v;
 	double *P; size_t nd;
 	if ((rc = tspws_hip_reduce_buffer(pl, p, mtr, &P, &nd))) return rc;
-	Chunk *d_chunks = nullptr;
-	unsigned *d_rf = nullptr;
-	if ((rc = scratch(pl, SCR_CHUNK, nck * ldpc * sizeof(double), &v))) return rc;
-	double *d_pc = (double *)v;
-	if ((rc = scratch(pl, SCR_PART, (size_t)K * pl->npart * sizeof(double2), &v))) return rc;
-	double2 *part = (double2 *)v;
 	if ((rc = scratch(pl, SCR_OUT, 6 * nc * sizeof(double), &v))) return rc;
 	double *OUT = (double *)v, *ST = OUT + 2 * nc, *PS = ST + 2 * nc;
 	if ((rc = scratch(pl, SCR_X2, 2 * N * sizeof(double), &v))) return rc;
 	double *x2 = (double *)v;
-	if (pl->inv_noct && (rc = scratch(pl, SCR_OBUF, (size_t)(pl->inv_noct + (pl->inv_ngeneric ? 1 : 0)) * 2 * N * sizeof(double), &v))) return rc;
-	if ((rc = chunk_tables(pl, pl->chunks, pl->row_first, K, A, true, &d_chunks, &d_rf))) return rc;
 	// the aux stream must not start before earlier work on the caller's stream (e.g. a previous call's readers)
 	HIP_TRY(hipEventRecord(pl->ev_grp[K], A));
 	HIP_TRY(hipStreamWaitEvent(Bq, pl->ev_grp[K], 0));
 	const bool prof = pl->prof_used + 2 <= pl->prof_ev.size();
-	unsigned pipe_batch = 5;
-	if (const char *e = getenv("TSPWS_PIPE_BATCH")) pipe_batch = (unsigned)std::max(1, atoi(e));
+	// groups per hand-over: a multiple of what one streaming launch covers (one workgroup per CU: two groups at N = 131072)
 	const unsigned bx = (unsigned)((N + 1023) / 1024);
-	const bool vec = (N % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x & 15) == 0);
+	unsigned pipe_batch = std::max(1u, 256u / std::max(1u, bx));
+	if (const char *e = getenv("TSPWS_PIPE_BATCH")) pipe_batch = (unsigned)std::max(1, atoi(e));
 	if (prof) HIP_TRY(hipEventRecord(pl->prof_ev[pl->prof_used], A));
-	for (unsigned g = 0; g < K; g++) {
-		const unsigned c0 = pl->row_first[g], c1 = pl->row_first[g + 1];
-		if (c1 > c0) {
-			if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, c1 - c0), dim3(256), 0, A, d_x, ld, N, d_chunks + c0, d_pc + (size_t)c0 * ldpc, ldpc);
-			else hipLaunchKernelGGL(k_partial<false>, dim3(bx, c1 - c0), dim3(256), 0, A, d_x, ld, N, d_chunks + c0, d_pc + (size_t)c0 * ldpc, ldpc);
-		}
-		hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((N + 255) / 256), 1), dim3(256), 0, A, (const double *)d_pc, ldpc, d_rf + g,
-		                   P + (size_t)g * N, N, N);
-		// hand finished groups to the transform stream in batches (a batch of traces shares the tap reads and
-		// fills the GPU better than single-trace launches)
-		if ((g + 1) % pipe_batch == 0 || g + 1 == K) {
-			const unsigned gb = (g / pipe_batch) * pipe_batch, nb = g + 1 - gb;
-			HIP_TRY(hipEventRecord(pl->ev_grp[g], A));
-			HIP_TRY(hipStreamWaitEvent(Bq, pl->ev_grp[g], 0));
-			if ((rc = forward_parts<double>(pl, P + (size_t)gb * N, nb, N, part + (size_t)gb * pl->npart, Bq))) return rc;
-			launch_accumulate(pl, (const double2 *)(part + (size_t)gb * pl->npart), nb, (double2 *)ST, (double2 *)PS, gb == 0 ? 1 : 0, nullptr, 0, Bq);
-		}
+	std::vector<unsigned> sched; // TSPWS_PIPE_SCHED=4,4,2: hand-over sizes in groups (the last one repeats)
+	if (const char *e = getenv("TSPWS_PIPE_SCHED")) { for (const char *q = e; *q;) { sched.push_back((unsigned)std::max(1, atoi(q))); while (*q && *q != ',') q++; if (*q == ',') q++; } }
+	size_t si = 0;
+	for (unsigned g0 = 0, step = pipe_batch; g0 < K; g0 += step) {
+		step = sched.empty() ? pipe_batch : sched[std::min(si++, sched.size() - 1)];
+		const unsigned g1 = std::min(K, g0 + step);
+		if ((rc = tspws_hip_partial_stacks_range(pl, d_x, ld, mtr, 0, mtr, K, g0, g1, P, N, A))) return rc;
+		HIP_TRY(hipEventRecord(pl->ev_grp[g0], A));
+		HIP_TRY(hipStreamWaitEvent(Bq, pl->ev_grp[g0], 0));
+		// transforms + phase stacks of the finished groups beside the streaming of the next ones
+		if ((rc = stacks_impl<double>(pl, P + (size_t)g0 * N, g1 - g0, N, ST, PS, Bq, g0 != 0))) return rc;
 	}
 	if (prof) { HIP_TRY(hipEventRecord(pl->prof_ev[pl->prof_used + 1], A)); pl->prof_used += 2; }
 	if ((rc = tspws_hip_weight(pl, OUT, ST, PS, K, (unsigned)mtr, p->wu, p->unbiased, Bq))) return rc;
