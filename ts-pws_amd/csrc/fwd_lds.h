@@ -435,19 +435,15 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 
 // grid = (workgroups of all LDS scales, trace slices); a workgroup handles traces [slice*tps, min(ntr, (slice+1)*tps))
 // FUSE: accST / accPS + slice * acc_stride are the [ncoef] planes that receive the slice's stacks of the unsplit scales.
+// one workgroup of the LDS kernel: `bid` = its index among the lds_blocks workgroups of a trace slice, `slice` = trace slice
 template <typename TIn, bool FUSE>
-__global__ void __launch_bounds__(FL_NT, 2) k_fwd_lds(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
-                                                 const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
-                                                 double2 *__restrict__ part, size_t npart, double2 *__restrict__ accST,
-                                                 double2 *__restrict__ accPS, size_t acc_stride, unsigned rev)
+__device__ __forceinline__ void fwd_lds_workgroup(const unsigned bid, const unsigned slice, char *smem, const TIn *__restrict__ x, size_t ld,
+                                                  unsigned ntr, unsigned tps, unsigned N, const ScaleDesc *__restrict__ sc, unsigned S,
+                                                  const double2 *__restrict__ w, double2 *__restrict__ part, size_t npart,
+                                                  double2 *__restrict__ accST, double2 *__restrict__ accPS, size_t acc_stride)
 {
-	extern __shared__ __attribute__((aligned(16))) char smem[];
 	double2 *tL = (double2 *)smem;
 	double *xL = (double *)(smem + FL_TAPS_BYTES);
-	// Workgroups are dispatched in blockIdx order and a launch is a few rounds of ~46 us workgroups, so the LAST round sets
-	// the tail: walk the scales from coarse to fine -- the fine scales (D <= 4: one slot per wave, half the work) finish
-	// the launch with short workgroups.
-	const unsigned bid = rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 	// scale of this workgroup: last s with lds_off[s] <= bid among the scales that use this kernel
 	unsigned lo = 0, hi = S;
 	while (hi - lo > 1) {
@@ -457,12 +453,12 @@ __global__ void __launch_bounds__(FL_NT, 2) k_fwd_lds(const TIn *__restrict__ x,
 	const ScaleDesc d = sc[lo];
 	const unsigned wl = bid - d.lds_off;
 	const unsigned chunk = wl / d.lds_bps, bb = wl - chunk * d.lds_bps; // one 64-phase chunk per workgroup (split == chunk)
-	const unsigned t0 = blockIdx.y * tps;
+	const unsigned t0 = slice * tps;
 	const unsigned nt = (ntr - t0) < tps ? (ntr - t0) : tps;
 	const TIn *x0 = x + (size_t)t0 * ld;
 	const double2 *ws = w + d.tap_off;
 	double *pout0 = (double *)(part + (size_t)t0 * npart + d.part_off + (size_t)chunk * d.Ns);
-	double2 *aS = FUSE ? accST + (size_t)blockIdx.y * acc_stride : nullptr, *aP = FUSE ? accPS + (size_t)blockIdx.y * acc_stride : nullptr;
+	double2 *aS = FUSE ? accST + (size_t)slice * acc_stride : nullptr, *aP = FUSE ? accPS + (size_t)slice * acc_stride : nullptr;
 	if (d.D >= 64) { fwd_lds_body<TIn, 6, FUSE, FL_PASSES>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); return; }
 	switch (d.logDL) {
 	case 0: fwd_lds_body<TIn, 0, FUSE, FL_PASSES_FINE>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break; // D = 1 (Mexican hat, uni): 8 coefficients per lane
@@ -472,4 +468,20 @@ __global__ void __launch_bounds__(FL_NT, 2) k_fwd_lds(const TIn *__restrict__ x,
 	case 4: fwd_lds_body<TIn, 4, FUSE, FL_PASSES>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
 	default: fwd_lds_body<TIn, 5, FUSE, FL_PASSES>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
 	}
+}
+
+// grid = (workgroups of all LDS scales, trace slices); a workgroup handles traces [slice*tps, min(ntr, (slice+1)*tps))
+// FUSE: accST / accPS + slice * acc_stride are the [ncoef] planes that receive the slice's stacks of the unsplit scales.
+template <typename TIn, bool FUSE>
+__global__ void __launch_bounds__(FL_NT, 2) k_fwd_lds(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
+                                                 const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
+                                                 double2 *__restrict__ part, size_t npart, double2 *__restrict__ accST,
+                                                 double2 *__restrict__ accPS, size_t acc_stride, unsigned rev)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	// Workgroups are dispatched in blockIdx order and a launch is a few rounds of ~46 us workgroups, so the LAST round sets
+	// the tail: walk the scales from coarse to fine -- the fine scales (D <= 4: one slot per wave, half the work) finish
+	// the launch with short workgroups.
+	const unsigned bid = rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+	fwd_lds_workgroup<TIn, FUSE>(bid, blockIdx.y, smem, x, ld, ntr, tps, N, sc, S, w, part, npart, accST, accPS, acc_stride);
 }

@@ -61,22 +61,22 @@ struct OctFwd {
 	unsigned long long tap_off[FO_VMAX], part_off[FO_VMAX];
 };
 
+// one workgroup: `bid` = its index among the workgroups of a trace slice, `slice` = trace slice
 template <typename TIn>
-__global__ void __launch_bounds__(FO_NT, 2) k_fwd_oct(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
-                                                      const OctFwd *__restrict__ oc, unsigned noct, const double2 *__restrict__ w,
-                                                      double2 *__restrict__ part, size_t npart, const TIn *__restrict__ xcm,
-                                                      unsigned ntr_all)
+__device__ __forceinline__ void fwd_oct_workgroup(const unsigned bid, const unsigned slice, char *smem, const TIn *__restrict__ x, size_t ld,
+                                                  unsigned ntr, unsigned tps, unsigned N, const OctFwd *__restrict__ oc, unsigned noct,
+                                                  const double2 *__restrict__ w, double2 *__restrict__ part, size_t npart,
+                                                  const TIn *__restrict__ xcm, unsigned ntr_all)
 {
 	constexpr int R = 8;
-	extern __shared__ __attribute__((aligned(16))) char smem[];
 	unsigned lo = 0, hi = noct;
 	while (hi - lo > 1) {
 		const unsigned mid = (lo + hi) >> 1;
-		if (oc[mid].wg_off <= blockIdx.x) lo = mid; else hi = mid;
+		if (oc[mid].wg_off <= bid) lo = mid; else hi = mid;
 	}
 	const OctFwd *__restrict__ o = oc + lo;
 	const unsigned D = o->D, Ns = o->Ns, nv = o->nv, XR = o->XR, amax = o->amax, trows = o->trows;
-	const unsigned wl = blockIdx.x - o->wg_off;
+	const unsigned wl = bid - o->wg_off;
 	const unsigned ci = wl / o->nob, ob = wl - ci * o->nob;
 	const unsigned tid = threadIdx.x, lane = tid & 63;
 	const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(FO_NT, 2) k_fwd_oct(const TIn *__restrict__ x,
 	double2 *tL = (double2 *)smem;                                      // [trows][64]: voice v owns rows trow[v] .. trow[v] + QR[v] - 1
 	double *xL = (double *)(smem + (size_t)trows * 64 * sizeof(double2)); // [XR][64]
 
-	const unsigned t0 = blockIdx.y * tps;
+	const unsigned t0 = slice * tps;
 	const unsigned nt = (ntr - t0) < tps ? (ntr - t0) : tps;
 	const TIn *x0 = x + (size_t)t0 * ld;
 
@@ -286,7 +286,42 @@ __global__ void __launch_bounds__(FO_NT, 2) k_fwd_oct(const TIn *__restrict__ x,
 #undef FO_STAMP
 }
 
-// ------------------------------------------------------------------------------------------------------------------
+
+template <typename TIn>
+__global__ void __launch_bounds__(FO_NT, 2) k_fwd_oct(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
+                                                      const OctFwd *__restrict__ oc, unsigned noct, const double2 *__restrict__ w,
+                                                      double2 *__restrict__ part, size_t npart, const TIn *__restrict__ xcm,
+                                                      unsigned ntr_all)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	fwd_oct_workgroup<TIn>(blockIdx.x, blockIdx.y, smem, x, ld, ntr, tps, N, oc, noct, w, part, npart, xcm, ntr_all);
+}
+
+#if FO_WAVES == 4
+// ONE launch for the octave-fused workgroups (D >= 64) and the LDS-kernel workgroups (D < 64): same block size, LDS = the
+// larger of the two, no streams / events between them and the block scheduler balances the two kinds.  The octave
+// workgroups (long) come first, `oct_slices` trace slices of them; the LDS workgroups follow, coarse scales first.
+template <typename TIn, bool FUSE>
+__global__ void __launch_bounds__(FL_NT, 2) k_fwd_lds_oct(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
+                                                          const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
+                                                          double2 *__restrict__ part, size_t npart, double2 *__restrict__ accST,
+                                                          double2 *__restrict__ accPS, size_t acc_stride, unsigned lds_blocks,
+                                                          const OctFwd *__restrict__ oc, unsigned noct, unsigned oct_wgs, unsigned oct_slices,
+                                                          unsigned oct_tps, const TIn *__restrict__ xcm)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const unsigned noctb = oct_wgs * oct_slices;
+	if (blockIdx.x < noctb) {
+		if (blockIdx.y) return; // the octave workgroups slice the traces themselves
+		const unsigned sl = blockIdx.x / oct_wgs;
+		fwd_oct_workgroup<TIn>(blockIdx.x - sl * oct_wgs, sl, smem, x, ld, ntr, oct_tps, N, oc, noct, w, part, npart, xcm, ntr);
+		return;
+	}
+	const unsigned bid = lds_blocks - 1u - (blockIdx.x - noctb); // coarse scales first
+	fwd_lds_workgroup<TIn, FUSE>(bid, blockIdx.y, smem, x, ld, ntr, tps, N, sc, S, w, part, npart, accST, accPS, acc_stride);
+}
+#endif
+
 // k_fwd_oct2: the same octave-fused transform as a two-team software pipeline.
 //
 // Why: with FL_TIMING the window load turned out to be bound by what one CU pulls in (~16 B/cycle: 90 KB for the two

@@ -1149,7 +1149,7 @@ static int build_oct_forward(tspws_hip_plan *p, std::vector<char> &is_oct)
 		p->cm_n[ti] = 0; p->cm_per_trace[ti] = 0;
 		const size_t esz = ti ? sizeof(double) : sizeof(float);
 		static int cm_on = -1;
-		if (cm_on < 0) { const char *e = getenv("TSPWS_FWD_CM"); cm_on = (e && *e == '0') ? 0 : 1; }
+		if (cm_on < 0) { const char *e = getenv("TSPWS_FWD_CM"); cm_on = (e && *e == '1') ? 1 : 0; } // opt-in: measured no faster than the strided windows
 		for (OctFwd &o : tab) {
 			o.cm_slot[ti] = ~0u; o.cm_pre[ti] = 0;
 			if (!cm_on || (size_t)o.D * esz <= 4096 || p->N % o.D != 0) continue;
@@ -1187,6 +1187,10 @@ static int upload_oct_forward(tspws_hip_plan *p)
 	HIP_TRY(hipMemcpy(p->d_ofw, tab, p->ofw_host.size(), hipMemcpyHostToDevice));
 	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_oct<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FO_LDS_MAX));
 	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_oct<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FO_LDS_MAX));
+	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_lds_oct<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FO_LDS_MAX));
+	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_lds_oct<double, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FO_LDS_MAX));
+	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_lds_oct<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FO_LDS_MAX));
+	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_lds_oct<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FO_LDS_MAX));
 	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_oct2<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS_MAX));
 	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_oct2<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS_MAX));
 	return 0;
@@ -1382,7 +1386,11 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 	// Up to three independent kernels transform disjoint sets of scales: the octave-fused kernel (D >= 64), the LDS kernel
 	// (D < 64) and the direct kernel (coarse scales, latency-bound).  They run side by side: two side streams are forked
 	// from and joined back into the caller's stream.
-	const int nk = (p->lds_blocks ? 1 : 0) + (p->fwd_waves ? 1 : 0) + (p->oct_wgs ? 1 : 0);
+	// merged: the octave-fused (mode 1) and the LDS workgroups share ONE launch (k_fwd_lds_oct); TSPWS_OCT_MERGE=0: own launches
+	static int merge_env = -1;
+	if (merge_env < 0) { const char *e = getenv("TSPWS_OCT_MERGE"); merge_env = (e && *e == '0') ? 0 : 1; }
+	const bool merged = merge_env && p->oct_wgs && p->lds_blocks && p->oct_mode == 1 && ntr <= 65535;
+	const int nk = (p->lds_blocks ? 1 : 0) + (p->fwd_waves ? 1 : 0) + ((p->oct_wgs && !merged) ? 1 : 0);
 	const bool both = nk > 1 && side_stream_enabled();
 	hipStream_t sp = st, so = st; // streams of the direct and of the octave kernel
 	if (both) {
@@ -1394,9 +1402,26 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 		if (!p->ev_join2) HIP_TRY(hipEventCreateWithFlags(&p->ev_join2, evf));
 		HIP_TRY(hipEventRecord(p->ev_fork, st));
 		if (p->fwd_waves && nk > 1) { HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0)); sp = p->side; }
-		if (p->oct_wgs && p->lds_blocks) { HIP_TRY(hipStreamWaitEvent(p->side2, p->ev_fork, 0)); so = p->side2; }
+		if (p->oct_wgs && p->lds_blocks && !merged) { HIP_TRY(hipStreamWaitEvent(p->side2, p->ev_fork, 0)); so = p->side2; }
 	}
-	if (p->oct_wgs) {
+	constexpr int TIX = sizeof(TIn) == 8 ? 1 : 0;
+	TIn *xcm_m = nullptr; // merged launch: chunk-major copies (if enabled) are made on the caller's stream first
+	if (merged && p->cm_n[TIX]) {
+		void *vx;
+		int rcx = scratch(p, SCR_XCM, ntr * p->cm_per_trace[TIX] * sizeof(TIn), &vx);
+		if (rcx) return rcx;
+		xcm_m = (TIn *)vx;
+		ChunkMajor cmj;
+		memset(&cmj, 0, sizeof cmj);
+		cmj.n = p->cm_n[TIX];
+		size_t big = 0;
+		for (unsigned k = 0; k < cmj.n; k++) {
+			cmj.D[k] = p->cm_D[TIX][k]; cmj.MC[k] = p->cm_MC[TIX][k];
+			big = std::max(big, (size_t)cmj.MC[k] * (p->N / cmj.D[k]) * 64);
+		}
+		hipLaunchKernelGGL((k_chunk_major<TIn>), dim3((unsigned)((big + 255) / 256), (unsigned)ntr, cmj.n), dim3(256), 0, st, d_x, ld, (unsigned)ntr, p->N, cmj, xcm_m);
+	}
+	if (p->oct_wgs && !merged) {
 		unsigned tps = (unsigned)std::min<size_t>(ntr, 32);
 		// mode 2: one workgroup per CU, so a single slice is best once half the CUs have work; mode 1: two per CU
 		const size_t want = p->oct_mode == 2 ? 128 : 256;
@@ -1458,6 +1483,21 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 		if (rev_env < 0) { const char *e = getenv("TSPWS_FWD_REV"); rev_env = (e && *e == '0') ? 0 : 1; }
 		const unsigned rev = (unsigned)rev_env;
 		const size_t per_launch = (size_t)tps * 65535;
+		if (merged) {
+			// octave workgroups: slices of the traces so that a workgroup lasts about as long as an LDS-kernel workgroup
+			static int osl = -1;
+			if (osl < 0) { const char *e = getenv("TSPWS_OCT_SLICES"); osl = e ? std::max(1, atoi(e)) : 2; }
+			const unsigned nsl = (unsigned)std::min<size_t>(ntr, (size_t)osl), otps = (unsigned)((ntr + nsl - 1) / nsl);
+			const unsigned oslices = (unsigned)((ntr + otps - 1) / otps);
+			const size_t lds = std::max<size_t>(FL_LDS_BYTES, p->oct_lds);
+			const dim3 grid(p->oct_wgs * oslices + p->lds_blocks, (unsigned)((ntr + tps - 1) / tps));
+			if (fuse)
+				hipLaunchKernelGGL((k_fwd_lds_oct<TIn, true>), grid, dim3(FL_NT), lds, st, d_x, ld, (unsigned)ntr, tps, p->N, p->d_sc, p->S, p->d_w, d_part, p->npart,
+				                   fz->accST, fz->accPS, fz->stride, p->lds_blocks, p->d_ofw, p->oct_n, p->oct_wgs, oslices, otps, (const TIn *)xcm_m);
+			else
+				hipLaunchKernelGGL((k_fwd_lds_oct<TIn, false>), grid, dim3(FL_NT), lds, st, d_x, ld, (unsigned)ntr, tps, p->N, p->d_sc, p->S, p->d_w, d_part, p->npart,
+				                   (double2 *)nullptr, (double2 *)nullptr, (size_t)0, p->lds_blocks, p->d_ofw, p->oct_n, p->oct_wgs, oslices, otps, (const TIn *)xcm_m);
+		} else
 		for (size_t t0 = 0; t0 < ntr; t0 += per_launch) {
 			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, per_launch);
 			if (fuse)
