@@ -6,13 +6,13 @@
 // traces: the x window of trace t+1 is fetched into registers while trace t is computed out of LDS, so the
 // global-memory latency hides behind the FMAs and the tap staging / scale set-up is paid once per workgroup.
 //
-// Why it is written the way it is (PMC, round 1): on gfx950 a wave64 v_fma_f64 costs 4 cycles and an integer
-// VALU op 2, so address arithmetic, predicates and 64-bit pointer math -- not the FP64 pipe -- were >75 % of the
-// issued VALU instructions of the first versions.  Hence: the body is templated on log2(D) so every LDS
-// address in the FMA loop is `one base VGPR + immediate`; staging has a predicate-free fast path (window fully
-// inside the trace, all taps inside the filter) and a generic slow path for the few workgroups at the circular
-// seam / filter end; the 64-lane phase reduction of D >= 64 goes through an LDS transpose (1 write + 1 read per
-// value) instead of 5-instruction shuffle stages.
+// Why it is written the way it is: a wave64 v_fma_f64 costs 4 cycles and so does almost every other 64-bit VALU op, so
+// address arithmetic, predicates and pointer math compete with the FP64 FMAs for the same issue slots.  Hence: the body
+// is templated on log2(D) so every LDS address in the FMA loop is `one base VGPR + immediate`; the window loads use a
+// uniform base pointer plus ONE opaque 32-bit offset per thread (the compiler otherwise hoists all row offsets out of
+// the trace loop as 64-bit pairs: 56 VGPRs and spills); the prefetched window stays raw in registers (conversion and the
+// idle-lane mask happen at the LDS store); the lane reductions run on the VALU (permlane swaps + DPP: no LDS traffic);
+// the workgroup barriers order LDS only (fl_lds_barrier below).
 //
 //   LOGD = 6 (D >= 64, any D): slot = output group g0+slot, lanes = 64 consecutive phases of the chunk;
 //             LDS x image  xL[row][64]   row j <-> sample (g0*8 + qa + j) D + m0 + lane - c   (88 rows)
@@ -22,16 +22,17 @@
 //             a wave fall on distinct banks (group stride 9 D doubles).
 //   Q <= 24 taps per phase: taps resident, one stage per trace.  Q > 24: balanced tiles of <= 24, taps re-staged.
 //
-// Tunables (compile time): FL_WAVES x FL_PASSES group slots per workgroup, FL_BATCH steps per LDS read burst.
-// Measured on MI355X for the 10 x 131072 north-star transforms: 4x2 (251 VGPR, 2 waves/SIMD) 166 us; 8x1 forced to
-// 128 VGPR (4 waves/SIMD, 60 B spill) 177 us; 4x1 with 16-row tap tiles (3 blocks/CU) 178 us.  tools/fma64_peak.hip
-// shows why none of them is near the FP64 roof: a pure v_fma_f64 stream sustains 23 / 42 / 49 / 55 / 60 TFLOP/s at
-// 1 / 2 / 4 / 8 / 16+ waves per SIMD, i.e. the pipe needs >= 4 FMA-issuing waves per SIMD, which this register tile
-// (64 accumulator VGPRs + staging) does not leave room for.
-// Ablation (same build, 10 x 131072): baseline 171 us; without the global x loads 151; additionally without the LDS
-// operand reads in the FMA loop 144; additionally without barriers 140 -- i.e. operand supply and synchronisation are
-// only ~30 us; the rest is the FMA stream itself at 2 waves/SIMD (~68 % of the sustained FP64 rate per the
-// micro-benchmark: ~100 us for these 1.6e9 lane-FMAs + 0.9e9 integer VALU ops) plus reduction / stores.
+// Tunables (compile time): FL_WAVES x FL_PASSES group slots per workgroup (FL_PASSES_FINE for D <= 4), FL_BATCH steps per
+// LDS read burst (FL_PREFETCH: the next burst's operands are requested first).
+// Measurements (MI355X, the ten 131072-sample north-star transforms):
+//   round 1: 4x2 slots 166 us; 8x1 forced to 128 VGPRs 177 us; 4x1 with 16-row tap tiles (3 workgroups per CU) 178 us.
+//   round 2 (-DFL_TIMING=1, tools/fwd_timing.py; PMC in profiles/r02_pmc_counters.txt): 138 us alone, 177-187 us with
+//   k_fwd_poly beside it.  Of the issued VALU instructions only 52 % are FMAs (48 M vs 25 M wave-instructions): lane
+//   reductions (~200 per wave and trace), window addressing (~100), phase normalisation, register moves; the VALU is
+//   active 51 % of the SIMD cycles, half of that in FMAs.  The D >= 64 workgroups spend 20-25 % of their cycles in the
+//   FMA passes: their 45 KB window (FP64 partial stacks) takes as long to pull in (~16 B/cycle per CU) as the FMAs take.
+//   One dense FMA-issuing wave per SIMD would be enough for ~85 % of the FP64 rate (tools/fma64_issue.hip) -- the time
+//   goes to everything around the FMA passes, not to the issue rate.
 //
 // Used for scales with at least 8 output groups (N_s >= 64) and D >= 64 or a power of two; everything else
 // (very coarse scales whose parallelism is only in the taps, odd small decimations) stays on k_fwd_poly.
