@@ -699,6 +699,7 @@ def test_prepared_jackknife_shares_the_streaming_pass(lib, torch):
     (dict(), 4096, 64), (dict(), 2048, 200), (dict(), 1501, 70), (dict(type=-3), 4096, 100), (dict(w0=2 * np.pi), 8192, 129),
     (dict(s0=3.7, J=6), 3001, 77), (dict(type=-2, wu=1.0), 2048, 90), (dict(unbiased=1), 16501, 96), (dict(uni=1, J=3), 1024, 65),
     (dict(b0=4.0), 8192, 80),
+    (dict(Kmax=80, unbiased=1), 2048, 200),   # two-stage with many groups: the 80 FP64 partial stacks take the many-trace path too
 ])
 def test_many_trace_single_stage_vs_oracle(lib, torch, kw, N, mtr):
     """Single-stage stacks of >= 64 traces run on the trace-lane kernel (csrc/fwd_tl.h: transposed batch, lanes = traces, fused
