@@ -180,6 +180,22 @@ int  tspws_hip_jackknife(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_
  * class sums.  The traces must not change between the two calls.  No-op for single-stage parameters. */
 int  tspws_hip_jackknife_prepare(tspws_hip_plan *plan, const t_tsPWS *p, const char *h_sel, unsigned C, size_t mtr);
 
+/* Trace-sharded jackknife (one shard per GPU; the reference has no counterpart -- its replicas, :735-813, walk one host
+ * array).  h_sel is the selection over the WHOLE ensemble, [C][mtr_global]; a trace's group in a replica is its rank among
+ * all selected traces (:766), so every shard evaluates the signatures globally and sums only its own traces.
+ *   _buffer : device rows [C * Kmax][max] doubles (row c * Kmax + g = group g of replica c), *nd = their count.
+ *   _local  : ONE pass over the shard fills those rows AND the rows of the plain two-stage groups
+ *             (tspws_hip_reduce_buffer) with the shard's sums; an empty shard gives zeros.  The caller adds the shards
+ *             (all-reduce, or a reduce of each replica's rows to the rank that owns it).
+ *   _finish : replicas [c_begin, c_end) from the (reduced) rows; outputs go to rows c_begin.. of the [C][max] arrays,
+ *             replica sizes to h_mtr_out[c_begin..]. */
+int  tspws_hip_jackknife_buffer(tspws_hip_plan *plan, const t_tsPWS *p, unsigned C, double **d_buf, size_t *nd);
+int  tspws_hip_jackknife_local(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_sigall, size_t ld, size_t mtr_local,
+                               size_t first, size_t mtr_global, const char *h_sel, unsigned C, void *stream);
+int  tspws_hip_jackknife_finish(tspws_hip_plan *plan, const t_tsPWS *p, size_t mtr_global, const char *h_sel, unsigned C,
+                                unsigned c_begin, unsigned c_end, float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out,
+                                void *stream);
+
 /* ---- random subsampling ---------------------------------------------------------------------- */
 /* Host: keep K of J traces at random with libc rand(), flipping whichever symbol is rarer.
  * SubsamplingPlan, ts_pws1f_lib.c:355-383 (same rand() call order, so the same masks from the same state). */

@@ -87,6 +87,91 @@ class OraclePlan:
         ls.copy_(torch.from_numpy(self.f.inverse(ST).astype(np.float32) / np.float32(mtr_global)))
 
 
+    # ---- trace-sharded jackknife: same interface as ts-pws_amd.Plan's jackknife_* methods ----
+    def jackknife_buffer(self, Cn):
+        n = Cn * self.p.Kmax * self.N
+        if getattr(self, "jbuf", None) is None or self.jbuf.numel() != n:
+            self.jbuf = torch.zeros(n, dtype=torch.float64)
+        return self.jbuf
+
+    def jackknife_local(self, traces, first, mtr_global, sel):
+        x = traces.numpy()
+        K, N, Cn = self.p.Kmax, self.N, sel.shape[0]
+        self.stack_local(traces, first, mtr_global)  # the plain groups
+        rows = self.jackknife_buffer(Cn)
+        rows.zero_()
+        R = rows.numpy().reshape(Cn, K, N)
+        for c in range(Cn):
+            Kc = int((sel[c] == 1).sum())
+            k = int((sel[c, :first] == 1).sum())     # rank among ALL selected traces (ts_pws1f_lib.c:766): global prefix
+            for i in range(x.shape[0]):
+                if sel[c, first + i] != 1:
+                    continue
+                g = int(np.floor(float(k * K) / float(Kc)))
+                R[c, g] += x[i].astype(np.float64)
+                k += 1
+
+    def jackknife_finish(self, mtr_global, sel, c_begin, c_end, ls_out, ts_out, mtr_out):
+        K, N, Cn, nc = self.p.Kmax, self.N, sel.shape[0], self.f.ncoef
+        orc = abi.oracle()
+        R = self.jackknife_buffer(Cn).numpy().reshape(Cn, K, N)
+        for c in range(c_begin, c_end):
+            Kc = int((sel[c] == 1).sum())
+            ST = np.zeros(nc, np.complex128)
+            PS = np.zeros(nc, np.complex128)
+            for g in range(K):
+                Y = self.f.forward(R[c, g])
+                orc.orc_accumulate(ST.ctypes.data, PS.ctypes.data, Y.ctypes.data, nc)
+            OUT = np.zeros(nc, np.complex128)
+            orc.orc_weight(OUT.ctypes.data, ST.ctypes.data, PS.ctypes.data, nc, K, Kc, self.p.wu, self.p.unbiased)
+            ts_out[c].copy_(torch.from_numpy(self.f.inverse(OUT).astype(np.float32)))
+            ls_out[c].copy_(torch.from_numpy((R[c].sum(axis=0) * (1.0 / Kc)).astype(np.float32)))
+            mtr_out[c] = Kc
+
+
+def _jk_times(mtr):
+    rng = np.random.default_rng(12)
+    return (1262304000 + 86400 * np.sort(rng.integers(0, 2 * 365, mtr))).astype(np.int64)
+
+
+def _jk_worker(rank, world, port, kw, mtr, N, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X = abi.synth_traces(mtr, N, seed=17)
+        p = abi.default_params(**kw)
+        Cn = abi.binomial(p.jackknife_n, p.jackknife_d)
+        sel = np.zeros((Cn, mtr), np.int8)
+        assert abi.oracle().orc_jackknife_plan(sel.ctypes.data, _jk_times(mtr).ctypes.data, mtr, p.jackknife_d, p.jackknife_n, Cn) == 0
+        first, count = tspws.shard_range(mtr, rank, world)
+        plan = OraclePlan(p, N)
+        ls, ts, jl, jt, jm = tspws.jackknife_sharded(plan, torch.from_numpy(X[first:first + count]), sel, first, mtr)
+        np.savez(os.path.join(out_dir, f"jk{rank}.npz"), ls=ls.numpy(), ts=ts.numpy(), jl=jl.numpy(), jt=jt.numpy(), jm=jm)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kw,mtr,world", [
+    (dict(Kmax=3, unbiased=1, jackknife_n=4, jackknife_d=1), 37, 2),   # 4 replicas on 2 ranks: two each
+    (dict(Kmax=2, jackknife_n=3, jackknife_d=1), 19, 3),               # one replica per rank
+    (dict(Kmax=2, jackknife_n=4, jackknife_d=2), 21, 2),               # 6 replicas, deletion pairs
+])
+def test_sharded_jackknife_matches_unsharded(tmp_path, kw, mtr, world):
+    """jackknife_sharded over gloo: shard-local rows from GLOBAL ranks, per-replica reductions to the owners, owners finish,
+    one all-reduce of the outputs -- every rank ends with the oracle's replicas and main stack."""
+    N = 1024
+    mp.spawn(_jk_worker, args=(world, _free_port(), kw, mtr, N, str(tmp_path)), nprocs=world, join=True)
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), abi.synth_traces(mtr, N, seed=17), times=_jk_times(mtr))
+    assert want["jk_mtr"].all()
+    for r in range(world):
+        got = np.load(tmp_path / f"jk{r}.npz")
+        np.testing.assert_array_equal(got["jm"], want["jk_mtr"])
+        assert abi.relerr(got["ls"], want["ls"]) < 2e-6 and abi.relerr(got["ts"], want["tsPWS"]) < 2e-6
+        for c in range(len(want["jk_mtr"])):
+            assert abi.relerr(got["jl"][c], want["jk_ls"][c]) < 2e-6
+            assert abi.relerr(got["jt"][c], want["jk_ts"][c]) < 2e-6
+
+
 def _worker(rank, world, port, kw, mtr, N, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

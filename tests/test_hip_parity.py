@@ -695,6 +695,65 @@ def test_prepared_jackknife_shares_the_streaming_pass(lib, torch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw,bounds", [
+    (dict(Kmax=6, unbiased=1, jackknife_n=5, jackknife_d=1), (0, 97, 97, 211, 300)),     # ragged shards, one of them EMPTY
+    (dict(Kmax=4, jackknife_n=6, jackknife_d=2, type=-3), (0, 150, 300)),
+])
+def test_sharded_jackknife_rows_add_up(lib, torch, kw, bounds):
+    """SURVEY 8e, jackknife sharding, through the C ABI in one process: every shard walks its traces once
+    (tspws_hip_jackknife_local), the shards' rows are added by hand (what the collective does), replicas are finished in two
+    ranges (what two owners do) -- against the oracle's tspws_main and against the unsharded engine."""
+    mtr, N = bounds[-1], 4096
+    p = tspws.resolve(abi.default_params(**kw), N)
+    K = p.Kmax
+    pl = tspws.Plan(p, N)
+    Xd = tspws.synth(mtr, N, seed=21)
+    rng = np.random.default_rng(9)
+    times = (1262304000 + 86400 * np.sort(rng.integers(0, 2 * 365, mtr))).astype(np.int64)
+    Cn = abi.binomial(p.jackknife_n, p.jackknife_d)
+    sel = np.zeros((Cn, mtr), np.int8)
+    assert lib.tspws_jackknife_plan(sel.ctypes.data, times.ctypes.data, mtr, p.jackknife_d, p.jackknife_n, Cn) == 0
+    main_sum = torch.zeros(K * N, dtype=torch.float64, device="cuda")
+    rows_sum = torch.zeros(Cn * K * N, dtype=torch.float64, device="cuda")
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        pl.jackknife_local(Xd[a:b], a, mtr, sel)
+        torch.cuda.synchronize()
+        main_sum += pl.reduce_buffer(mtr)
+        rows_sum += pl.jackknife_buffer(Cn)
+    pl.reduce_buffer(mtr).copy_(main_sum)
+    pl.jackknife_buffer(Cn).copy_(rows_sum)
+    ls = torch.empty(N, dtype=torch.float32, device="cuda")
+    ts = torch.empty(N, dtype=torch.float32, device="cuda")
+    pl.stack_finish(mtr, ls, ts)
+    jl = torch.zeros((Cn, N), dtype=torch.float32, device="cuda")
+    jt = torch.zeros((Cn, N), dtype=torch.float32, device="cuda")
+    jm = np.zeros(Cn, np.uint32)
+    cut = Cn // 2 + 1
+    pl.jackknife_finish(mtr, sel, cut, Cn, jl, jt, jm)   # the ranges in any order
+    pl.jackknife_finish(mtr, sel, 0, cut, jl, jt, jm)
+    pl.jackknife_finish(mtr, sel, 2, 2, jl, jt, jm)      # empty range: nothing happens
+    torch.cuda.synchronize()
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), Xd.cpu().numpy(), times=times)
+    np.testing.assert_array_equal(jm, want["jk_mtr"])
+    assert abi.relerr(ls.cpu().numpy(), want["ls"]) < TOL32 and abi.relerr(ts.cpu().numpy(), want["tsPWS"]) < TOL32
+    for c in range(Cn):
+        assert abi.relerr(jl[c].cpu().numpy(), want["jk_ls"][c]) < TOL32
+        assert abi.relerr(jt[c].cpu().numpy(), want["jk_ts"][c]) < TOL32
+    # world 1 through the orchestration: same kernels on one shard, no collective
+    l1, t1, jl1, jt1, jm1 = tspws.jackknife_sharded(pl, Xd, sel)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(jm1, want["jk_mtr"])
+    assert abi.relerr(t1.cpu().numpy(), want["tsPWS"]) < TOL32
+    assert max(abi.relerr(jt1[c].cpu().numpy(), jt[c].cpu().numpy()) for c in range(Cn)) < 1e-6  # shard boundaries move roundings only
+    assert max(abi.relerr(jl1[c].cpu().numpy(), jl[c].cpu().numpy()) for c in range(Cn)) < 1e-6
+    # argument checks
+    with pytest.raises(tspws.TspwsError):
+        pl.jackknife_local(Xd[:10], 295, mtr, sel)       # shard sticks out of the ensemble
+    with pytest.raises(tspws.TspwsError):
+        pl.jackknife_finish(mtr, sel, 3, Cn + 1, jl, jt, jm)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kw,N,mtr", [
     (dict(), 4096, 64), (dict(), 2048, 200), (dict(), 1501, 70), (dict(type=-3), 4096, 100), (dict(w0=2 * np.pi), 8192, 129),
     (dict(s0=3.7, J=6), 3001, 77), (dict(type=-2, wu=1.0), 2048, 90), (dict(unbiased=1), 16501, 96), (dict(uni=1, J=3), 1024, 65),

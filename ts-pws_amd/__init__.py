@@ -107,6 +107,9 @@ SYMBOLS = {
     "tspws_jackknife_plan": (_i, [_vp, _vp, _sz, _u, _u, _u]),
     "tspws_hip_jackknife": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _u, _vp, _vp, _vp, _vp]),
     "tspws_hip_jackknife_prepare": (_i, [_vp, _vp, _vp, _u, _sz]),
+    "tspws_hip_jackknife_buffer": (_i, [_vp, _vp, _u, C.POINTER(_vp), C.POINTER(_sz)]),
+    "tspws_hip_jackknife_local": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _u, _vp]),
+    "tspws_hip_jackknife_finish": (_i, [_vp, _vp, _sz, _vp, _u, _u, _u, _vp, _vp, _vp, _vp]),
     "tspws_subsampling_plan": (_i, [_vp, _sz, _sz]),
     "tspws_hip_subsample": (_i, [_vp, _vp, _vp, _sz, _sz, _u, _vp, _vp, _vp]),
     "tspws_hip_convergence": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -250,6 +253,40 @@ class Plan:
         check(self.lib.tspws_hip_stack_finish_tail(self.h, C.byref(self.params), mtr_global, self._out(ls, "ls"), self._out(ts, "ts"),
                                                    self._stream()), "stack_finish_tail")
 
+    # ---- trace-sharded jackknife (see jackknife_sharded) ------------------------------
+    @staticmethod
+    def _sel(sel, C_, mtr_global):
+        import numpy as np
+        sel = np.ascontiguousarray(sel, dtype=np.int8)
+        if sel.shape != (C_, mtr_global):
+            raise TspwsError(f"selection must be [{C_}][{mtr_global}] (replica x trace of the WHOLE ensemble), got {sel.shape}")
+        return sel
+
+    def jackknife_buffer(self, C_):
+        """torch view (float64, [C * Kmax * N]) of the replicas' partial-stack rows a multi-GPU caller reduces."""
+        import torch
+        ptr, n = C.c_void_p(), C.c_size_t()
+        check(self.lib.tspws_hip_jackknife_buffer(self.h, C.byref(self.params), C_, C.byref(ptr), C.byref(n)), "jackknife_buffer")
+        return _as_tensor(ptr.value, n.value, torch.float64, self.device)
+
+    def jackknife_local(self, traces, first, mtr_global, sel):
+        """One pass over the shard: its sums for the plain groups (reduce_buffer) and for every replica (jackknife_buffer)."""
+        mtr, ld = self._traces(traces)
+        sel = self._sel(sel, sel.shape[0], mtr_global)
+        check(self.lib.tspws_hip_jackknife_local(self.h, C.byref(self.params), traces.data_ptr(), ld, mtr, first, mtr_global, sel.ctypes.data,
+                                                 sel.shape[0], self._stream()), "jackknife_local")
+
+    def jackknife_finish(self, mtr_global, sel, c_begin, c_end, ls_out, ts_out, mtr_out):
+        """Replicas [c_begin, c_end) from the reduced rows into rows of the [C][N] float32 tensors; sizes into mtr_out (uint32 numpy)."""
+        import torch
+        sel = self._sel(sel, sel.shape[0], mtr_global)
+        for t, name in ((ls_out, "ls_out"), (ts_out, "ts_out")):
+            if t.dtype != torch.float32 or tuple(t.shape) != (sel.shape[0], self.N) or not t.is_contiguous() or not t.is_cuda or \
+                    (t.device.index or 0) != self.device:
+                raise TspwsError(f"{name} must be a contiguous float32 [{sel.shape[0]}][{self.N}] tensor on cuda:{self.device}")
+        check(self.lib.tspws_hip_jackknife_finish(self.h, C.byref(self.params), mtr_global, sel.ctypes.data, sel.shape[0], c_begin, c_end,
+                                                  ls_out.data_ptr(), ts_out.data_ptr(), mtr_out.ctypes.data, self._stream()), "jackknife_finish")
+
     def stack(self, traces, first=0, mtr_global=None, group=None):
         """ls, tsPWS (float32 cuda tensors) of a shard of HBM-resident traces; see stack_sharded."""
         return stack_sharded(self, traces, first, mtr_global, group)
@@ -320,6 +357,65 @@ def stack_sharded(plan, traces, first=0, mtr_global=None, group=None):
     ts = torch.empty(plan.N, dtype=torch.float32, device=traces.device)
     plan.stack_finish(mtr_global, ls, ts)
     return ls, ts
+
+
+def jackknife_sharded(plan, traces, sel, first=0, mtr_global=None, group=None):
+    """Two-stage stack AND its jackknife replicas over a trace-sharded ensemble ("Jackknife sharding").
+
+    `sel` is the [C][mtr_global] selection of the whole ensemble (tspws_jackknife_plan), identical on every rank.  Each rank
+    walks its shard ONCE (plan.jackknife_local): the sums of its traces for the Kmax plain groups and for the Kmax groups of
+    every replica -- group indices come from the GLOBAL trace order, so the shards' rows simply add.  The plain rows are
+    all-reduced and every rank finishes the stack (as in stack_sharded).  The replicas are SHARDED for the finish stage,
+    which is where their time goes (Kmax transforms + an inverse each): replica c belongs to rank c % world, its Kmax rows
+    are reduced to that rank only (C reductions of Kmax x N doubles instead of one all-reduce of all C of them on every
+    rank), the owner finishes it, and one all-reduce of the [C][N] float outputs (zeros from the non-owners: exact)
+    hands every rank all replicas.  Returns ls, ts, ls_out[C][N], ts_out[C][N], mtr_out[C]."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    mtr_global = traces.shape[0] if mtr_global is None else mtr_global
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    sel = np.ascontiguousarray(sel, dtype=np.int8)
+    Cn = sel.shape[0]
+    K, N = plan.params.Kmax, plan.N
+    plan.jackknife_local(traces, first, mtr_global, sel)
+    dev = traces.device
+    ls = torch.empty(N, dtype=torch.float32, device=dev)
+    ts = torch.empty(N, dtype=torch.float32, device=dev)
+    ls_out = torch.zeros((Cn, N), dtype=torch.float32, device=dev)
+    ts_out = torch.zeros((Cn, N), dtype=torch.float32, device=dev)
+    mtr_out = np.zeros(Cn, np.uint32)
+    works = []
+    if distributed:
+        rows = plan.jackknife_buffer(Cn).view(Cn, K * N)
+        works.append(dist.all_reduce(plan.reduce_buffer(mtr_global), op=dist.ReduceOp.SUM, group=group, async_op=True))
+        for c in range(Cn):
+            dst = c % world
+            works.append(dist.reduce(rows[c], dst=dist.get_global_rank(group, dst) if group is not None else dst, op=dist.ReduceOp.SUM,
+                                     group=group, async_op=True))
+    for w in works[:1]:
+        w.wait()
+    plan.stack_finish(mtr_global, ls, ts)  # runs while the replicas' rows are still being reduced
+    for w in works[1:]:
+        w.wait()
+    mine = [c for c in range(Cn) if c % world == rank]
+    # owned replicas are finished in runs of consecutive indices (world 1: one run, batched like the single-GPU call)
+    i = 0
+    while i < len(mine):
+        j = i
+        while j + 1 < len(mine) and mine[j + 1] == mine[j] + 1:
+            j += 1
+        plan.jackknife_finish(mtr_global, sel, mine[i], mine[j] + 1, ls_out, ts_out, mtr_out)
+        i = j + 1
+    if distributed:
+        dist.all_reduce(ls_out, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(ts_out, op=dist.ReduceOp.SUM, group=group)
+        cnt = torch.from_numpy(mtr_out.astype(np.int64)).to(dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+        mtr_out = cnt.cpu().numpy().astype(np.uint32)
+    return ls, ts, ls_out, ts_out, mtr_out
 
 
 def split_groups(K):

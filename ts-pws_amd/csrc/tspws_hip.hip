@@ -165,7 +165,8 @@ struct tspws_hip_plan {
 	struct ClassSums {
 		bool valid = false, has_main = false;
 		const float *d_x = nullptr;
-		size_t ld = 0, mtr = 0;
+		size_t ld = 0, mtr = 0;                         // mtr: traces of the WHOLE ensemble the selection refers to
+		size_t first = 0, mtr_local = 0;                // the shard the sums were taken over (first = 0, mtr_local = mtr: all)
 		unsigned C = 0, KM = 0, ncls = 0;
 		std::vector<char> sel;                          // the selection the classes were built from
 		std::vector<std::vector<unsigned short>> sig;   // per class: group in each replica (0xFFFF = deleted) [+ plain group]
@@ -1999,7 +2000,7 @@ extern "C" int tspws_hip_epilogue(float *d_ls, float *d_ts, const double *d_xst,
 // ------------------------------------------------------------------------------------------
 static bool is_two_stage(const t_tsPWS *p, size_t mtr_global) { return !(!p->Kmax || p->Kmax > mtr_global); }
 static int class_sums(tspws_hip_plan *pl, unsigned KM, const float *d_x, size_t ld, size_t mtr, const char *h_sel, unsigned C, bool with_main,
-                      hipStream_t st);
+                      hipStream_t st, size_t first = 0, size_t mtr_local = ~(size_t)0);
 static int combine_classes(tspws_hip_plan *pl, unsigned col0, unsigned col1, double *d_P, hipStream_t st);
 
 extern "C" int tspws_hip_reduce_buffer(tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, double **d_buf, size_t *nd)
@@ -2279,11 +2280,17 @@ __global__ void __launch_bounds__(256) k_jk_linear(const double *__restrict__ P,
 // replica form a class (maximal runs of consecutive traces; equal signatures of separate runs share a class), the
 // streaming kernel sums every class once, and each (replica, group) partial stack is a sum of class sums.
 // with_main: the plain two-stage groups of ALL traces (ts_pws1f_lib.c:876) are one more signature column.
+// Sharded ensembles: d_x holds traces [first, first + mtr_local) of the mtr the selection refers to; signatures come from
+// the GLOBAL trace index (a trace's group in a replica is its rank among ALL selected traces, :766), the sums run over the
+// shard's traces only, so the rows of all shards add up to the rows of the whole ensemble.
 static int class_sums(tspws_hip_plan *pl, unsigned KM, const float *d_x, size_t ld, size_t mtr, const char *h_sel, unsigned C, bool with_main,
-                      hipStream_t st)
+                      hipStream_t st, size_t first, size_t mtr_local)
 {
 	tspws_hip_plan::ClassSums &cs = pl->cs;
 	cs.valid = false;
+	if (mtr_local == ~(size_t)0) { first = 0; mtr_local = mtr; }
+	if (first > mtr || mtr_local > mtr - first) return fail(TSPWS_E_ARG, "class sums: shard outside the ensemble");
+	const size_t lo = first, hi = first + mtr_local;
 	const size_t N = pl->N;
 	const unsigned W = C + (with_main ? 1u : 0u);
 	// signature of trace i: group index in every replica (0xFFFF = deleted)
@@ -2302,16 +2309,16 @@ static int class_sums(tspws_hip_plan *pl, unsigned KM, const float *d_x, size_t 
 	if (with_main) for (size_t i = 0; i < mtr; i++) sig[i * W + C] = (unsigned short)std::min<size_t>((size_t)floor((double)(i * KM) / (double)mtr), KM - 1);
 	cs.sig.clear(); cs.chunks.clear();
 	std::vector<std::vector<Chunk>> cls_chunks;
-	const unsigned clen = chunk_len_for(N, mtr);
-	for (size_t i = 0; i < mtr;) {
+	const unsigned clen = chunk_len_for(N, std::max<size_t>(mtr_local, 1));
+	for (size_t i = lo; i < hi;) {
 		size_t j = i + 1;
-		while (j < mtr && !memcmp(&sig[i * W], &sig[j * W], W * sizeof(unsigned short))) j++;
+		while (j < hi && !memcmp(&sig[i * W], &sig[j * W], W * sizeof(unsigned short))) j++;
 		std::vector<unsigned short> sg(sig.begin() + i * W, sig.begin() + (i + 1) * W);
 		size_t id = 0;
 		for (; id < cs.sig.size(); id++) if (cs.sig[id] == sg) break;
 		if (id == cs.sig.size()) { cs.sig.push_back(sg); cls_chunks.emplace_back(); }
 		for (size_t t = i; t < j; t += clen) {
-			Chunk c; c.t0 = t; c.count = (unsigned)std::min<size_t>(clen, j - t); c.row = (unsigned)id;
+			Chunk c; c.t0 = t - lo; c.count = (unsigned)std::min<size_t>(clen, j - t); c.row = (unsigned)id; // t0: row of d_x
 			cls_chunks[id].push_back(c);
 		}
 		i = j;
@@ -2325,9 +2332,9 @@ static int class_sums(tspws_hip_plan *pl, unsigned KM, const float *d_x, size_t 
 	cs.row_first[ncls] = (unsigned)cs.chunks.size();
 	int rc;
 	void *v;
-	if ((rc = scratch(pl, SCR_CLS, (size_t)ncls * N * sizeof(double), &v))) return rc;
-	if ((rc = run_chunks(pl, d_x, ld, N, cs.chunks, cs.row_first, ncls, (double *)v, N, st, false))) return rc; // own table: not the cached one
-	cs.d_x = d_x; cs.ld = ld; cs.mtr = mtr; cs.C = C; cs.KM = KM; cs.ncls = ncls; cs.has_main = with_main;
+	if ((rc = scratch(pl, SCR_CLS, std::max<size_t>((size_t)ncls * N, 1) * sizeof(double), &v))) return rc;
+	if (ncls && (rc = run_chunks(pl, d_x, ld, N, cs.chunks, cs.row_first, ncls, (double *)v, N, st, false))) return rc; // own table: not the cached one
+	cs.d_x = d_x; cs.ld = ld; cs.mtr = mtr; cs.first = first; cs.mtr_local = mtr_local; cs.C = C; cs.KM = KM; cs.ncls = ncls; cs.has_main = with_main;
 	cs.sel.assign(h_sel, h_sel + (size_t)C * mtr);
 	cs.valid = true;
 	return 0;
@@ -2387,36 +2394,36 @@ extern "C" int tspws_hip_jackknife(tspws_hip_plan *pl, const t_tsPWS *p, const f
 	return masked_two_stage(pl, p, d_x, ld, mtr, h_sel, C, d_ls_out, d_ts_out, h_mtr_out, s);
 }
 
-// All C masked two-stage replicas from ONE pass over the traces (shared by the jackknife and the two-stage
-// random subsampling, whose per-replica bodies are identical in the reference: :758-811 and :642-691).
-static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, const char *h_sel, unsigned C,
-                            float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s)
+// Rows of the masked replicas: d_P[c * KM + g][N] (SCR_JKP; the replicas' trace counts follow the rows).
+static int replica_rows_buffer(tspws_hip_plan *pl, unsigned KM, unsigned C, double **d_P)
 {
-	HIP_TRY(hipSetDevice(pl->device));
+	void *v;
+	int rc = scratch(pl, SCR_JKP, ((size_t)C * KM * pl->N + C) * sizeof(double), &v);
+	if (rc) return rc;
+	*d_P = (double *)v;
+	return 0;
+}
+
+// Replicas [c_begin, c_end) from their partial-stack rows: transforms, phase stacks, weights, time-domain linear stacks,
+// inverses.  Outputs land in rows c_begin.. of d_ls_out / d_ts_out / h_mtr_out ([C][N] arrays indexed by replica).
+static int finish_replicas(tspws_hip_plan *pl, const t_tsPWS *p, double *d_P, const std::vector<size_t> &Kc, unsigned C, unsigned c_begin,
+                           unsigned c_end, float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s)
+{
 	hipStream_t st = S_(s);
 	const unsigned KM = p->Kmax;
 	const size_t N = pl->N;
 	int rc;
 	void *v;
-	// class sums: left behind by a prepared tspws_hip_stack_local of these traces with this selection, else streamed now
-	tspws_hip_plan::ClassSums &cs = pl->cs;
-	const bool reuse = cs.valid && cs.d_x == d_x && cs.ld == ld && cs.mtr == mtr && cs.C == C && cs.KM == KM &&
-	                   cs.sel.size() == (size_t)C * mtr && !memcmp(cs.sel.data(), h_sel, (size_t)C * mtr);
-	if (!reuse && (rc = class_sums(pl, KM, d_x, ld, mtr, h_sel, C, false, st))) return rc;
-	const std::vector<size_t> Kc = cs.Kc;
-	if ((rc = scratch(pl, SCR_JKP, ((size_t)C * KM * N + C) * sizeof(double), &v))) return rc;
-	double *d_P = (double *)v, *d_Mv = d_P + (size_t)C * KM * N; // partial stacks of every replica, then the replicas' trace counts
+	double *d_Mv = d_P + (size_t)C * KM * N;
 	std::vector<double> h_Mv(C);
 	for (unsigned c = 0; c < C; c++) h_Mv[c] = (double)Kc[c];
 	HIP_TRY(hipMemcpyAsync(d_Mv, h_Mv.data(), C * sizeof(double), hipMemcpyHostToDevice, st));
-	if ((rc = combine_classes(pl, 0, C, d_P, st))) return rc;
-	cs.valid = false; // one use: the traces may change after this call
-	HIP_TRY(hipGetLastError());
 	// Replicas are processed in batches: ONE forward launch transforms the KM partials of a whole batch of replicas (the
 	// kernels fill the GPU far better with 100 traces than with 10), then per replica the phase accumulation and the
 	// weight (KM, K_c), and the inverses two replicas at a time.
 	const size_t nc = pl->ncoef;
-	unsigned RB = (unsigned)std::max<size_t>(1, std::min<size_t>(C, part_budget_bytes() / std::max<size_t>(1, (size_t)KM * pl->npart * sizeof(double2))));
+	const unsigned nrep = c_end - c_begin;
+	unsigned RB = (unsigned)std::max<size_t>(1, std::min<size_t>(nrep, part_budget_bytes() / std::max<size_t>(1, (size_t)KM * pl->npart * sizeof(double2))));
 	if (RB > 1) RB &= ~1u; // pairs for the two-set inverse
 	if ((rc = scratch(pl, SCR_PART, (size_t)RB * KM * pl->npart * sizeof(double2), &v))) return rc;
 	double2 *part = (double2 *)v;
@@ -2424,8 +2431,8 @@ static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d
 	if ((rc = scratch(pl, SCR_JKOUT, ((size_t)RB * 6 * nc + (size_t)RB * N) * sizeof(double), &v))) return rc;
 	double *OUT = (double *)v, *STr = OUT + (size_t)RB * 2 * nc, *xr = STr + (size_t)RB * 4 * nc;
 	const bool fuse = fuse_enabled() && pl->fwd_kind == 1 && pl->n_fusable;
-	for (unsigned c0 = 0; c0 < C; c0 += RB) {
-		const unsigned nr = std::min(RB, C - c0);
+	for (unsigned c0 = c_begin; c0 < c_end; c0 += RB) {
+		const unsigned nr = std::min(RB, c_end - c0);
 		// one slice of the fused forward kernel = the KM partial stacks of one replica: its stacks land in the replica's planes
 		FuseOut fz;
 		fz.accST = (double2 *)STr; fz.accPS = (double2 *)STr + nc; fz.stride = 2 * nc; fz.tps = KM;
@@ -2446,6 +2453,77 @@ static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st)); // host tables above go out of scope
 	return 0;
+}
+
+// All C masked two-stage replicas from ONE pass over the traces (shared by the jackknife and the two-stage
+// random subsampling, whose per-replica bodies are identical in the reference: :758-811 and :642-691).
+static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, const char *h_sel, unsigned C,
+                            float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s)
+{
+	HIP_TRY(hipSetDevice(pl->device));
+	hipStream_t st = S_(s);
+	const unsigned KM = p->Kmax;
+	int rc;
+	// class sums: left behind by a prepared tspws_hip_stack_local of these traces with this selection, else streamed now
+	tspws_hip_plan::ClassSums &cs = pl->cs;
+	const bool reuse = cs.valid && cs.d_x == d_x && cs.ld == ld && cs.mtr == mtr && cs.first == 0 && cs.mtr_local == mtr && cs.C == C && cs.KM == KM &&
+	                   cs.sel.size() == (size_t)C * mtr && !memcmp(cs.sel.data(), h_sel, (size_t)C * mtr);
+	if (!reuse && (rc = class_sums(pl, KM, d_x, ld, mtr, h_sel, C, false, st))) return rc;
+	const std::vector<size_t> Kc = cs.Kc;
+	double *d_P;
+	if ((rc = replica_rows_buffer(pl, KM, C, &d_P))) return rc;
+	if ((rc = combine_classes(pl, 0, C, d_P, st))) return rc;
+	cs.valid = false; // one use: the traces may change after this call
+	HIP_TRY(hipGetLastError());
+	return finish_replicas(pl, p, d_P, Kc, C, 0, C, d_ls_out, d_ts_out, h_mtr_out, s);
+}
+
+// ---- trace-sharded jackknife: shard-local rows -> the caller's reduction -> replicas finished where they are owned ----
+extern "C" int tspws_hip_jackknife_buffer(tspws_hip_plan *pl, const t_tsPWS *p, unsigned C, double **d_buf, size_t *nd)
+{
+	if (!pl || !p || !d_buf || !nd) return fail(TSPWS_E_ARG, "jackknife_buffer: NULL");
+	if (!p->Kmax || !C) return fail(TSPWS_E_ARG, "jackknife_buffer: two-stage calls with C > 0");
+	HIP_TRY(hipSetDevice(pl->device));
+	*nd = (size_t)C * p->Kmax * pl->N;
+	return replica_rows_buffer(pl, p->Kmax, C, d_buf);
+}
+
+extern "C" int tspws_hip_jackknife_local(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr_local, size_t first,
+                                         size_t mtr_global, const char *h_sel, unsigned C, void *s)
+{
+	if (!pl || !p || !h_sel || (!d_x && mtr_local)) return fail(TSPWS_E_ARG, "jackknife_local: NULL");
+	if (!is_two_stage(p, mtr_global) || !C) return fail(TSPWS_E_ARG, "jackknife_local: two-stage calls with C > 0");
+	HIP_TRY(hipSetDevice(pl->device));
+	hipStream_t st = S_(s);
+	const unsigned KM = p->Kmax;
+	double *main_rows, *d_P;
+	size_t nd;
+	int rc;
+	if ((rc = tspws_hip_reduce_buffer(pl, p, mtr_global, &main_rows, &nd))) return rc;
+	if ((rc = replica_rows_buffer(pl, KM, C, &d_P))) return rc;
+	pl->jk_prepared = false;
+	// ONE pass over the shard for the plain groups and for every replica (empty shard: all rows zero)
+	if ((rc = class_sums(pl, KM, d_x, ld, mtr_global, h_sel, C, true, st, first, mtr_local))) return rc;
+	if ((rc = combine_classes(pl, C, C + 1, main_rows, st))) return rc;
+	if ((rc = combine_classes(pl, 0, C, d_P, st))) return rc;
+	pl->cs.valid = false; // the rows, not the class sums, are what the caller reduces
+	HIP_TRY(hipStreamSynchronize(st)); // the CSR tables of the two combine passes share one scratch block and host vectors
+	return 0;
+}
+
+extern "C" int tspws_hip_jackknife_finish(tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, const char *h_sel, unsigned C, unsigned c_begin,
+                                          unsigned c_end, float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s)
+{
+	if (!pl || !p || !h_sel || !d_ls_out || !d_ts_out || !h_mtr_out) return fail(TSPWS_E_ARG, "jackknife_finish: NULL");
+	if (!is_two_stage(p, mtr_global) || !C || c_begin > c_end || c_end > C) return fail(TSPWS_E_ARG, "jackknife_finish: two-stage calls, 0 <= c_begin <= c_end <= C");
+	if (c_begin == c_end) return 0;
+	HIP_TRY(hipSetDevice(pl->device));
+	std::vector<size_t> Kc(C, 0);
+	for (unsigned c = 0; c < C; c++) for (size_t i = 0; i < mtr_global; i++) if (h_sel[(size_t)c * mtr_global + i] == 1) Kc[c]++;
+	double *d_P;
+	int rc;
+	if ((rc = replica_rows_buffer(pl, p->Kmax, C, &d_P))) return rc;
+	return finish_replicas(pl, p, d_P, Kc, C, c_begin, c_end, d_ls_out, d_ts_out, h_mtr_out, s);
 }
 
 // ------------------------------------------------------------------------------------------
