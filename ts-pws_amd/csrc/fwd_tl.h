@@ -94,17 +94,20 @@ __global__ void __launch_bounds__(TL_NT, 2) k_fwd_tl(const TIn *__restrict__ xT,
 	const unsigned tb = blockIdx.y;               // 64-trace block
 	const unsigned rho_lo = split * o->pps, rho_hi = (rho_lo + o->pps < D) ? rho_lo + o->pps : D;
 	const unsigned nph = rho_hi - rho_lo;
-	// LDS: two buffers of { x rows [XR][64] double, tap rows [trows] double2 }
-	const size_t buf_bytes = (size_t)XR * 64 * sizeof(double) + (size_t)trows * sizeof(double2);
-	auto xbuf = [&](unsigned b) { return (double *)(smem + b * buf_bytes); };
-	auto tbuf = [&](unsigned b) { return (double2 *)(smem + b * buf_bytes + (size_t)XR * 64 * sizeof(double)); };
+	// LDS: two buffers of { x rows [XR][64] TIn -- RAW, converted at the read --, tap rows [trows] double2 }
+	constexpr unsigned ROWB = 64 * sizeof(TIn);
+	const size_t buf_bytes = (size_t)XR * ROWB + (size_t)trows * sizeof(double2);
+	auto xbuf = [&](unsigned b) { return (const TIn *)(smem + b * buf_bytes); };
+	auto tbuf = [&](unsigned b) { return (double2 *)(smem + b * buf_bytes + (size_t)XR * ROWB); };
 
 	// ---- staging of one step (output block kb, residue rho) --------------------------------------------------------------
-	// 16-byte loads: a thread fetches VEC consecutive traces of a row (the vector memory path works per INSTRUCTION --
-	// 13 dword loads per thread took ~1.7 k cycles to issue, FL_TIMING -- so the fewer, wider loads the better):
-	// LPR threads cover a row, the workgroup RPP rows per load instruction.
-	constexpr int VEC = 16 / (int)sizeof(TIn), LPR = 64 / VEC, RPP = TL_NT / LPR, NLD = (TL_XRMAX + RPP - 1) / RPP;
-	typedef TIn vecT __attribute__((ext_vector_type(VEC)));
+	// The rows go from global memory STRAIGHT into LDS (global_load_lds_dwordx4: 1 KB per wave-instruction, no staging
+	// registers, no LDS store pass): a lane fetches VEC consecutive traces of a row, LPR lanes cover a row, so the 64 lanes
+	// of a wave fill RPW consecutive LDS rows (the destination is wave-uniform base + lane x 16 B: rows are contiguous),
+	// the workgroup RPP rows per instruction.  XR is a multiple of 4, hence a wave-instruction is valid or idle as a whole.
+	constexpr int VEC = 16 / (int)sizeof(TIn), LPR = 64 / VEC, RPW = 64 / LPR, RPP = TL_NT / LPR, NLD = (TL_XRMAX + RPP - 1) / RPP;
+	typedef __attribute__((address_space(3))) void lds_void;
+	typedef __attribute__((address_space(1))) const void glb_void;
 	const unsigned srow = tid / LPR, ssub = (tid % LPR) * VEC; // first row and first trace of this thread's fetches
 	const TIn *xcol = xT + (size_t)tb * 64 + ssub;
 	unsigned tv = 0, tq = 0;
@@ -113,35 +116,36 @@ __global__ void __launch_bounds__(TL_NT, 2) k_fwd_tl(const TIn *__restrict__ xT,
 	const unsigned long long tap_base = o->tap_off[tv];
 	const unsigned tap_L = o->L[tv], tap_b = o->b[tv];
 	const unsigned stp = (unsigned)(((unsigned long long)RPP * D) % N);
-	auto load_stage = [&](vecT (&xv)[NLD], double2 &tp, const unsigned kb, const unsigned rho) {
-		// sample of image row i: (j0 + i) D + rho  (mod N), j0 = 32 kb - amax - 1; this thread: rows srow, srow + RPP, ...
-		long long s0 = ((long long)kb * 32 - (long long)amax - 1 + (long long)srow) * D + rho;
+	// Row / tap position of the stage to be loaded next, kept INCREMENTALLY: a residue step moves every row by one sample,
+	// a block step by 32 D - (nph - 1)  (a `% N` per step would be a 64-bit software division of ~130 instructions).
+	unsigned n_st;        // sample of this thread's first row: ((32 kb - amax - 1 + srow) D + rho) mod N
+	long long l_st;       // tap index of this thread's tap-image element: (tq - 1) D + rho + b
+	{
+		long long s0 = ((long long)kb0 * 32 - (long long)amax - 1 + (long long)srow) * D + rho_lo;
 		s0 %= (long long)N; if (s0 < 0) s0 += N;
-		unsigned n = (unsigned)s0;
+		n_st = (unsigned)s0;
+		l_st = ((long long)tq - 1) * D + rho_lo + tap_b;
+	}
+	const unsigned blk_stp = (unsigned)((32ull * D + (unsigned long long)N - (unsigned long long)((nph - 1) % N)) % N);
+	auto next_residue = [&]() { n_st += 1u; if (n_st >= N) n_st -= N; l_st += 1; };
+	auto next_block = [&]() { n_st += blk_stp; if (n_st >= N) n_st -= N; l_st -= (long long)(nph - 1); };
+	auto load_stage = [&](double2 &tp, const unsigned b) {
+		// sample of image row i: (j0 + i) D + rho  (mod N), j0 = 32 kb - amax - 1; this thread: rows srow, srow + RPP, ...
+		unsigned n = n_st;
 		asm volatile("" : "+v"(n)); // keeps the compiler from hoisting every row offset out of the step loop
+		char *dst = smem + b * buf_bytes + (size_t)(wv * RPW) * ROWB; // this wave's first row (wave-uniform)
 #pragma unroll
 		for (int i = 0; i < NLD; i++) {
-			// rows past the image (i RPP + srow >= XR) re-read the last valid row of this thread: harmless, never stored
-			xv[i] = *(const vecT *)(xcol + (size_t)n * TP);
-			const bool more = srow + (unsigned)(i + 1) * RPP < XR;
-			n += more ? stp : 0u;
+			if ((unsigned)i * RPP + wv * RPW < XR)
+				__builtin_amdgcn_global_load_lds((glb_void *)(xcol + (size_t)n * TP), (lds_void *)(dst + (size_t)i * RPP * ROWB), 16, 0, 0);
+			n += stp;
 			if (n >= N) n -= N;
 		}
-		if (tap_thread) {
-			const long long l = ((long long)tq - 1) * D + rho + tap_b;
-			tp = (l >= 0 && l < (long long)tap_L) ? w[tap_base + (unsigned long long)l] : make_double2(0.0, 0.0);
-		}
+		if (tap_thread) tp = (l_st >= 0 && l_st < (long long)tap_L) ? w[tap_base + (unsigned long long)l_st] : make_double2(0.0, 0.0);
 	};
-	auto store_stage = [&](const vecT (&xv)[NLD], const double2 tp, const unsigned b) {
-		double *xd = xbuf(b) + (size_t)srow * 64 + ssub;
-#pragma unroll
-		for (int i = 0; i < NLD; i++) {
-			if (srow + (unsigned)i * RPP < XR) {
-#pragma unroll
-				for (int e = 0; e < VEC; e += 2)
-					*(double2 *)(xd + (size_t)i * RPP * 64 + e) = make_double2((double)xv[i][e], (double)xv[i][e + 1]);
-			}
-		}
+	// own rows landed + the tap image element written: after the workgroup barrier that follows, buffer b is complete
+	auto store_stage = [&](const double2 tp, const unsigned b) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		if (tap_thread) tbuf(b)[tid] = tp;
 	};
 
@@ -198,9 +202,8 @@ __global__ void __launch_bounds__(TL_NT, 2) k_fwd_tl(const TIn *__restrict__ xT,
 		}
 	};
 
-	vecT xv[NLD];
 	double2 tp = make_double2(0.0, 0.0);
-	load_stage(xv, tp, kb0, rho_lo);
+	load_stage(tp, 0);
 	unsigned cur = 0;
 #if FL_TIMING
 	unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter(), nsteps = 0;
@@ -217,29 +220,29 @@ __global__ void __launch_bounds__(TL_NT, 2) k_fwd_tl(const TIn *__restrict__ xT,
 		const bool group_live = kb * 32u + wv * R < Ns;
 		for (unsigned ph = 0; ph < nph; ph++) {
 			TL_STAMP(5); // (end of the previous step's output / loop overhead)
-			store_stage(xv, tp, cur);
+			store_stage(tp, cur);
 			TL_STAMP(2); // wait for the rows + LDS stores
 			fl_lds_barrier(); // buffer `cur` complete; everyone is done with the other buffer (computed one step ago)
 			TL_STAMP(1); // barrier
-			if (ph + 1 < nph) load_stage(xv, tp, kb, rho_lo + ph + 1);
-			else if (kb + 1 < kb1) load_stage(xv, tp, kb + 1, rho_lo);
+			if (ph + 1 < nph) { next_residue(); load_stage(tp, cur ^ 1u); }
+			else if (kb + 1 < kb1) { next_block(); load_stage(tp, cur ^ 1u); }
 			TL_STAMP(3); // issue of the next step's loads
 #if FL_TIMING
 			nsteps++;
 #endif
 			if (group_live) {
-				const double *xi = xbuf(cur) + (size_t)wv * R * 64 + lane;
+				const TIn *xi = xbuf(cur) + (size_t)wv * R * 64 + lane;
 				const double2 *tbv0 = tbuf(cur);
 #pragma unroll
 				for (int v = 0; v < TL_VMAX; v++) {
 					if ((unsigned)v < nv) {
 						const unsigned QR = vQR[v];
-						const double *xb = xi + (size_t)vrow[v] * 64;
+						const TIn *xb = xi + (size_t)vrow[v] * 64;
 						const double2 *tbv = tbv0;
 						tbv0 += QR;
 						double xw[R];
 #pragma unroll
-						for (int j = 0; j < R - 1; j++) xw[j] = xb[j * 64];
+						for (int j = 0; j < R - 1; j++) xw[j] = (double)xb[j * 64];
 						for (unsigned sb = 0; sb < QR; sb += R) { // QR is a multiple of 4
 #pragma unroll
 							for (int h = 0; h < 2; h++) {
@@ -248,7 +251,7 @@ __global__ void __launch_bounds__(TL_NT, 2) k_fwd_tl(const TIn *__restrict__ xT,
 									double2 tn[4];
 #pragma unroll
 									for (int u = 0; u < 4; u++) {
-										xn[u] = xb[(h * 4 + u + R - 1) * 64];
+										xn[u] = (double)xb[(h * 4 + u + R - 1) * 64];
 										tn[u] = tbv[h * 4 + u]; // same address in every lane: broadcast
 									}
 #pragma unroll
