@@ -810,3 +810,68 @@ def test_many_trace_path_matches_the_few_trace_kernels(lib, torch):
     U = np.where(mag > 0, Y / np.where(mag > 0, mag, 1.0), 0.0)
     assert abi.relerr(ST, Y.sum(axis=0)) < TOL64
     assert abi.relerr(PS, U.sum(axis=0)) < TOL64
+
+
+def _random_case(rng):
+    """One random parameter set within the CLI's grammar (ts_pws1f.c:163-215): wavelet, Q / cycles / w0, fixed or automatic
+    V / s0 / b0 / J, fmin, power, unbiased, two-stage, rm, fold; odd, prime and power-of-two lengths."""
+    kw = {}
+    typ = int(rng.choice([-1, -1, -1, -2, -3]))
+    kw["type"] = typ
+    if typ != -3:
+        how = rng.integers(0, 4)
+        if how == 1:
+            kw.update(Q=float(rng.uniform(2.0, 9.0)), w0set=1)
+        elif how == 2:
+            kw.update(cycle=float(rng.uniform(1.0, 5.0)), w0set=2)
+        elif how == 3:
+            kw["w0"] = float(rng.uniform(2.5, 13.0))   # below ~3.8: b0 = 0 -> every decimation 1 (SURVEY 8 a1 quirk)
+    if rng.random() < 0.3:
+        kw["V"] = int(rng.integers(1, 7))
+    if rng.random() < 0.3:
+        kw["s0"] = float(rng.uniform(1.0, 5.0))
+    if rng.random() < 0.3:
+        kw["b0"] = float(rng.choice([0.5, 1.0, 2.0, 3.0, 4.0]))
+    if rng.random() < 0.4:
+        kw["J"] = int(rng.integers(1, 7))
+    elif rng.random() < 0.3:
+        kw["fmin"] = float(rng.uniform(0.002, 0.05))
+    kw["wu"] = float(rng.choice([2.0, 2.0, 1.0, 1.5, 0.5, 3.0]))
+    if kw["wu"] == 2.0 and rng.random() < 0.5:
+        kw["unbiased"] = 1
+    if rng.random() < 0.5:
+        kw["Kmax"] = int(rng.integers(1, 13))
+    if rng.random() < 0.3:
+        kw["lrm"] = 1
+    N = int(rng.choice([256, 257, 509, 640, 1000, 1024, 1501, 2048, 2311, 3000, 4096, 5003]))
+    mtr = int(rng.choice([1, 2, 3, 7, 16, 33, 70, 100]))
+    beg = 0.0
+    if rng.random() < 0.25:
+        kw["fold"] = 1
+        beg = -0.5 * (N - 1) if rng.random() < 0.8 else 0.0   # symmetric lag axis (fold applies) or not (warning, ignored)
+    return kw, N, mtr, beg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_random_parameter_sets_vs_oracle(lib, seed):
+    """Seeded random sweep over the parameter grammar: return codes, resolved parameters (the call mutates *tspws like the
+    reference, ts_pws1f_lib.c:91-124), mutated traces (fold / rm) and both outputs against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    for it in range(6):
+        kw, N, mtr, beg = _random_case(rng)
+        X = abi.synth_traces(mtr, N, seed=100 * seed + it)
+        p = abi.default_params(**kw)
+        a = abi.run_main(lib.tspws_main, p, X, beg=beg)
+        b = abi.run_main(abi.oracle().orc_tspws_main, p, X, beg=beg)
+        tag = f"seed {seed} case {it}: {kw} N={N} mtr={mtr} beg={beg}"
+        assert a["rc"] == b["rc"], tag
+        for f in ("J", "V", "fold"):
+            assert getattr(a["params"], f) == getattr(b["params"], f), tag
+        for f in ("s0", "b0", "w0"):
+            assert getattr(a["params"], f) == getattr(b["params"], f), tag
+        if a["rc"]:
+            continue
+        np.testing.assert_array_equal(a["sigall"], b["sigall"], err_msg=tag)
+        assert abi.relerr(a["ls"], b["ls"]) < TOL32, tag
+        assert abi.relerr(a["tsPWS"], b["tsPWS"]) < TOL32, tag
