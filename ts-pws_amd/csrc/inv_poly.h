@@ -212,3 +212,16 @@ __global__ void __launch_bounds__(256) k_inv_combine(const double *__restrict__ 
 	for (unsigned s = 1; s < nslots; s++) a += obuf[(size_t)s * slot_stride + i];
 	xout[i] = a;
 }
+
+// The stack's two reconstructions (set 0 = ICWT(OUT), set 1 = ICWT(ST)) summed over the obuf rows in the same fixed order as
+// k_inv_combine and cast straight to the float outputs (epilogue, ts_pws1f_lib.c:233-241: ls is a FLOAT division).
+__global__ void __launch_bounds__(256) k_inv_combine_out(const double *__restrict__ obuf, size_t slot_stride, unsigned nslots, size_t N,
+                                                         float *__restrict__ ts, float *__restrict__ ls, float mtr)
+{
+	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (n >= N) return;
+	double a = obuf[n], b = obuf[N + n];
+	for (unsigned s = 1; s < nslots; s++) { a += obuf[(size_t)s * slot_stride + n]; b += obuf[(size_t)s * slot_stride + N + n]; }
+	if (ts) ts[n] = (float)a;
+	if (ls) ls[n] = (float)b / mtr;
+}

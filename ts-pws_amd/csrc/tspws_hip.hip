@@ -1931,8 +1931,11 @@ static bool use_generic_inverse()
 }
 
 // nb independent NREC-set reconstructions in one launch (grid.y): set j reads Y + j NREC ncoef, writes x + j NREC N
+// f_ts / f_ls (NREC == 2, nb == 1 only): the stack's float outputs are written by the combining kernel itself (no FP64
+// reconstructions in memory, no epilogue launch); x may then be NULL.
 template <int NREC>
-static int inverse_launch(tspws_hip_plan *p, const double2 *Y, double *x, hipStream_t st, unsigned nb = 1)
+static int inverse_launch(tspws_hip_plan *p, const double2 *Y, double *x, hipStream_t st, unsigned nb = 1, float *f_ts = nullptr, float *f_ls = nullptr,
+                          float f_mtr = 1.0f)
 {
 	const unsigned nbx = (p->N + 255) / 256;
 	const size_t slot = (size_t)NREC * p->N;
@@ -1955,8 +1958,11 @@ static int inverse_launch(tspws_hip_plan *p, const double2 *Y, double *x, hipStr
 	if (p->inv_ngeneric)
 		hipLaunchKernelGGL(k_inverse_generic<NREC>, dim3(nbx, nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->S, p->d_wd,
 		                   obuf + (size_t)p->inv_noct * slot, 1, (size_t)NREC * p->ncoef, (size_t)nslots * slot);
-	hipLaunchKernelGGL(k_inv_combine, dim3((unsigned)((slot + 255) / 256), nb), dim3(256), 0, st, obuf, slot, nslots, slot, x,
-	                   (size_t)nslots * slot, slot);
+	if (NREC == 2 && nb == 1 && (f_ts || f_ls))
+		hipLaunchKernelGGL(k_inv_combine_out, dim3(nbx), dim3(256), 0, st, obuf, slot, nslots, (size_t)p->N, f_ts, f_ls, f_mtr);
+	else
+		hipLaunchKernelGGL(k_inv_combine, dim3((unsigned)((slot + 255) / 256), nb), dim3(256), 0, st, obuf, slot, nslots, slot, x,
+		                   (size_t)nslots * slot, slot);
 	return 0;
 }
 
@@ -2078,6 +2084,11 @@ extern "C" int tspws_hip_stack_finish_tail(tspws_hip_plan *pl, const t_tsPWS *p,
 	if ((rc = finish_block(pl, &OUT, &ST, &PS))) return rc;
 	const unsigned K = is_two_stage(p, mtr_global) ? p->Kmax : (unsigned)mtr_global;
 	if ((rc = tspws_hip_weight(pl, OUT, ST, PS, K, (unsigned)mtr_global, p->wu, p->unbiased, s))) return rc;
+	if (!use_generic_inverse() && pl->inv_noct) { // set 0 = ICWT(OUT), set 1 = ICWT(ST); the combining kernel writes the floats
+		if ((rc = inverse_launch<2>(pl, (const double2 *)OUT, nullptr, S_(s), 1, d_ts, d_ls, (float)(unsigned)mtr_global))) return rc;
+		HIP_TRY(hipGetLastError());
+		return 0;
+	}
 	if ((rc = scratch(pl, SCR_X2, 2 * (size_t)pl->N * sizeof(double), &v))) return rc;
 	double *x2 = (double *)v;
 	if ((rc = tspws_hip_inverse(pl, OUT, 2, x2, s))) return rc; // row 0 = ICWT(OUT), row 1 = ICWT(ST)
@@ -2124,7 +2135,7 @@ extern "C" int tspws_hip_profile_begin(tspws_hip_plan *pl, size_t max_calls)
 	const size_t need = max_calls * 2;
 	while (pl->prof_ev.size() < need) {
 		hipEvent_t e;
-		HIP_TRY(hipEventCreate(&e));
+		HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableSystemFence)); // timing on, device-scope ordering only: a system-scope release would write the fresh partial stacks back out of L2 (8 us per call)
 		pl->prof_ev.push_back(e);
 	}
 	pl->prof_used = 0;
