@@ -92,6 +92,9 @@ __device__ __forceinline__ void fl_lds_barrier()
 __device__ unsigned long long *fl_timing_out; // [7 classes][8]: set-up, barrier 1, stage, barrier 2, FMA, reduce, traces, waves
 #endif
 
+struct FlWrapNo { static constexpr bool value = true; };   // run<NW>: no circular wrap in any window of the workgroup
+struct FlWrapYes { static constexpr bool value = false; };
+
 // FUSE: scales without phase splits (D <= 64) do not write per-trace coefficients at all: the workgroup owns its
 // coefficients for the whole trace slice, so it phase-normalises each one right after the lane reduction and keeps
 // ST += Y, PS += Y/|Y| (ts_pws1f_lib.c:489-492) in registers, in trace order; one store per coefficient and slice at
@@ -134,31 +137,41 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 	const bool mok = SMALL ? true : (m < D);
 	// Addressing: uniform trace pointer + one 32-bit element offset per thread that walks the window; the empty asm keeps
 	// the compiler from hoisting all NXV offsets (trace-independent) out of the trace loop as 64-bit register pairs.
-	auto load_x = [&](TIn (&xv)[NXV], const TIn *__restrict__ xt, unsigned qa) {
+	// NW (no circular wrap anywhere in this workgroup's windows -- all but the blocks at the seam): uniform row offsets
+	// (SGPRs, advanced on the scalar unit) + one constant 32-bit lane offset, i.e. the loads need no VALU address arithmetic
+	// at all -- a wave's address VALU ops queue behind the other wave's 4-cycle FMAs (a load took 100-300 cycles to
+	// issue).  The two cases are separate instantiations of the trace loop (run<NW> below): inside one function the compiler
+	// merges their loads and computes per-lane 64-bit addresses for both.  Wrap: one opaque 32-bit element offset per
+	// thread that walks the window (the empty asm keeps the compiler from hoisting all NXV offsets, which are trace-
+	// independent, out of the trace loop as 64-bit register pairs).
+	const unsigned qa_last = (ntile - 1) * qt;
+	const bool nw_all = SMALL ? (x_base(0) >= 0 && x_base(qa_last) + NXV * FL_NT <= (long long)N)
+	                          : (full && x_base(0) >= 0 && x_base(qa_last) + (long long)(XROWS - 1) * D + 63 < (long long)N);
+	auto load_x = [&](auto NWT, TIn (&xv)[NXV], const TIn *__restrict__ xt, unsigned qa) {
 		const long long base = x_base(qa);
-		unsigned off, stp, mod;
-		if (SMALL) {
-			const bool nw = base >= 0 && base + NXV * FL_NT <= (long long)N; // no circular wrap
-			off = nw ? (unsigned)base + tid : wrap_index(base + tid, N);
-			stp = nw ? (unsigned)FL_NT : (unsigned)FL_NT % N;
-			mod = nw ? 0u : N;
-		} else {
-			const long long s_last = base + (long long)(XROWS - 1) * D + 63;
-			const bool nw = full && base >= 0 && s_last < (long long)N;
-			// circular seam and / or a last chunk with idle phase lanes (they read a valid address, store_x zeroes them)
-			off = nw ? (unsigned)(base + (long long)wv * D) + lane : wrap_index(base + (long long)wv * D + (mok ? lane : 0), N);
-			stp = nw ? (unsigned)FL_WAVES * D : (unsigned)(((unsigned long long)FL_WAVES * D) % N);
-			mod = nw ? 0u : N;
-		}
-		asm volatile("" : "+v"(off));
-		if (mod == 0) {
+		if constexpr (decltype(NWT)::value) {
+			// buffer loads: resource = this trace (uniform, rebuilt per trace on the scalar unit), voffset = the lane's constant
+			// byte offset, soffset = the row's uniform byte offset -- `buffer_load v, v_lane, s[rsrc], s_row offen`
+			const unsigned ubase = SMALL ? (unsigned)base : (unsigned)(base + (long long)wv * D);
+			const unsigned stp = (SMALL ? (unsigned)FL_NT : (unsigned)FL_WAVES * D) * (unsigned)sizeof(TIn);
+			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)xt, 0, N * (unsigned)sizeof(TIn), 0x00020000);
+			const unsigned vb = (SMALL ? tid : lane) * (unsigned)sizeof(TIn);
+			unsigned so = __builtin_amdgcn_readfirstlane(ubase) * (unsigned)sizeof(TIn);
 #pragma unroll
-			for (int i = 0; i < NXV; i++) { xv[i] = xt[off]; off += stp; }
+			for (int i = 0; i < NXV; i++) {
+				if constexpr (sizeof(TIn) == 8) xv[i] = __builtin_bit_cast(TIn, __builtin_amdgcn_raw_buffer_load_b64(rs, vb, so, 0));
+				else xv[i] = __builtin_bit_cast(TIn, __builtin_amdgcn_raw_buffer_load_b32(rs, vb, so, 0));
+				so += stp;
+			}
 		} else {
+			// circular seam and / or a last chunk with idle phase lanes (they read a valid address, store_x zeroes them)
+			unsigned off = SMALL ? wrap_index(base + tid, N) : wrap_index(base + (long long)wv * D + (mok ? lane : 0), N);
+			const unsigned wstp = SMALL ? (unsigned)FL_NT % N : (unsigned)(((unsigned long long)FL_WAVES * D) % N);
+			asm volatile("" : "+v"(off));
 #pragma unroll
 			for (int i = 0; i < NXV; i++) {
 				xv[i] = xt[off];
-				off += stp; if (off >= mod) off -= mod;
+				off += wstp; if (off >= N) off -= N;
 			}
 		}
 	};
@@ -208,8 +221,9 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 	};
 
 	if (resident) stage_taps(0, d.Q); // made visible by the barrier in front of the first compute
+	auto run = [&](auto NWT) {
 	TIn xv[NXV];
-	if (resident) load_x(xv, x0, 0);
+	if (resident) load_x(NWT, xv, x0, 0);
 
 	constexpr int NACC = FUSE ? (SMALL ? (LOGD <= 3 ? (8 >> LOGD) : 1) : 1) : 1; // complex coefficients per lane and pass
 	const bool fuse = FUSE && d.nsplit == 1;
@@ -240,11 +254,11 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 			const unsigned qn = (d.Q - qa) < qt ? (d.Q - qa) : qt;
 			fl_lds_barrier(); // everyone is done reading the previous image (x rows, taps)
 			FL_STAMP(1); // barrier 1 (+ accumulator reset)
-			if (!resident) { stage_taps(qa, qn); load_x(xv, xt, qa); }
+			if (!resident) { stage_taps(qa, qn); load_x(NWT, xv, xt, qa); }
 			store_x(xv);
 			FL_STAMP(2); // wait for the prefetched x (vmcnt) + LDS stores
 			fl_lds_barrier();
-			if (resident && t + 1 < ntr) load_x(xv, xt + ld, 0); // next trace's window flies while this one is computed
+			if (resident && t + 1 < ntr) load_x(NWT, xv, xt + ld, 0); // next trace's window flies while this one is computed
 			FL_STAMP(3); // barrier 2 + issue of the next prefetch
 			// ------------------------------------------------------------------ compute: two passes (group slots) per wave
 #pragma unroll
@@ -431,6 +445,8 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 		atomicAdd(&fl_timing_out[(SMALL ? LOGD : 6) * 8 + 7], 1ull);
 	}
 #endif
+	}; // run
+	if (nw_all) run(FlWrapNo()); else run(FlWrapYes());
 #undef FL_STAMP
 }
 
