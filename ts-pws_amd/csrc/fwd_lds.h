@@ -145,8 +145,9 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 	// thread that walks the window (the empty asm keeps the compiler from hoisting all NXV offsets, which are trace-
 	// independent, out of the trace loop as 64-bit register pairs).
 	const unsigned qa_last = (ntile - 1) * qt;
-	const bool nw_all = SMALL ? (x_base(0) >= 0 && x_base(qa_last) + NXV * FL_NT <= (long long)N)
-	                          : (full && x_base(0) >= 0 && x_base(qa_last) + (long long)(XROWS - 1) * D + 63 < (long long)N);
+	const bool nw_all = (unsigned long long)N * sizeof(TIn) <= 0xFFFFFFFFull && // (a trace must fit a buffer resource's 32-bit byte range)
+	                    (SMALL ? (x_base(0) >= 0 && x_base(qa_last) + NXV * FL_NT <= (long long)N)
+	                           : (full && x_base(0) >= 0 && x_base(qa_last) + (long long)(XROWS - 1) * D + 63 < (long long)N));
 	auto load_x = [&](auto NWT, TIn (&xv)[NXV], const TIn *__restrict__ xt, unsigned qa) {
 		const long long base = x_base(qa);
 		if constexpr (decltype(NWT)::value) {
