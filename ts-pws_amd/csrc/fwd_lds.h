@@ -57,6 +57,9 @@
 #ifndef FL_PREFETCH
 #define FL_PREFETCH 1                           /* 1: LDS operands of the next burst are requested before this burst's FMAs */
 #endif
+#ifndef FL_WIDE
+#define FL_WIDE 1                               /* D >= 64: the two slots of a wave as ONE 16-output window (half the LDS reads per FMA) */
+#endif
 #define FL_NT (64 * FL_WAVES)                   /* threads per workgroup */
 #define FL_SLOTS (FL_WAVES * FL_PASSES)
 #if FL_QT % FL_R != 0
@@ -111,6 +114,9 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 	constexpr unsigned DC = 1u << (SMALL ? LOGD : 6);     // D when SMALL
 	constexpr unsigned GW = SMALL ? (64u >> LG) : 1u;     // groups per wave-slot
 	constexpr int SLOTS = FL_WAVES * PASSES;               // group slots of this workgroup
+	// WIDE (D >= 64, two slots per wave): the wave's two slots are ADJACENT output groups and share one 16-output sliding
+	// window -- one x row and one tap row per 32 FMAs instead of per 16 (the tap row alone is a 1-KB LDS read per wave).
+	constexpr bool WIDE = !SMALL && PASSES == 2 && FL_WIDE;
 	constexpr int XROWS = SLOTS * FL_R + FL_QT;            // rows staged when D >= 64
 	constexpr int NXV = SMALL ? (SLOTS * 512 + 23 * 32 + FL_NT - 1) / FL_NT : XROWS / FL_WAVES; // x values staged per thread
 	const unsigned D = SMALL ? DC : d.D;
@@ -262,6 +268,41 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 			if (resident && t + 1 < ntr) load_x(NWT, xv, xt + ld, 0); // next trace's window flies while this one is computed
 			FL_STAMP(3); // barrier 2 + issue of the next prefetch
 			// ------------------------------------------------------------------ compute: two passes (group slots) per wave
+			if constexpr (WIDE) {
+				constexpr int R2 = 2 * R;
+				const double *xb = xL + wv * (R2 * 64) + lane; // slots 2 wv, 2 wv + 1: outputs (g0 + 2 wv) R .. + 15
+				const double2 *tb = tL + lane;
+				double xw[R2];
+#pragma unroll
+				for (int j = 0; j < R2 - 1; j++) xw[j] = xb[j * 64];
+				double xn[2][FL_BATCH];
+				double2 tn[2][FL_BATCH];
+#pragma unroll
+				for (int u = 0; u < FL_BATCH; u++) { xn[0][u] = xb[(u + R2 - 1) * 64]; tn[0][u] = tb[u * 64]; }
+#pragma unroll
+				for (int h = 0; h < FL_QT / FL_BATCH; h++) {
+					if ((unsigned)(h * FL_BATCH) < qn) {
+						if (h + 1 < FL_QT / FL_BATCH) {
+#pragma unroll
+							for (int u = 0; u < FL_BATCH; u++) {
+								xn[(h + 1) & 1][u] = xb[((h + 1) * FL_BATCH + u + R2 - 1) * 64]; // (last row read: 16 wv + FL_QT + 14 < XROWS)
+								tn[(h + 1) & 1][u] = tb[((h + 1) * FL_BATCH + u) * 64];
+							}
+							asm volatile("" ::: "memory"); // the scheduler otherwise sinks these reads to just in front of their FMAs
+						}
+#pragma unroll
+						for (int u = 0; u < FL_BATCH; u++) {
+							const int sidx = h * FL_BATCH + u; // compile-time after unrolling
+							xw[(sidx + R2 - 1) % R2] = xn[h & 1][u];
+#pragma unroll
+							for (int r = 0; r < R2; r++) {
+								ar[r / R][r % R] = fma(xw[(sidx + r) % R2], tn[h & 1][u].x, ar[r / R][r % R]);
+								ai[r / R][r % R] = fma(xw[(sidx + r) % R2], tn[h & 1][u].y, ai[r / R][r % R]);
+							}
+						}
+					}
+				}
+			} else
 #pragma unroll
 			for (int p = 0; p < PASSES; p++) {
 				const unsigned slot = (unsigned)p * (unsigned)FL_WAVES + wv;
@@ -407,7 +448,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 				for (int r = 0; r < R; r++) { v[2 * r] = ar[p][r]; v[2 * r + 1] = ai[p][r]; }
 				const double sum = valu_reduce16(v, lane);
 				const unsigned o = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-				const unsigned k = (g0 + (unsigned)p * (unsigned)FL_WAVES + wv) * R + (o >> 1);
+				const unsigned k = (g0 + (WIDE ? wv * (unsigned)PASSES + (unsigned)p : (unsigned)p * (unsigned)FL_WAVES + wv)) * R + (o >> 1);
 				if ((lane & 3) == 0 && k < d.Ns) pout[(size_t)k * 2 + (o & 1)] = (o & 1) ? -sum : sum; // conj
 			}
 		}
@@ -428,7 +469,8 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 		if (!(lane & dup_mask)) {
 #pragma unroll
 			for (int p = 0; p < PASSES; p++) {
-				const unsigned g = SMALL ? g0 + ((unsigned)p * (unsigned)FL_WAVES + wv) * GW + lane_g : g0 + (unsigned)p * (unsigned)FL_WAVES + wv;
+				const unsigned g = SMALL ? g0 + ((unsigned)p * (unsigned)FL_WAVES + wv) * GW + lane_g
+				                         : g0 + (WIDE ? wv * (unsigned)PASSES + (unsigned)p : (unsigned)p * (unsigned)FL_WAVES + wv);
 #pragma unroll
 				for (int i = 0; i < NACC; i++) {
 					const unsigned k = g * R + (first >> 1) + (unsigned)i;
