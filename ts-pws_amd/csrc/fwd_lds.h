@@ -33,6 +33,13 @@
 //   FMA passes: their 45 KB window (FP64 partial stacks) takes as long to pull in (~16 B/cycle per CU) as the FMAs take.
 //   One dense FMA-issuing wave per SIMD would be enough for ~85 % of the FP64 rate (tools/fma64_issue.hip) -- the time
 //   goes to everything around the FMA passes, not to the issue rate.
+//   Timing ablations (results wrong, whole-call time on the ten transforms, direct kernel not running beside): the
+//   D >= 64 workgroups cost 62 us, the D < 64 ones 57 us, one after the other.  Of the 62 us: prologue (scale search,
+//   descriptor, tap staging, first window) 2, the per-trace skeleton (two barriers, LDS image store, window loads) 20,
+//   lane reductions + phase normalisation + partial stores 20, FMA passes with their LDS reads 20.  The window loads are
+//   NOT on the critical path: contiguous rows instead of D-strided ones, or no window loads at all, change the call by
+//   0-3 us (the phase timers charge the waiting to whichever phase meets the barrier).  Hence the two changes that did
+//   pay: buffer loads (no address VALU work) and the 16-output window (half the LDS reads per FMA): -4 and -8 us.
 //
 // Used for scales with at least 8 output groups (N_s >= 64) and D >= 64 or a power of two; everything else
 // (very coarse scales whose parallelism is only in the taps, odd small decimations) stays on k_fwd_poly.
