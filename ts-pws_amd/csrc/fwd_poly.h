@@ -399,10 +399,42 @@ __global__ void __launch_bounds__(256) k_gather_parts(const double2 *__restrict_
 	Y[(size_t)blockIdx.y * ncoef + i] = a;
 }
 
+// Phase weighting of one coefficient (tspws_biased :909-943, tspws_unbiased :965-984).
+// mode 0: wu == 2 biased, 1: wu == 1, 2: general power, 3: unbiased (K > 1); K = stacked units, M = traces.
+struct WeightArgs {
+	double2 *OUT;   // nullptr: no weighting
+	int mode;
+	double K, M, wu;
+};
+__device__ __forceinline__ double2 weight_value(const double2 st, const double2 ps, const int mode, const double K, const double M, const double wu)
+{
+	double a;
+	if (mode == 0) {
+		const double g = 1. / (K * K * M);
+		a = (ps.x * ps.x + ps.y * ps.y) * g;
+		return make_double2(a * st.x, a * st.y);
+	} else if (mode == 1) {
+		const double g = 1. / (K * M);
+		const double r = hypot(ps.x, ps.y);
+		return make_double2(st.x * r * g, st.y * r * g);
+	} else if (mode == 2) {
+		a = hypot(ps.x, ps.y) / K;
+		a = pow(a, wu);
+		return make_double2(st.x * a / M, st.y * a / M);
+	}
+	const double iK = 1. / K, iK1 = 1. / (K - 1), iM = 1. / M;
+	const double px = ps.x * iK, py = ps.y * iK;
+	a = px * px + py * py;
+	a = (K * a - 1) * iK1;
+	return make_double2(st.x * a * iM, st.y * a * iM);
+}
+
 // ST += sum_b Y_b ; PS += sum_b Y_b/|Y_b|  straight from the split partials (ts_pws1f_lib.c:489-492); scales the fused
 // forward kernel stacked itself (fuse_ok) are skipped or combined from its slice planes.
 // One block works on ONE scale (acc2_off[s] = its first block), so the scale lookup and descriptor reads are
-// wave-uniform scalar work.  Scales without splits: 256 coefficients per block, one thread each.  Split scales (coarse
+// wave-uniform scalar work.  wa.OUT != nullptr (the call finishes the stacks: every trace of a single batch): the thread
+// that completes a coefficient also writes its weighted value -- no separate pass over the coefficients.
+// Scales without splits: 256 coefficients per block, one thread each.  Split scales (coarse
 // scales: few coefficients, up to 32 partials each): 32 coefficients per block, 8 lanes per coefficient share the
 // partial loads and combine with three shuffles -- otherwise a handful of threads would walk hundreds of dependent-
 // latency loads and set the kernel's duration.
@@ -410,7 +442,7 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
                                                           unsigned S, unsigned ntr, double2 *__restrict__ ST, double2 *__restrict__ PS,
                                                           int zero_first, int fused, const double2 *__restrict__ fzST,
                                                           const double2 *__restrict__ fzPS, size_t fz_stride, unsigned nslices,
-                                                          size_t y_part, size_t y_stack, int many)
+                                                          size_t y_part, size_t y_stack, int many, WeightArgs wa)
 {
 	// blockIdx.y = independent stack (jackknife replica): its ntr transformed traces start y_part further in `part`, its
 	// ST / PS y_stack further (the fused forward kernel wrote the fuse_ok scales there directly: fused == 1)
@@ -424,10 +456,11 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 	if (fused && sc[lo].fuse_ok) {
 		// the forward kernel already stacked this scale: fused == 1, straight into ST / PS (nothing left to do);
 		// fused == 2, one plane pair per trace slice, added here in slice order
-		if (fused == 1) return;
+		if (fused == 1 && !wa.OUT) return;
 		const unsigned k = (blockIdx.x - sc[lo].acc2_off) * 256u + threadIdx.x;
 		if (k >= Ns) return;
 		const size_t i = sc[lo].coef_off + k;
+		if (fused == 1) { wa.OUT[i] = weight_value(ST[i], PS[i], wa.mode, wa.K, wa.M, wa.wu); return; }
 		double2 st = make_double2(0, 0), ps = make_double2(0, 0);
 		if (!zero_first) { st = ST[i]; ps = PS[i]; }
 		for (unsigned j = 0; j < nslices; j++) {
@@ -435,6 +468,7 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 			st.x += a.x; st.y += a.y; ps.x += b.x; ps.y += b.y;
 		}
 		ST[i] = st; PS[i] = ps;
+		if (wa.OUT) wa.OUT[i] = weight_value(st, ps, wa.mode, wa.K, wa.M, wa.wu);
 		return;
 	}
 	const bool wide = nsplit > 1;
@@ -458,6 +492,7 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 		if (lane == 0) {
 			if (!zero_first) { const double2 a = ST[i], b = PS[i]; st.x += a.x; st.y += a.y; ps.x += b.x; ps.y += b.y; }
 			ST[i] = st; PS[i] = ps;
+			if (wa.OUT) wa.OUT[i] = weight_value(st, ps, wa.mode, wa.K, wa.M, wa.wu);
 		}
 		return;
 	}
@@ -489,5 +524,8 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 			add_unit_phasor(ps, v);
 		}
 	}
-	if (sub == 0 && live) { ST[i] = st; PS[i] = ps; }
+	if (sub == 0 && live) {
+		ST[i] = st; PS[i] = ps;
+		if (wa.OUT) wa.OUT[i] = weight_value(st, ps, wa.mode, wa.K, wa.M, wa.wu);
+	}
 }

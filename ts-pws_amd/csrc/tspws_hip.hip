@@ -1619,15 +1619,17 @@ extern "C" int tspws_hip_accumulate(tspws_hip_plan *p, const double *d_Y, size_t
 
 // launches k_accumulate_parts for `nb` transformed traces; fz = what forward_parts left behind (may be NULL / not applied)
 static void launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb, double2 *ST, double2 *PS, int zero_first, const FuseOut *fz,
-                              unsigned nslices, hipStream_t st, unsigned nbatch = 1, size_t y_part = 0, size_t y_stack = 0, bool tl = false)
+                              unsigned nslices, hipStream_t st, unsigned nbatch = 1, size_t y_part = 0, size_t y_stack = 0, bool tl = false,
+                              const WeightArgs *wa = nullptr)
 {
+	WeightArgs w0; w0.OUT = nullptr; w0.mode = 0; w0.K = w0.M = w0.wu = 0;
 	const bool on = fz && fz->applied;
 	const bool direct = on && fz->accST == ST; // the single slice went straight into ST / PS
 	// tl: the many-trace decomposition's scale table (partial layout, fused flags, block geometry)
 	hipLaunchKernelGGL(k_accumulate_parts, dim3(tl ? p->tl_acc2_blocks : p->acc2_blocks, nbatch), dim3(256), 0, st, part, tl ? p->tl_npart : p->npart,
 	                   tl ? p->d_sc_tl : p->d_sc, p->S, nb, ST, PS, zero_first,
 	                   on ? (direct ? 1 : 2) : 0, on ? (const double2 *)fz->accST : nullptr, on ? (const double2 *)fz->accPS : nullptr,
-	                   on ? fz->stride : (size_t)0, nslices, y_part, y_stack, tl ? 1 : 0);
+	                   on ? fz->stride : (size_t)0, nslices, y_part, y_stack, tl ? 1 : 0, wa ? *wa : w0);
 }
 
 // slice length of the fused forward kernel for a batch of nb traces: whole batch when it is small (two-stage: the K
@@ -1643,7 +1645,8 @@ static unsigned fuse_tps(size_t nb)
 // Many traces (single-stage stacks): trace-lane kernel on the transposed batch (fwd_tl.h); the stacks of the fused scales
 // come back as one plane pair per 64-trace block, the split / coarse scales as per-trace partials in the tl layout.
 template <typename TIn>
-static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, hipStream_t st, bool keep)
+static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, hipStream_t st, bool keep,
+                     const WeightArgs *wa = nullptr, bool *weighted = nullptr)
 {
 	int rc;
 	void *v;
@@ -1675,19 +1678,23 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 		}
 		FuseOut fz;
 		fz.accST = planes; fz.accPS = planes + p->ncoef; fz.stride = 2 * p->ncoef; fz.tps = 64; fz.applied = true;
-		launch_accumulate(p, part, nb, (double2 *)d_ST, (double2 *)d_PS, (t0 == 0 && !keep) ? 1 : 0, &fz, nblk, st, 1, 0, 0, true);
+		const bool last = t0 + batch >= ntr; // the launch that completes the stacks also weights them (wa)
+		launch_accumulate(p, part, nb, (double2 *)d_ST, (double2 *)d_PS, (t0 == 0 && !keep) ? 1 : 0, &fz, nblk, st, 1, 0, 0, true, last && !keep ? wa : nullptr);
+		if (last && !keep && wa && wa->OUT && weighted) *weighted = true;
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
 
 template <typename TIn>
-static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, void *s, bool keep = false)
+static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, void *s, bool keep = false,
+                       const WeightArgs *wa = nullptr, bool *weighted = nullptr)
 { // keep: add to the stacks already in d_ST / d_PS instead of starting from zero
+  // wa: weighting to apply where the stacks are completed (same kernel launch); *weighted tells whether that happened
 	HIP_TRY(hipSetDevice(p->device));
 	hipStream_t st = S_(s);
 	if (ntr >= tl_min_traces() && tl_enabled() && fuse_enabled() && p->fwd_kind == 1 && p->tl_n && !use_generic_forward())
-		return stacks_tl<TIn>(p, d_x, ntr, ld, d_ST, d_PS, st, keep);
+		return stacks_tl<TIn>(p, d_x, ntr, ld, d_ST, d_PS, st, keep, wa, weighted);
 	if (!ntr) { if (!keep) { HIP_TRY(hipMemsetAsync(d_ST, 0, p->ncoef * 16, st)); HIP_TRY(hipMemsetAsync(d_PS, 0, p->ncoef * 16, st)); } return 0; }
 	int rc;
 	if (use_generic_forward()) {
@@ -1725,7 +1732,9 @@ static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld,
 			else { fz.accST = (double2 *)vz; fz.accPS = (double2 *)vz + p->ncoef; fz.stride = 2 * p->ncoef; }
 		}
 		if ((rc = forward_parts<TIn>(p, d_x + t0 * ld, nb, ld, (double2 *)v, st, fuse ? &fz : nullptr))) return rc;
-		launch_accumulate(p, (const double2 *)v, (unsigned)nb, (double2 *)d_ST, (double2 *)d_PS, zero_first, &fz, nsl, st);
+		const bool all = nb == ntr && !keep; // one batch holds every trace: the accumulation completes the stacks
+		launch_accumulate(p, (const double2 *)v, (unsigned)nb, (double2 *)d_ST, (double2 *)d_PS, zero_first, &fz, nsl, st, 1, 0, 0, false, all ? wa : nullptr);
+		if (all && wa && wa->OUT && weighted) *weighted = true;
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
@@ -1756,27 +1765,7 @@ __global__ void __launch_bounds__(256) k_weight(double2 *__restrict__ OUT, const
 	// blockIdx.y = independent stack (jackknife replica) with its own trace count M
 	OUT += (size_t)blockIdx.y * y_out; ST += (size_t)blockIdx.y * y_stack; PS += (size_t)blockIdx.y * y_stack;
 	if (Mv) M = Mv[blockIdx.y];
-	const double2 st = ST[i], ps = PS[i];
-	double a;
-	if (mode == 0) {
-		const double g = 1. / (K * K * M);
-		a = (ps.x * ps.x + ps.y * ps.y) * g;
-		OUT[i] = make_double2(a * st.x, a * st.y);
-	} else if (mode == 1) {
-		const double g = 1. / (K * M);
-		const double r = hypot(ps.x, ps.y);
-		OUT[i] = make_double2(st.x * r * g, st.y * r * g);
-	} else if (mode == 2) {
-		a = hypot(ps.x, ps.y) / K;
-		a = pow(a, wu);
-		OUT[i] = make_double2(st.x * a / M, st.y * a / M);
-	} else {
-		const double iK = 1. / K, iK1 = 1. / (K - 1), iM = 1. / M;
-		const double px = ps.x * iK, py = ps.y * iK;
-		a = px * px + py * py;
-		a = (K * a - 1) * iK1;
-		OUT[i] = make_double2(st.x * a * iM, st.y * a * iM);
-	}
+	OUT[i] = weight_value(ST[i], PS[i], mode, K, M, wu);
 }
 
 extern "C" int tspws_hip_weight(tspws_hip_plan *p, double *d_OUT, const double *d_ST, const double *d_PS, unsigned K, unsigned M,
@@ -2074,16 +2063,15 @@ extern "C" int tspws_hip_stack_finish_range(tspws_hip_plan *pl, const t_tsPWS *p
 	return stacks_impl<double>(pl, P + (size_t)g_begin * pl->N, g_end - g_begin, pl->N, ST, PS, s, g_begin != 0);
 }
 
-extern "C" int tspws_hip_stack_finish_tail(tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, float *d_ls, float *d_ts, void *s)
+static int finish_tail(tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, float *d_ls, float *d_ts, void *s, bool weighted)
 {
-	if (!pl || !p) return fail(TSPWS_E_ARG, "stack_finish_tail: NULL");
 	HIP_TRY(hipSetDevice(pl->device));
 	double *OUT, *ST, *PS;
 	int rc;
 	void *v;
 	if ((rc = finish_block(pl, &OUT, &ST, &PS))) return rc;
 	const unsigned K = is_two_stage(p, mtr_global) ? p->Kmax : (unsigned)mtr_global;
-	if ((rc = tspws_hip_weight(pl, OUT, ST, PS, K, (unsigned)mtr_global, p->wu, p->unbiased, s))) return rc;
+	if (!weighted && (rc = tspws_hip_weight(pl, OUT, ST, PS, K, (unsigned)mtr_global, p->wu, p->unbiased, s))) return rc;
 	if (!use_generic_inverse() && pl->inv_noct) { // set 0 = ICWT(OUT), set 1 = ICWT(ST); the combining kernel writes the floats
 		if ((rc = inverse_launch<2>(pl, (const double2 *)OUT, nullptr, S_(s), 1, d_ts, d_ls, (float)(unsigned)mtr_global))) return rc;
 		HIP_TRY(hipGetLastError());
@@ -2095,13 +2083,28 @@ extern "C" int tspws_hip_stack_finish_tail(tspws_hip_plan *pl, const t_tsPWS *p,
 	return tspws_hip_epilogue(d_ls, d_ts, x2 + pl->N, x2, pl->N, (unsigned)mtr_global, s);
 }
 
+extern "C" int tspws_hip_stack_finish_tail(tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, float *d_ls, float *d_ts, void *s)
+{
+	if (!pl || !p) return fail(TSPWS_E_ARG, "stack_finish_tail: NULL");
+	return finish_tail(pl, p, mtr_global, d_ls, d_ts, s, false);
+}
+
 extern "C" int tspws_hip_stack_finish(tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, float *d_ls, float *d_ts, void *s)
 {
 	if (!pl || !p) return fail(TSPWS_E_ARG, "stack_finish: NULL");
 	HIP_TRY(hipSetDevice(pl->device));
 	int rc;
 	if (is_two_stage(p, mtr_global)) {
-		if ((rc = tspws_hip_stack_finish_range(pl, p, mtr_global, 0, p->Kmax, s))) return rc;
+		// all Kmax partial stacks at once: the launch that completes ST / PS also writes the weighted coefficients
+		double *OUT, *ST, *PS, *P;
+		size_t nd;
+		if ((rc = finish_block(pl, &OUT, &ST, &PS))) return rc;
+		if ((rc = tspws_hip_reduce_buffer(pl, p, mtr_global, &P, &nd))) return rc;
+		WeightArgs wa;
+		wa.OUT = (double2 *)OUT; wa.mode = weight_mode(p->wu, p->unbiased, p->Kmax); wa.K = (double)p->Kmax; wa.M = (double)(unsigned)mtr_global; wa.wu = p->wu;
+		bool weighted = false;
+		if ((rc = stacks_impl<double>(pl, P, p->Kmax, pl->N, ST, PS, s, false, &wa, &weighted))) return rc;
+		return finish_tail(pl, p, mtr_global, d_ls, d_ts, s, weighted);
 	} else {
 		double *OUT, *ST, *PS, *B;
 		size_t nd;
