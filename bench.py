@@ -73,6 +73,11 @@ def main():
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     single = world == 1
+    # N > 1: share of the scales this rank finishes (None: plan without a sharded finish, or TSPWS_SHARD_FINISH=0)
+    shard = None
+    if world > 1 and os.environ.get("TSPWS_SHARD_FINISH", "1") != "0":
+        shard = plan.finish_shard(mtr_global, rank, world)
+    x2 = torch.empty(2 * N, dtype=torch.float64, device=X.device)
 
     def step(i=None):
         if single:
@@ -82,7 +87,7 @@ def main():
             return
         # N > 1: the streaming stage in two halves of the groups; the all-reduce of the first half (RCCL, its own
         # stream) overlaps the streaming of the second -- one logical fp64 reduction of P[Kmax][N] (ts-pws_amd.stack_sharded)
-        half = tspws.split_groups(K)
+        half = tspws.split_groups(K, shard is not None)
         buf = red.view(K, N)
         if i is not None:
             ev[i][0].record()
@@ -99,6 +104,15 @@ def main():
         if i is not None:
             ev[i][1].record()
         w2 = dist.all_reduce(buf[half:], op=dist.ReduceOp.SUM, async_op=True)
+        if shard is not None:
+            # scale-sharded finish: this rank transforms / weights / reconstructs its share of the scales only; the ranks add
+            # their partial reconstructions (2 N doubles) and every rank ends with the outputs (ts-pws_amd.stack_sharded)
+            w1.wait()
+            w2.wait()
+            plan.stack_finish_scales(mtr_global, shard[0], shard[1], x2)
+            dist.all_reduce(x2, op=dist.ReduceOp.SUM)
+            plan.epilogue(x2, mtr_global, ls, ts)
+            return
         w1.wait()
         plan.stack_finish_range(mtr_global, 0, half)   # transforms of the reduced half run beside the second reduction
         w2.wait()
@@ -139,7 +153,7 @@ def main():
     if single:
         nlaunch = max(1, lib.tspws_hip_stream_launches(plan.h))
     else:  # two pieces (split_groups), each launched two groups at a time; the library reports the last piece only
-        h = tspws.split_groups(K)
+        h = tspws.split_groups(K, shard is not None)
         rpl = max(1, 256 // max(1, -(-N // 1024)))
         nlaunch = (-(-h // rpl) if h else 0) + -(-(K - h) // rpl)
     traffic = None
@@ -161,7 +175,11 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{mtr_local} traces/GPU x {N} samples, Morlet w0=pi*sqrt(2/ln2) V=4 J={params.J}, "
                                f"two-stage K={K} + unbiased phase coherence (BASELINE configs[2]); HBM-resident float32 traces",
-                   "traces_total": mtr_global, "plan_create_ms": round(t_plan * 1e3, 3), "parallelism": f"trace-sharded x{world}, fp64 all-reduce of P[K][N] in two halves: the first overlaps the streaming of the second, the second the transforms of the first"},
+                   "traces_total": mtr_global, "plan_create_ms": round(t_plan * 1e3, 3), "parallelism": (f"trace-sharded x{world}: fp64 all-reduce of P[K][N] in two pieces (the first, K-2 groups, overlaps the streaming of the last two), then a "
+                                   f"scale-sharded finish stage: every rank transforms / weights / reconstructs its share of the scales, all-reduce of the 2 N partial "
+                                   f"reconstructions" if shard is not None else
+                                   f"trace-sharded x{world}, fp64 all-reduce of P[K][N] in two halves: the first overlaps the streaming of the second, the second the "
+                                   f"transforms of the first; every rank finishes redundantly")},
         "roofline": {"bound": "hbm", "kernel": "k_partial", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes / nlaunch, "ms_per_launch": stream_ms / nlaunch, "launches_per_call": nlaunch,

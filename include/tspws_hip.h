@@ -164,6 +164,20 @@ int  tspws_hip_profile_end(tspws_hip_plan *plan, double *mean_ms, size_t *ncalls
  * few groups at a time so that every launch puts one workgroup on every CU. */
 int  tspws_hip_stream_launches(const tspws_hip_plan *plan);
 
+/* ---- scale-sharded finish stage (multi-GPU; no counterpart in the reference) ---------------------------------------------
+ * After the all-reduce every rank holds the same Kmax partial stacks.  The transforms, the weighting and the inverse are
+ * separable by scale and the reconstruction is a SUM over scales: rank r finishes only its share of the scales and the
+ * ranks add their partial reconstructions (2 * max doubles) before tspws_hip_epilogue.
+ *   _finish_shard : work-balanced, contiguous share [*s_begin, *s_end) of the scales (whole decimation octaves, possibly
+ *                   empty) of `rank` in `world`; returns 1 (not an error) when the plan / parameters have no sharded finish
+ *                   (single-stage calls, debug kernels, >= 64 groups): finish with tspws_hip_stack_finish then.
+ *   _finish_scales: transforms + stacks + weights + inverse of those scales from the reduced partial stacks
+ *                   (tspws_hip_reduce_buffer); d_x2 receives [ICWT(OUT) | ICWT(ST)] restricted to them, 2 * max doubles. */
+int  tspws_hip_finish_shard(const tspws_hip_plan *plan, const t_tsPWS *p, size_t mtr_global, unsigned rank, unsigned world,
+                            unsigned *s_begin, unsigned *s_end);
+int  tspws_hip_stack_finish_scales(tspws_hip_plan *plan, const t_tsPWS *p, size_t mtr_global, unsigned s_begin, unsigned s_end,
+                                   double *d_x2, void *stream);
+
 /* ---- jackknife (two-stage only, like the reference) ------------------------------------- */
 /* Host: deletion masks sel[C][mtr] (1 = kept) from start times.  JackknifePlans, :385-430.
  * Returns 0, 1 for NULL arguments, -2 when time[0]==0 (no start times). */

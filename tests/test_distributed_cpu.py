@@ -87,6 +87,39 @@ class OraclePlan:
         ls.copy_(torch.from_numpy(self.f.inverse(ST).astype(np.float32) / np.float32(mtr_global)))
 
 
+    # ---- scale-sharded finish: same interface as ts-pws_amd.Plan's finish_shard / stack_finish_scales / epilogue ----
+    def finish_shard(self, mtr_global, rank, world):
+        if not self.two_stage(mtr_global):
+            return None
+        S = self.f.S
+        D = self.f.D
+        octs = [0] + [s for s in range(1, S) if D[s] != D[s - 1]] + [S]   # decimation octaves
+        n = len(octs) - 1
+        lo, hi = rank * n // world, (rank + 1) * n // world               # any contiguous split of whole octaves is valid
+        return (octs[lo], octs[hi]) if lo < hi else (0, 0)
+
+    def stack_finish_scales(self, mtr_global, s_begin, s_end, x2):
+        nc, K, N = self.f.ncoef, self.p.Kmax, self.N
+        orc = abi.oracle()
+        P = self.buf.numpy().reshape(K, N)
+        ST = np.zeros(nc, np.complex128)
+        PS = np.zeros(nc, np.complex128)
+        for g in range(K):
+            Y = self.f.forward(P[g])
+            orc.orc_accumulate(ST.ctypes.data, PS.ctypes.data, Y.ctypes.data, nc)
+        OUT = np.zeros(nc, np.complex128)
+        orc.orc_weight(OUT.ctypes.data, ST.ctypes.data, PS.ctypes.data, nc, K, mtr_global, self.p.wu, self.p.unbiased)
+        off = np.concatenate(([0], np.cumsum(self.f.Ns.astype(np.int64))))  # ragged container: d[s+1] = d[s] + N[s]
+        mask = np.zeros(nc, bool)
+        mask[off[s_begin]:off[s_end]] = True                                # the reconstruction is a sum over scales
+        x2.numpy()[:N] = self.f.inverse(np.where(mask, OUT, 0))
+        x2.numpy()[N:] = self.f.inverse(np.where(mask, ST, 0))
+
+    def epilogue(self, x2, mtr_global, ls, ts):
+        N = self.N
+        ts.copy_(torch.from_numpy(x2.numpy()[:N].astype(np.float32)))
+        ls.copy_(torch.from_numpy(x2.numpy()[N:].astype(np.float32) / np.float32(mtr_global)))
+
     # ---- trace-sharded jackknife: same interface as ts-pws_amd.Plan's jackknife_* methods ----
     def jackknife_buffer(self, Cn):
         n = Cn * self.p.Kmax * self.N
@@ -200,6 +233,23 @@ def test_two_rank_shards_match_unsharded(tmp_path, kw):
     for r in range(world):
         assert abi.relerr(np.load(tmp_path / f"ls{r}.npy"), want["ls"]) < 2e-6
         assert abi.relerr(np.load(tmp_path / f"ts{r}.npy"), want["tsPWS"]) < 2e-6
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_scale_sharded_finish_over_gloo(tmp_path, world, monkeypatch):
+    """stack_sharded with the scale-sharded finish stage (default for world > 1 when the plan offers one): the ranks finish
+    disjoint runs of octaves and add their partial reconstructions; with TSPWS_SHARD_FINISH=0 every rank finishes
+    redundantly.  Both schedules against the unsharded oracle call."""
+    kw, mtr, N = dict(Kmax=5, unbiased=1), 23, 1024
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), abi.synth_traces(mtr, N, seed=17))
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TSPWS_SHARD_FINISH", mode)
+        out = tmp_path / mode
+        out.mkdir()
+        mp.spawn(_worker, args=(world, _free_port(), kw, mtr, N, str(out)), nprocs=world, join=True)
+        for r in range(world):
+            assert abi.relerr(np.load(out / f"ls{r}.npy"), want["ls"]) < 2e-6
+            assert abi.relerr(np.load(out / f"ts{r}.npy"), want["tsPWS"]) < 2e-6
 
 
 def test_empty_shard_reaches_the_collective(tmp_path):

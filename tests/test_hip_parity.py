@@ -7,6 +7,7 @@ device path is FP64 like the reference, so the tests hold it to much tighter bou
   * float32 outputs: 2e-6 (an ulp of the peak, plus rounding of values near a float tie)
 """
 import ctypes as C
+import os
 import importlib
 
 import numpy as np
@@ -875,3 +876,95 @@ def test_random_parameter_sets_vs_oracle(lib, seed):
         np.testing.assert_array_equal(a["sigall"], b["sigall"], err_msg=tag)
         assert abi.relerr(a["ls"], b["ls"]) < TOL32, tag
         assert abi.relerr(a["tsPWS"], b["tsPWS"]) < TOL32, tag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,N,world", [
+    (dict(Kmax=10, unbiased=1), 131072, 8), (dict(Kmax=5), 16501, 3), (dict(type=-3, Kmax=4, wu=1.0), 8192, 4),
+    (dict(Kmax=3, w0=3.0), 4096, 2),    # b0 = 0: every decimation is 1 -> ONE octave: ranks 1.. get empty shares
+    (dict(Kmax=6, unbiased=1, V=3), 3001, 5),
+])
+def test_scale_sharded_finish_adds_up(lib, torch, kw, N, world):
+    """Sharded finish stage (multi-GPU): the ranks' shares of the scales partition the frame, every share is a run of whole
+    decimation octaves, and the partial reconstructions of all shares add up to the plain finish -- same kernels on
+    sub-ranges of their launch lists, only the order of the final sum over octaves differs."""
+    mtr = 60
+    p = tspws.resolve(abi.default_params(**kw), N)
+    pl = tspws.Plan(p, N)
+    Xd = tspws.synth(mtr, N, seed=31)
+    ls0 = torch.empty(N, dtype=torch.float32, device="cuda")
+    ts0 = torch.empty(N, dtype=torch.float32, device="cuda")
+    pl.stack_local(Xd, 0, mtr)
+    pl.stack_finish(mtr, ls0, ts0)
+    shares = [pl.finish_shard(mtr, r, world) for r in range(world)]
+    assert all(s is not None for s in shares)
+    D = pl.tables()["D"]
+    covered = []
+    for a, b in shares:
+        assert 0 <= a <= b <= pl.S
+        if a < b:
+            assert a == 0 or D[a - 1] != D[a]          # starts an octave
+            assert b == pl.S or D[b - 1] != D[b]        # ends one
+            covered += list(range(a, b))
+    assert covered == list(range(pl.S))                # a partition, in rank order
+    total = torch.zeros(2 * N, dtype=torch.float64, device="cuda")
+    x2 = torch.empty(2 * N, dtype=torch.float64, device="cuda")
+    for a, b in shares[::-1]:                           # any order: each call recomputes its scales from the reduce buffer
+        pl.stack_finish_scales(mtr, a, b, x2)
+        total += x2
+    ls1 = torch.empty(N, dtype=torch.float32, device="cuda")
+    ts1 = torch.empty(N, dtype=torch.float32, device="cuda")
+    pl.epilogue(total, mtr, ls1, ts1)
+    torch.cuda.synchronize()
+    assert abi.relerr(ls1.cpu().numpy(), ls0.cpu().numpy()) < 1e-6 and abi.relerr(ts1.cpu().numpy(), ts0.cpu().numpy()) < 1e-6
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), Xd.cpu().numpy())
+    assert abi.relerr(ts1.cpu().numpy(), want["tsPWS"]) < TOL32 and abi.relerr(ls1.cpu().numpy(), want["ls"]) < TOL32
+    # the plain finish is untouched by the range state
+    ls2 = torch.empty(N, dtype=torch.float32, device="cuda")
+    ts2 = torch.empty(N, dtype=torch.float32, device="cuda")
+    pl.stack_finish(mtr, ls2, ts2)
+    torch.cuda.synchronize()
+    assert torch.equal(ls2, ls0) and torch.equal(ts2, ts0)
+    with pytest.raises(tspws.TspwsError):
+        pl.stack_finish_scales(mtr, 1, pl.S, x2)        # not an octave boundary (V >= 2 everywhere here) ... or a single octave
+    # single-stage parameters have no sharded finish
+    pl1 = tspws.Plan(tspws.resolve(abi.default_params(), N), N)
+    assert pl1.finish_shard(mtr, 0, 2) is None
+
+
+def _gpu_shard_worker(rank, world, port, kw, mtr, N, out_dir):
+    import torch as th
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # (one GPU here: RCCL wants one device per rank; gloo moves the same tensors)
+    try:
+        pl = tspws.Plan(tspws.resolve(abi.default_params(**kw), N), N)
+        first, count = tspws.shard_range(mtr, rank, world)
+        X = tspws.synth(count, N, seed=31, first=first)
+        ls, ts = tspws.stack_sharded(pl, X, first, mtr)
+        th.cuda.synchronize()
+        np.save(os.path.join(out_dir, f"ls{rank}.npy"), ls.cpu().numpy())
+        np.save(os.path.join(out_dir, f"ts{rank}.npy"), ts.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shard_finish", ["1", "0"])
+def test_two_processes_share_the_gpu_over_gloo(lib, torch, tmp_path, monkeypatch, shard_finish):
+    """The multi-GPU orchestration (stack_sharded: two-piece streaming + reductions, scale-sharded or redundant finish) with
+    the real engine: two processes on this GPU, gloo as the collective.  Every rank must end with the one-process outputs."""
+    import socket
+    import torch.multiprocessing as mp
+    kw, mtr, N, world = dict(Kmax=10, unbiased=1), 200, 16384, 2
+    monkeypatch.setenv("TSPWS_SHARD_FINISH", shard_finish)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_gpu_shard_worker, args=(world, port, kw, mtr, N, str(tmp_path)), nprocs=world, join=True)
+    pl = tspws.Plan(tspws.resolve(abi.default_params(**kw), N), N)
+    ls, ts = pl.stack(tspws.synth(mtr, N, seed=31))
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert abi.relerr(np.load(tmp_path / f"ls{r}.npy"), ls.cpu().numpy()) < 1e-6
+        assert abi.relerr(np.load(tmp_path / f"ts{r}.npy"), ts.cpu().numpy()) < 1e-6

@@ -107,6 +107,8 @@ SYMBOLS = {
     "tspws_jackknife_plan": (_i, [_vp, _vp, _sz, _u, _u, _u]),
     "tspws_hip_jackknife": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _u, _vp, _vp, _vp, _vp]),
     "tspws_hip_jackknife_prepare": (_i, [_vp, _vp, _vp, _u, _sz]),
+    "tspws_hip_finish_shard": (_i, [_vp, _vp, _sz, _u, _u, C.POINTER(_u), C.POINTER(_u)]),
+    "tspws_hip_stack_finish_scales": (_i, [_vp, _vp, _sz, _u, _u, _vp, _vp]),
     "tspws_hip_jackknife_buffer": (_i, [_vp, _vp, _u, C.POINTER(_vp), C.POINTER(_sz)]),
     "tspws_hip_jackknife_local": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _u, _vp]),
     "tspws_hip_jackknife_finish": (_i, [_vp, _vp, _sz, _vp, _u, _u, _u, _vp, _vp, _vp, _vp]),
@@ -287,6 +289,29 @@ class Plan:
         check(self.lib.tspws_hip_jackknife_finish(self.h, C.byref(self.params), mtr_global, sel.ctypes.data, sel.shape[0], c_begin, c_end,
                                                   ls_out.data_ptr(), ts_out.data_ptr(), mtr_out.ctypes.data, self._stream()), "jackknife_finish")
 
+    # ---- scale-sharded finish stage (see stack_sharded) --------------------------------
+    def finish_shard(self, mtr_global, rank, world):
+        """Scales [s_begin, s_end) that `rank` of `world` finishes, or None when this plan / parameter set has no sharded finish."""
+        a, b = C.c_uint(), C.c_uint()
+        rc = self.lib.tspws_hip_finish_shard(self.h, C.byref(self.params), mtr_global, rank, world, C.byref(a), C.byref(b))
+        if rc == 1:
+            return None
+        check(rc, "finish_shard")
+        return a.value, b.value
+
+    def stack_finish_scales(self, mtr_global, s_begin, s_end, x2):
+        """This rank's share of the finish stage: x2 (float64 [2 N], cuda) receives the partial reconstructions of the scales."""
+        import torch
+        if x2.dtype != torch.float64 or x2.numel() != 2 * self.N or not x2.is_contiguous() or not x2.is_cuda or (x2.device.index or 0) != self.device:
+            raise TspwsError(f"x2 must be a contiguous float64 tensor of {2 * self.N} values on cuda:{self.device}")
+        check(self.lib.tspws_hip_stack_finish_scales(self.h, C.byref(self.params), mtr_global, s_begin, s_end, x2.data_ptr(), self._stream()),
+              "stack_finish_scales")
+
+    def epilogue(self, x2, mtr_global, ls, ts):
+        """ls = (float)x2[N:] / mtr, ts = (float)x2[:N]  (reference epilogue, ts_pws1f_lib.c:233-241)."""
+        check(self.lib.tspws_hip_epilogue(self._out(ls, "ls"), self._out(ts, "ts"), x2.data_ptr() + 8 * self.N, x2.data_ptr(), self.N, mtr_global,
+                                          self._stream()), "epilogue")
+
     def stack(self, traces, first=0, mtr_global=None, group=None):
         """ls, tsPWS (float32 cuda tensors) of a shard of HBM-resident traces; see stack_sharded."""
         return stack_sharded(self, traces, first, mtr_global, group)
@@ -331,7 +356,8 @@ def stack_sharded(plan, traces, first=0, mtr_global=None, group=None):
     if distributed and callable(getattr(plan, "partial_stacks_range", None)) and K >= 2 and K <= mtr_global:
         # two-stage: the sum is row-separable, so the all-reduce of the first half of the groups runs (on the collective's
         # own stream) while the second half is still being streamed -- still one logical reduction of P[Kmax][N]
-        half = split_groups(K)
+        shard = _finish_shard(plan, mtr_global, group)
+        half = split_groups(K, shard is not None)
         buf = plan.reduce_buffer(mtr_global).view(K, plan.N)
         plan.partial_stacks_range(traces, first, mtr_global, 0, half)
         w1 = dist.all_reduce(buf[:half], op=dist.ReduceOp.SUM, group=group, async_op=True)
@@ -339,6 +365,16 @@ def stack_sharded(plan, traces, first=0, mtr_global=None, group=None):
         w2 = dist.all_reduce(buf[half:], op=dist.ReduceOp.SUM, group=group, async_op=True)
         ls = torch.empty(plan.N, dtype=torch.float32, device=traces.device)
         ts = torch.empty(plan.N, dtype=torch.float32, device=traces.device)
+        if shard is not None:
+            # scale-sharded finish: every rank transforms / weights / reconstructs only its share of the scales of the
+            # reduced partial stacks; the partial reconstructions (2 N doubles) are added and every rank ends with the outputs
+            w1.wait()
+            w2.wait()
+            x2 = torch.empty(2 * plan.N, dtype=torch.float64, device=traces.device)
+            plan.stack_finish_scales(mtr_global, shard[0], shard[1], x2)
+            dist.all_reduce(x2, op=dist.ReduceOp.SUM, group=group)
+            plan.epilogue(x2, mtr_global, ls, ts)
+            return ls, ts
         w1.wait()
         if callable(getattr(plan, "stack_finish_range", None)):
             # the transforms of the first half of the groups run while the second half is still being reduced
@@ -418,11 +454,24 @@ def jackknife_sharded(plan, traces, sel, first=0, mtr_global=None, group=None):
     return ls, ts, ls_out, ts_out, mtr_out
 
 
-def split_groups(K):
-    """First piece of the two-piece streaming / reduction schedule: about half the groups, EVEN when possible -- the streaming
-    pass launches the groups two at a time (one workgroup per CU at N = 131072), so an odd piece would end on a launch that
+def _finish_shard(plan, mtr_global, group=None):
+    """This rank's share of the scales for the sharded finish stage, or None (plan without one, world 1, TSPWS_SHARD_FINISH=0)."""
+    import torch.distributed as dist
+    if os.environ.get("TSPWS_SHARD_FINISH", "1") == "0" or not callable(getattr(plan, "finish_shard", None)):
+        return None
+    world = dist.get_world_size(group)
+    if world < 2:
+        return None
+    return plan.finish_shard(mtr_global, dist.get_rank(group), world)
+
+
+def split_groups(K, sharded_finish=False):
+    """First piece of the two-piece streaming / reduction schedule.  Redundant finish: about half the groups -- the second
+    reduction then hides behind the transforms of the first half.  Scale-sharded finish (nothing to hide behind): all but
+    the last two groups, so that only a small reduction is left exposed.  EVEN when possible -- the streaming pass
+    launches the groups two at a time (one workgroup per CU at N = 131072), so an odd piece would end on a launch that
     fills half the CUs."""
-    half = K // 2
+    half = K - 2 if (sharded_finish and K > 3) else K // 2
     if half >= 2 and half % 2:
         half -= 1
     return half

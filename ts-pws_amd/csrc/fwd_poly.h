@@ -230,13 +230,13 @@ __device__ __forceinline__ void valu_reduce_cplx64(const double (&v)[16], const 
 template <typename TIn, int B>
 __global__ void __launch_bounds__(256) k_fwd_poly(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned N,
                                                   const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
-                                                  double2 *__restrict__ part, size_t npart, unsigned total_waves)
+                                                  double2 *__restrict__ part, size_t npart, unsigned total_waves, unsigned wid0 = 0)
 {
 	constexpr int R = FWD_R;
 	const unsigned lane = threadIdx.x & 63;
 	// readfirstlane makes the wave index provably uniform: the scale lookup and the whole descriptor then
-	// live in SGPRs (scalar loads, scalar branches) instead of VGPRs
-	const unsigned wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	// live in SGPRs (scalar loads, scalar branches) instead of VGPRs.  wid0 / total_waves: the launch's range of the wave list
+	const unsigned wid = wid0 + blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	if (wid >= total_waves) return;
 	// scale of this wave: last s with wave_off[s] <= wid
 	unsigned lo = 0, hi = S;
@@ -442,22 +442,23 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
                                                           unsigned S, unsigned ntr, double2 *__restrict__ ST, double2 *__restrict__ PS,
                                                           int zero_first, int fused, const double2 *__restrict__ fzST,
                                                           const double2 *__restrict__ fzPS, size_t fz_stride, unsigned nslices,
-                                                          size_t y_part, size_t y_stack, int many, WeightArgs wa)
+                                                          size_t y_part, size_t y_stack, int many, WeightArgs wa, unsigned blk0)
 {
+	const unsigned bx = blk0 + blockIdx.x; // (blk0: the launch may cover a sub-range of the scales)
 	// blockIdx.y = independent stack (jackknife replica): its ntr transformed traces start y_part further in `part`, its
 	// ST / PS y_stack further (the fused forward kernel wrote the fuse_ok scales there directly: fused == 1)
 	part += (size_t)blockIdx.y * y_part; ST += (size_t)blockIdx.y * y_stack; PS += (size_t)blockIdx.y * y_stack;
 	unsigned lo = 0, hi = S;
 	while (hi - lo > 1) {
 		const unsigned mid = (lo + hi) >> 1;
-		if (sc[mid].acc2_off <= blockIdx.x) lo = mid; else hi = mid;
+		if (sc[mid].acc2_off <= bx) lo = mid; else hi = mid;
 	}
 	const unsigned Ns = sc[lo].Ns, nsplit = sc[lo].nsplit;
 	if (fused && sc[lo].fuse_ok) {
 		// the forward kernel already stacked this scale: fused == 1, straight into ST / PS (nothing left to do);
 		// fused == 2, one plane pair per trace slice, added here in slice order
 		if (fused == 1 && !wa.OUT) return;
-		const unsigned k = (blockIdx.x - sc[lo].acc2_off) * 256u + threadIdx.x;
+		const unsigned k = (bx - sc[lo].acc2_off) * 256u + threadIdx.x;
 		if (k >= Ns) return;
 		const size_t i = sc[lo].coef_off + k;
 		if (fused == 1) { wa.OUT[i] = weight_value(ST[i], PS[i], wa.mode, wa.K, wa.M, wa.wu); return; }
@@ -476,7 +477,7 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 		// many traces, few coefficients (coarse / residue-split scales of a single-stage batch; table geometry: 4 coefficients
 		// per block): a wave per coefficient, its 64 lanes take every 64th TRACE (all splits of it), then a wave reduction --
 		// the dependent-load chain is ntr / 64 long and there are Ns / 4 blocks instead of Ns / 32
-		const unsigned k = (blockIdx.x - sc[lo].acc2_off) * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+		const unsigned k = (bx - sc[lo].acc2_off) * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 		if (k >= Ns) return;
 		const size_t i = sc[lo].coef_off + k;
 		const double2 *p0 = part + sc[lo].part_off + k;
@@ -497,7 +498,7 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 		return;
 	}
 	const unsigned sub = wide ? (threadIdx.x & 7) : 0, stride = wide ? 8u : 1u;
-	const unsigned k = (blockIdx.x - sc[lo].acc2_off) * (wide ? 32u : 256u) + (wide ? threadIdx.x >> 3 : threadIdx.x);
+	const unsigned k = (bx - sc[lo].acc2_off) * (wide ? 32u : 256u) + (wide ? threadIdx.x >> 3 : threadIdx.x);
 	const bool live = k < Ns;
 	if (!wide && !live) return;
 	const unsigned kc = live ? k : Ns - 1; // lanes past the end still take part in the shuffles

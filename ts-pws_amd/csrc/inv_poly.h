@@ -225,3 +225,16 @@ __global__ void __launch_bounds__(256) k_inv_combine_out(const double *__restric
 	if (ts) ts[n] = (float)a;
 	if (ls) ls[n] = (float)b / mtr;
 }
+
+// xout[i] = sum of the obuf rows [a0, a0 + na) and [b0, b0 + nb), in that order (a scale sub-range: its octave items form
+// one run per class); no rows at all give zeros.
+__global__ void __launch_bounds__(256) k_inv_combine_ranges(const double *__restrict__ obuf, size_t slot_stride, unsigned a0, unsigned na, unsigned b0,
+                                                            unsigned nb, size_t total, double *__restrict__ xout)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= total) return;
+	double a = 0;
+	for (unsigned s = 0; s < na; s++) a += obuf[(size_t)(a0 + s) * slot_stride + i];
+	for (unsigned s = 0; s < nb; s++) a += obuf[(size_t)(b0 + s) * slot_stride + i];
+	xout[i] = a;
+}

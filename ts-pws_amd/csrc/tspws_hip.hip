@@ -128,6 +128,7 @@ struct tspws_hip_plan {
 	FwdGroup *d_pairs = nullptr;
 	double *d_bt = nullptr;
 	size_t mfma_lds = 0;
+	std::vector<unsigned> oc_s0, oc_nv, oc_wave_off, oc_nwaves, oc_gen; // host copy of the inverse's octave items (launch order)
 	unsigned inv_waves = 0, inv_waves_fast = 0, inv_noct = 0, inv_ngeneric = 0; // polyphase inverse: waves (of the octaves whose D divides N first), octave items, scales left to the generic kernel
 	struct OctDesc *d_oc = nullptr;
 	std::vector<ScaleDesc> sc;
@@ -182,6 +183,16 @@ struct tspws_hip_plan {
 	// blocks of exported slots (tspws_hip_reduce_buffer hands out SCR_P / SCR_STPS) that were outgrown: a caller may
 	// still hold the old pointer (e.g. as the buffer of an in-flight collective), so they live until plan_destroy
 	std::vector<void *> retired;
+	// Scale sub-range of the finish-stage launches (sharded finish, tspws_hip_stack_finish_scales): scales [rs0, rs1);
+	// rs1 == 0 means all.  The launches take their workgroup / wave / block ranges from the per-scale offset tables.
+	unsigned rs0 = 0, rs1 = 0;
+	bool ranged() const { return rs1 != 0; }
+	unsigned lds_begin() const { return ranged() ? sc[rs0].lds_off : 0u; }
+	unsigned lds_end() const { return ranged() && rs1 < S ? sc[rs1].lds_off : lds_blocks; }
+	unsigned wav_begin() const { return ranged() ? sc[rs0].wave_off : 0u; }
+	unsigned wav_end() const { return ranged() && rs1 < S ? sc[rs1].wave_off : fwd_waves; }
+	unsigned acc_begin() const { return ranged() ? sc[rs0].acc2_off : 0u; }
+	unsigned acc_end() const { return ranged() && rs1 < S ? sc[rs1].acc2_off : acc2_blocks; }
 };
 
 static int scratch(tspws_hip_plan *p, int slot, size_t bytes, void **out)
@@ -1391,7 +1402,8 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 	static int merge_env = -1;
 	if (merge_env < 0) { const char *e = getenv("TSPWS_OCT_MERGE"); merge_env = (e && *e == '0') ? 0 : 1; }
 	const bool merged = merge_env && p->oct_wgs && p->lds_blocks && p->oct_mode == 1 && ntr <= 65535;
-	const int nk = (p->lds_blocks ? 1 : 0) + (p->fwd_waves ? 1 : 0) + ((p->oct_wgs && !merged) ? 1 : 0);
+	const bool has_lds = p->lds_end() > p->lds_begin(), has_poly = p->wav_end() > p->wav_begin(); // (this call's scale range)
+	const int nk = (has_lds ? 1 : 0) + (has_poly ? 1 : 0) + ((p->oct_wgs && !merged) ? 1 : 0);
 	const bool both = nk > 1 && side_stream_enabled();
 	hipStream_t sp = st, so = st; // streams of the direct and of the octave kernel
 	if (both) {
@@ -1402,7 +1414,7 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 		if (!p->ev_join) HIP_TRY(hipEventCreateWithFlags(&p->ev_join, evf));
 		if (!p->ev_join2) HIP_TRY(hipEventCreateWithFlags(&p->ev_join2, evf));
 		HIP_TRY(hipEventRecord(p->ev_fork, st));
-		if (p->fwd_waves && nk > 1) { HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0)); sp = p->side; }
+		if (has_poly && nk > 1) { HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0)); sp = p->side; }
 		if (p->oct_wgs && p->lds_blocks && !merged) { HIP_TRY(hipStreamWaitEvent(p->side2, p->ev_fork, 0)); so = p->side2; }
 	}
 	constexpr int TIX = sizeof(TIn) == 8 ? 1 : 0;
@@ -1460,20 +1472,21 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 	}
 	// the direct kernel first: its few hundred long, latency-bound workgroups (no LDS, 88 VGPRs) get their slots and the
 	// LDS kernel's workgroups fill in beside them
-	if (p->fwd_waves) {
-		const unsigned nb = (p->fwd_waves + 3) / 4;
+	const unsigned w0 = p->wav_begin(), w1 = p->wav_end(), b0 = p->lds_begin(), b1 = p->lds_end(); // this call's share of the launch lists
+	if (w1 > w0) {
+		const unsigned nb = (w1 - w0 + 3) / 4;
 		if (ntr == 1) {
 			hipLaunchKernelGGL((k_fwd_poly<TIn, 1>), dim3(nb, 1), dim3(256), 0, sp, d_x, ld, 1u, p->N, p->d_sc, p->S, p->d_w, d_part,
-			                   p->npart, p->fwd_waves);
+			                   p->npart, w1, w0);
 		} else {
 			for (size_t t0 = 0; t0 < ntr; t0 += 2 * 32768) {
 				const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, 2 * 32768);
 				hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nb, (nt + 1) / 2), dim3(256), 0, sp, d_x + t0 * ld, ld, nt, p->N, p->d_sc,
-				                   p->S, p->d_w, d_part + t0 * p->npart, p->npart, p->fwd_waves);
+				                   p->S, p->d_w, d_part + t0 * p->npart, p->npart, w1, w0);
 			}
 		}
 	}
-	if (p->lds_blocks) {
+	if (b1 > b0) {
 		const bool fuse = fz && fz->accST && p->n_fusable;
 		// traces per workgroup: enough slices to fill the GPU (>= ~2048 workgroups), at most 32 traces per slice
 		unsigned tps = (unsigned)std::min<size_t>(ntr, 32);
@@ -1502,12 +1515,12 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 		for (size_t t0 = 0; t0 < ntr; t0 += per_launch) {
 			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, per_launch);
 			if (fuse)
-				hipLaunchKernelGGL((k_fwd_lds<TIn, true>), dim3(p->lds_blocks, (nt + tps - 1) / tps), dim3(FL_NT), FL_LDS_BYTES, st, d_x + t0 * ld, ld,
+				hipLaunchKernelGGL((k_fwd_lds<TIn, true>), dim3(b1 - b0, (nt + tps - 1) / tps), dim3(FL_NT), FL_LDS_BYTES, st, d_x + t0 * ld, ld,
 				                   nt, tps, p->N, p->d_sc, p->S, p->d_w, d_part + t0 * p->npart, p->npart, fz->accST + (t0 / tps) * fz->stride,
-				                   fz->accPS + (t0 / tps) * fz->stride, fz->stride, rev);
+				                   fz->accPS + (t0 / tps) * fz->stride, fz->stride, rev, b0);
 			else
-				hipLaunchKernelGGL((k_fwd_lds<TIn, false>), dim3(p->lds_blocks, (nt + tps - 1) / tps), dim3(FL_NT), FL_LDS_BYTES, st, d_x + t0 * ld, ld,
-				                   nt, tps, p->N, p->d_sc, p->S, p->d_w, d_part + t0 * p->npart, p->npart, (double2 *)nullptr, (double2 *)nullptr, (size_t)0, rev);
+				hipLaunchKernelGGL((k_fwd_lds<TIn, false>), dim3(b1 - b0, (nt + tps - 1) / tps), dim3(FL_NT), FL_LDS_BYTES, st, d_x + t0 * ld, ld,
+				                   nt, tps, p->N, p->d_sc, p->S, p->d_w, d_part + t0 * p->npart, p->npart, (double2 *)nullptr, (double2 *)nullptr, (size_t)0, rev, b0);
 		}
 		if (fuse) fz->applied = true;
 	}
@@ -1626,10 +1639,12 @@ static void launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned n
 	const bool on = fz && fz->applied;
 	const bool direct = on && fz->accST == ST; // the single slice went straight into ST / PS
 	// tl: the many-trace decomposition's scale table (partial layout, fused flags, block geometry)
-	hipLaunchKernelGGL(k_accumulate_parts, dim3(tl ? p->tl_acc2_blocks : p->acc2_blocks, nbatch), dim3(256), 0, st, part, tl ? p->tl_npart : p->npart,
+	const unsigned a0 = tl ? 0u : p->acc_begin(), a1 = tl ? p->tl_acc2_blocks : p->acc_end();
+	if (a1 <= a0) return;
+	hipLaunchKernelGGL(k_accumulate_parts, dim3(a1 - a0, nbatch), dim3(256), 0, st, part, tl ? p->tl_npart : p->npart,
 	                   tl ? p->d_sc_tl : p->d_sc, p->S, nb, ST, PS, zero_first,
 	                   on ? (direct ? 1 : 2) : 0, on ? (const double2 *)fz->accST : nullptr, on ? (const double2 *)fz->accPS : nullptr,
-	                   on ? fz->stride : (size_t)0, nslices, y_part, y_stack, tl ? 1 : 0, wa ? *wa : w0);
+	                   on ? fz->stride : (size_t)0, nslices, y_part, y_stack, tl ? 1 : 0, wa ? *wa : w0, a0);
 }
 
 // slice length of the fused forward kernel for a batch of nb traces: whole batch when it is small (two-stage: the K
@@ -1905,6 +1920,11 @@ static int build_inverse_items(tspws_hip_plan *p)
 		if (!oc[i].gen) p->inv_waves_fast = woff;
 	}
 	p->inv_waves = woff; p->inv_noct = (unsigned)oc.size();
+	p->oc_s0.clear(); p->oc_nv.clear(); p->oc_wave_off.clear(); p->oc_nwaves.clear(); p->oc_gen.clear();
+	for (const OctDesc &o : oc) {
+		p->oc_s0.push_back(o.s0); p->oc_nv.push_back(o.nv); p->oc_wave_off.push_back(o.wave_off); p->oc_nwaves.push_back(o.MC * o.ngw);
+		p->oc_gen.push_back(o.gen);
+	}
 	if (!oc.empty()) {
 		HIP_TRY(hipMalloc(&p->d_oc, oc.size() * sizeof(OctDesc)));
 		HIP_TRY(hipMemcpy(p->d_oc, oc.data(), oc.size() * sizeof(OctDesc), hipMemcpyHostToDevice));
@@ -1967,6 +1987,41 @@ extern "C" int tspws_hip_inverse(tspws_hip_plan *p, const double *d_Y, size_t nr
 	}
 	if (nrec & 1)
 		if ((rc = inverse_launch<1>(p, (const double2 *)d_Y + (nrec - 1) * p->ncoef, d_x + (nrec - 1) * p->N, S_(s)))) return rc;
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// Two reconstructions (sets 0 and 1 of Y) from the scales [s_lo, s_hi) ONLY -- whole decimation octaves -- as FP64 partial
+// sums x2[2][N]: the reconstruction is a sum over scales, so the shares of disjoint scale ranges add up to the whole.
+static int inverse_scales(tspws_hip_plan *p, const double2 *Y, double *x2, hipStream_t st, unsigned s_lo, unsigned s_hi)
+{
+	const size_t slot = 2 * (size_t)p->N;
+	void *v;
+	int rc = scratch(p, SCR_OBUF, (size_t)p->inv_noct * slot * sizeof(double), &v);
+	if (rc) return rc;
+	double *obuf = (double *)v;
+	// the octave items are stored class by class (decimation divides N first), in scale order inside a class: the items
+	// of a scale range are one contiguous run per class
+	unsigned first[2] = {~0u, ~0u}, last[2] = {0, 0};
+	for (unsigned i = 0; i < p->inv_noct; i++) {
+		if (p->oc_s0[i] < s_lo || p->oc_s0[i] >= s_hi) continue;
+		const unsigned c = p->oc_gen[i] ? 1u : 0u;
+		if (first[c] == ~0u) first[c] = i;
+		last[c] = i;
+	}
+	for (unsigned c = 0; c < 2; c++) {
+		if (first[c] == ~0u) continue;
+		const unsigned w0 = p->oc_wave_off[first[c]], w1 = p->oc_wave_off[last[c]] + p->oc_nwaves[last[c]];
+		if (c == 0)
+			hipLaunchKernelGGL((k_inv_poly<2, false>), dim3((w1 - w0 + 3) / 4, 1), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->d_oc, p->inv_noct, p->d_wd,
+			                   obuf, slot, w1, (size_t)2 * p->ncoef, (size_t)p->inv_noct * slot, w0);
+		else
+			hipLaunchKernelGGL((k_inv_poly<2, true>), dim3((w1 - w0 + 3) / 4, 1), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->d_oc, p->inv_noct, p->d_wd,
+			                   obuf, slot, w1, (size_t)2 * p->ncoef, (size_t)p->inv_noct * slot, w0);
+	}
+	const unsigned a0 = first[0] == ~0u ? 0u : first[0], na = first[0] == ~0u ? 0u : last[0] - first[0] + 1;
+	const unsigned b0 = first[1] == ~0u ? 0u : first[1], nb = first[1] == ~0u ? 0u : last[1] - first[1] + 1;
+	hipLaunchKernelGGL(k_inv_combine_ranges, dim3((unsigned)((slot + 255) / 256)), dim3(256), 0, st, (const double *)obuf, slot, a0, na, b0, nb, slot, x2);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -2113,6 +2168,80 @@ extern "C" int tspws_hip_stack_finish(tspws_hip_plan *pl, const t_tsPWS *p, size
 		HIP_TRY(hipMemcpyAsync(ST, B, 4 * pl->ncoef * sizeof(double), hipMemcpyDeviceToDevice, S_(s)));
 	}
 	return tspws_hip_stack_finish_tail(pl, p, mtr_global, d_ls, d_ts, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// Scale-sharded finish stage (multi-GPU).  After the all-reduce every rank holds the same K partial stacks; instead of
+// finishing redundantly, rank r transforms, weights and reconstructs only ITS share of the scales -- the reconstruction
+// is a sum over scales -- and the ranks add their partial reconstructions (2 N doubles) before the epilogue.
+// ------------------------------------------------------------------------------------------
+static bool finish_shardable(const tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global)
+{
+	return is_two_stage(p, mtr_global) && pl->fwd_kind == 1 && !use_generic_forward() && !use_generic_inverse() && pl->inv_noct && !pl->inv_ngeneric &&
+	       !pl->oct_wgs && !(p->Kmax >= tl_min_traces() && tl_enabled() && fuse_enabled() && pl->tl_n);
+}
+
+// Contiguous, work-balanced share of the scales for `rank` of `world`: whole decimation octaves (the inverse sums the voices
+// of an octave in registers), cost = forward MACs.  Returns 0 with [*s_begin, *s_end) (possibly empty), 1 when this plan /
+// parameter set has no sharded finish (the caller then finishes as a whole), an error code for bad arguments.
+extern "C" int tspws_hip_finish_shard(const tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, unsigned rank, unsigned world, unsigned *s_begin,
+                                      unsigned *s_end)
+{
+	if (!pl || !p || !s_begin || !s_end || !world || rank >= world) return fail(TSPWS_E_ARG, "finish_shard: bad argument");
+	if (!finish_shardable(pl, p, mtr_global)) return 1;
+	std::vector<unsigned> items(pl->inv_noct);
+	for (unsigned i = 0; i < pl->inv_noct; i++) items[i] = i;
+	std::sort(items.begin(), items.end(), [&](unsigned a, unsigned b) { return pl->oc_s0[a] < pl->oc_s0[b]; });
+	std::vector<double> cost(items.size());
+	double total = 0;
+	for (size_t k = 0; k < items.size(); k++) {
+		double c = 0;
+		for (unsigned s = pl->oc_s0[items[k]]; s < pl->oc_s0[items[k]] + pl->oc_nv[items[k]]; s++) c += (double)pl->sc[s].L * (double)pl->sc[s].Ns;
+		cost[k] = c; total += c;
+	}
+	// item k goes to rank floor(world * (cum_before + cost / 2) / total): contiguous, balanced, deterministic on every rank
+	unsigned lo = ~0u, hi = 0;
+	double cum = 0;
+	for (size_t k = 0; k < items.size(); k++) {
+		unsigned owner = total > 0 ? (unsigned)((double)world * (cum + 0.5 * cost[k]) / total) : 0u;
+		if (owner >= world) owner = world - 1;
+		cum += cost[k];
+		if (owner != rank) continue;
+		if (lo == ~0u) lo = pl->oc_s0[items[k]];
+		hi = pl->oc_s0[items[k]] + pl->oc_nv[items[k]];
+	}
+	*s_begin = lo == ~0u ? 0u : lo;
+	*s_end = lo == ~0u ? 0u : hi;
+	return 0;
+}
+
+extern "C" int tspws_hip_stack_finish_scales(tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, unsigned s_begin, unsigned s_end, double *d_x2,
+                                             void *s)
+{
+	if (!pl || !p || !d_x2) return fail(TSPWS_E_ARG, "stack_finish_scales: NULL");
+	if (!finish_shardable(pl, p, mtr_global)) return fail(TSPWS_E_ARG, "stack_finish_scales: no sharded finish for this plan / parameter set (tspws_hip_finish_shard tells)");
+	if (s_begin > s_end || s_end > pl->S) return fail(TSPWS_E_ARG, "stack_finish_scales: 0 <= s_begin <= s_end <= S");
+	HIP_TRY(hipSetDevice(pl->device));
+	hipStream_t st = S_(s);
+	if (s_begin == s_end) { HIP_TRY(hipMemsetAsync(d_x2, 0, 2 * (size_t)pl->N * sizeof(double), st)); return 0; }
+	bool lo_ok = false, hi_ok = false; // whole octaves only
+	for (unsigned i = 0; i < pl->inv_noct; i++) { lo_ok |= pl->oc_s0[i] == s_begin; hi_ok |= pl->oc_s0[i] + pl->oc_nv[i] == s_end; }
+	if (!lo_ok || !hi_ok) return fail(TSPWS_E_ARG, "stack_finish_scales: the range must consist of whole decimation octaves");
+	double *OUT, *ST, *PS, *P;
+	size_t nd;
+	int rc;
+	if ((rc = finish_block(pl, &OUT, &ST, &PS))) return rc;
+	if ((rc = tspws_hip_reduce_buffer(pl, p, mtr_global, &P, &nd))) return rc;
+	WeightArgs wa;
+	wa.OUT = (double2 *)OUT; wa.mode = weight_mode(p->wu, p->unbiased, p->Kmax); wa.K = (double)p->Kmax; wa.M = (double)(unsigned)mtr_global; wa.wu = p->wu;
+	bool weighted = false;
+	pl->rs0 = s_begin; pl->rs1 = s_end; // the finish-stage launches below cover these scales only
+	rc = stacks_impl<double>(pl, P, p->Kmax, pl->N, ST, PS, s, false, &wa, &weighted);
+	pl->rs0 = pl->rs1 = 0;
+	if (rc) return rc;
+	// (several forward batches: weight afterwards -- over all coefficients; those of other scales are never read)
+	if (!weighted && (rc = tspws_hip_weight(pl, OUT, ST, PS, p->Kmax, (unsigned)mtr_global, p->wu, p->unbiased, s))) return rc;
+	return inverse_scales(pl, (const double2 *)OUT, d_x2, st, s_begin, s_end);
 }
 
 // ------------------------------------------------------------------------------------------
