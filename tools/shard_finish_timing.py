@@ -23,3 +23,7 @@ for world in (2, 4, 8):
     t = [timeit(lambda a=a, b=b: (pl.stack_finish_scales(mtr, a, b, x2), pl.epilogue(x2, mtr, ls, ts))) for a, b in shares]
     print("world %d shares %s" % (world, shares))
     print("        per rank ms: %s   max %.4f" % (" ".join("%.3f" % v for v in t), max(t)))
+# per-octave times (one share = one decimation octave), for tuning the cost model of tspws_hip_finish_shard
+D = pl.tables()["D"]
+octs = [0] + [s for s in range(1, pl.S) if D[s] != D[s - 1]] + [pl.S]
+print("per octave ms:", " ".join("D=%d:%.3f" % (D[a], timeit(lambda a=a, b=b: pl.stack_finish_scales(mtr, a, b, x2), 20)) for a, b in zip(octs[:-1], octs[1:])))

@@ -2182,7 +2182,7 @@ static bool finish_shardable(const tspws_hip_plan *pl, const t_tsPWS *p, size_t 
 }
 
 // Contiguous, work-balanced share of the scales for `rank` of `world`: whole decimation octaves (the inverse sums the voices
-// of an octave in registers), cost = forward MACs.  Returns 0 with [*s_begin, *s_end) (possibly empty), 1 when this plan /
+// of an octave in registers), cost = weighted forward MACs.  Returns 0 with [*s_begin, *s_end) (possibly empty), 1 when this plan /
 // parameter set has no sharded finish (the caller then finishes as a whole), an error code for bad arguments.
 extern "C" int tspws_hip_finish_shard(const tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, unsigned rank, unsigned world, unsigned *s_begin,
                                       unsigned *s_end)
@@ -2196,7 +2196,13 @@ extern "C" int tspws_hip_finish_shard(const tspws_hip_plan *pl, const t_tsPWS *p
 	double total = 0;
 	for (size_t k = 0; k < items.size(); k++) {
 		double c = 0;
-		for (unsigned s = pl->oc_s0[items[k]]; s < pl->oc_s0[items[k]] + pl->oc_nv[items[k]]; s++) c += (double)pl->sc[s].L * (double)pl->sc[s].Ns;
+		// forward MACs.  Shares of one or two octaves (world >= 4) are latency-bound -- a launch lasts as long as its
+		// longest workgroup -- and the far-decimated octaves then cost about twice as much (tools/shard_finish_timing.py, per
+		// octave on the north-star frame: 13 us above the launch-chain floor for D <= 128, ~30 us for D >= 256); shares of
+		// many octaves (world 2: 0.148 | 0.157 ms for an even split of the MACs) follow the MAC count
+		const double far_w = world >= 4 ? 2.0 : 1.0;
+		for (unsigned s = pl->oc_s0[items[k]]; s < pl->oc_s0[items[k]] + pl->oc_nv[items[k]]; s++)
+			c += (double)pl->sc[s].L * (double)pl->sc[s].Ns * (pl->sc[s].D >= 256 ? far_w : 1.0);
 		cost[k] = c; total += c;
 	}
 	// item k goes to rank floor(world * (cum_before + cost / 2) / total): contiguous, balanced, deterministic on every rank
