@@ -2256,9 +2256,9 @@ extern "C" int tspws_hip_stack_finish_scales(tspws_hip_plan *pl, const t_tsPWS *
 // streaming is HBM-bound, so they overlap), then weight / inverses / epilogue.  Same results as
 // stack_local + stack_finish (same kernels, same summation order).
 // ------------------------------------------------------------------------------------------
-// Measured on MI355X (round 1): co-running slows the streaming kernel by ~15 % and the transforms by 2-3x, so the
-// pipelined schedule (1.19-1.25 ms) does not beat the plain back-to-back one (1.14-1.18 ms) yet; it stays opt-in
-// (TSPWS_OVERLAP=1) until the transform kernels are less memory-latency sensitive.
+// Measured on MI355X (round 2, after the streaming pass went to one workgroup per CU and launch): the transforms now
+// co-run, but the streaming stage slows from 0.73 to 0.80-0.85 ms -- 0.98-1.00 ms per call against 0.99-1.01 ms for the
+// plain back-to-back schedule, within the box-to-box spread.  It stays opt-in (TSPWS_OVERLAP=1); DESIGN.md section 4.
 static bool overlap_enabled()
 {
 	static int v = -1;
