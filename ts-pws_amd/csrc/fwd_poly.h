@@ -227,25 +227,15 @@ __device__ __forceinline__ void valu_reduce_cplx64(const double (&v)[16], const 
 	first = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2;
 }
 
-template <typename TIn, int B>
-__global__ void __launch_bounds__(256) k_fwd_poly(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned N,
-                                                  const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
-                                                  double2 *__restrict__ part, size_t npart, unsigned total_waves, unsigned wid0 = 0)
+// One wave of the direct kernel: R outputs per thread (8, or 16 for the scales flagged r16: 64 phase lanes and at least 16
+// outputs -- one x value and one tap per 2 R FMAs and trace, i.e. half the operand bytes per FMA; the kernel is bound by
+// the L2 operand stream: without the tap loads the call is 10 us shorter), BS tap steps per load block.
+template <typename TIn, int B, int R, int BS>
+__device__ __forceinline__ void fwd_poly_wave(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned N, const ScaleDesc &d,
+                                              const double2 *__restrict__ w, double2 *__restrict__ part, size_t npart, const unsigned wl,
+                                              const unsigned lane)
 {
-	constexpr int R = FWD_R;
-	const unsigned lane = threadIdx.x & 63;
-	// readfirstlane makes the wave index provably uniform: the scale lookup and the whole descriptor then
-	// live in SGPRs (scalar loads, scalar branches) instead of VGPRs.  wid0 / total_waves: the launch's range of the wave list
-	const unsigned wid = wid0 + blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	if (wid >= total_waves) return;
-	// scale of this wave: last s with wave_off[s] <= wid
-	unsigned lo = 0, hi = S;
-	while (hi - lo > 1) {
-		const unsigned mid = (lo + hi) >> 1;
-		if (sc[mid].wave_off <= wid) lo = mid; else hi = mid;
-	}
-	const ScaleDesc d = sc[lo];
-	const unsigned wl = wid - d.wave_off;
+	static_assert(R % BS == 0, "a ring of R window registers is walked in blocks of BS steps");
 	const unsigned split = wl / d.ngw, gb = wl - split * d.ngw;
 	const unsigned lane_m = lane & (d.DL - 1);
 	const unsigned g = gb * (64u / d.DL) + (lane >> d.logDL);
@@ -283,32 +273,39 @@ __global__ void __launch_bounds__(256) k_fwd_poly(const TIn *__restrict__ x, siz
 		}
 		unsigned l = mm;
 		for (unsigned q = 0; q < d.Q; q += R) {
-			// issue every load of the block first (R rows per trace + R taps), then R tap steps of FMAs
-			const unsigned nsteps = d.Q - q; // >= R for a full block
-			double xn[B][R];
-			double2 tp[R];
 #pragma unroll
-			for (int u = 0; u < R; u++) {
+			for (int h = 0; h < R / BS; h++) {
+				if (q + (unsigned)(h * BS) < d.Q) { // wave-uniform
+					// issue every load of the block first (BS rows per trace + BS taps), then BS tap steps of FMAs
+					const unsigned nsteps = d.Q - q - (unsigned)(h * BS); // >= BS for a full block
+					double xn[B][BS];
+					double2 tp[BS];
 #pragma unroll
-				for (int b = 0; b < B; b++) xn[b][u] = (double)xb[b][row];
-				row += Dw; if (row >= N) row -= N;
-				const unsigned lu = l + (unsigned)u * d.D;
-				const bool ok = mvalid && lu < d.L;
-				tp[u] = ws[ok ? lu : 0];
-				if (!ok) tp[u] = make_double2(0.0, 0.0); // taps past the filter end / idle lanes contribute exactly nothing
-			}
+					for (int u = 0; u < BS; u++) {
 #pragma unroll
-			for (int u = 0; u < R; u++) {
-				if ((unsigned)u < nsteps) { // wave-uniform: only the last, partial block skips steps
+						for (int b = 0; b < B; b++) xn[b][u] = (double)xb[b][row];
+						row += Dw; if (row >= N) row -= N;
+						const unsigned lu = l + (unsigned)(h * BS + u) * d.D;
+						const bool ok = mvalid && lu < d.L;
+						tp[u] = ws[ok ? lu : 0];
+						if (!ok) tp[u] = make_double2(0.0, 0.0); // taps past the filter end / idle lanes contribute exactly nothing
+					}
 #pragma unroll
-					for (int b = 0; b < B; b++) xw[b][(u + R - 1) % R] = xn[b][u];
+					for (int u = 0; u < BS; u++) {
+						if ((unsigned)u < nsteps) { // wave-uniform: only the last, partial block skips steps
+							constexpr int dummy = 0; (void)dummy;
+							const int sidx = h * BS + u; // compile-time after unrolling
 #pragma unroll
-					for (int b = 0; b < B; b++)
+							for (int b = 0; b < B; b++) xw[b][(sidx + R - 1) % R] = xn[b][u];
 #pragma unroll
-						for (int r = 0; r < R; r++) {
-							ar[b][r] = fma(xw[b][(u + r) % R], tp[u].x, ar[b][r]);
-							ai[b][r] = fma(xw[b][(u + r) % R], tp[u].y, ai[b][r]);
+							for (int b = 0; b < B; b++)
+#pragma unroll
+								for (int r = 0; r < R; r++) {
+									ar[b][r] = fma(xw[b][(sidx + r) % R], tp[u].x, ar[b][r]);
+									ai[b][r] = fma(xw[b][(sidx + r) % R], tp[u].y, ai[b][r]);
+								}
 						}
+					}
 				}
 			}
 			l += (unsigned)R * d.D;
@@ -320,18 +317,22 @@ __global__ void __launch_bounds__(256) k_fwd_poly(const TIn *__restrict__ x, siz
 		const unsigned o = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
 #pragma unroll
 		for (int b = 0; b < B; b++) {
-			double v16[16];
 #pragma unroll
-			for (int r = 0; r < R; r++) { v16[2 * r] = ar[b][r]; v16[2 * r + 1] = ai[b][r]; }
-			const double sum = valu_reduce16(v16, lane);
-			const unsigned t = blockIdx.y * B + b, k = k0 + (o >> 1);
-			if ((lane & 3) == 0 && t < ntr && k < d.Ns) {
-				double *dst = (double *)(part + (size_t)t * npart + d.part_off + (size_t)split * d.Ns);
-				dst[(size_t)k * 2 + (o & 1)] = (o & 1) ? -sum : sum; // conj
+			for (int half = 0; half < R / 8; half++) { // 16 values (8 complex outputs) per reduction
+				double v16[16];
+#pragma unroll
+				for (int r = 0; r < 8; r++) { v16[2 * r] = ar[b][half * 8 + r]; v16[2 * r + 1] = ai[b][half * 8 + r]; }
+				const double sum = valu_reduce16(v16, lane);
+				const unsigned t = blockIdx.y * B + b, k = k0 + (unsigned)(half * 8) + (o >> 1);
+				if ((lane & 3) == 0 && t < ntr && k < d.Ns) {
+					double *dst = (double *)(part + (size_t)t * npart + d.part_off + (size_t)split * d.Ns);
+					dst[(size_t)k * 2 + (o & 1)] = (o & 1) ? -sum : sum; // conj
+				}
 			}
 		}
 		return;
 	}
+	if constexpr (R == 8) {
 	// fewer than 64 phase lanes per group: shuffle reduce-scatter over lane bits 0..logDL-1
 	constexpr int NV = 2 * B * R;
 	double v[NV];
@@ -366,6 +367,28 @@ __global__ void __launch_bounds__(256) k_fwd_poly(const TIn *__restrict__ x, siz
 			}
 		}
 	}
+	} // R == 8 (scales with fewer than 64 phase lanes are never flagged r16)
+}
+
+template <typename TIn, int B>
+__global__ void __launch_bounds__(256) k_fwd_poly(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned N,
+                                                  const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
+                                                  double2 *__restrict__ part, size_t npart, unsigned total_waves, unsigned wid0 = 0)
+{
+	const unsigned lane = threadIdx.x & 63;
+	// readfirstlane makes the wave index provably uniform: the scale lookup and the whole descriptor then
+	// live in SGPRs (scalar loads, scalar branches) instead of VGPRs.  wid0 / total_waves: the launch's range of the wave list
+	const unsigned wid = wid0 + blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	if (wid >= total_waves) return;
+	// scale of this wave: last s with wave_off[s] <= wid
+	unsigned lo = 0, hi = S;
+	while (hi - lo > 1) {
+		const unsigned mid = (lo + hi) >> 1;
+		if (sc[mid].wave_off <= wid) lo = mid; else hi = mid;
+	}
+	const ScaleDesc d = sc[lo];
+	if (d.r16) fwd_poly_wave<TIn, B, 16, 4>(x, ld, ntr, N, d, w, part, npart, wid - d.wave_off, lane);
+	else fwd_poly_wave<TIn, B, FWD_R, FWD_R>(x, ld, ntr, N, d, w, part, npart, wid - d.wave_off, lane);
 }
 
 // PS += Y/|Y| unless the quotient is not a unit phasor (Y == 0 gives NaN and is skipped), ts_pws1f_lib.c:491-492.

@@ -67,7 +67,8 @@ struct ScaleDesc {
 	unsigned lds_off, lds_bps;  // first workgroup of this scale in k_fwd_lds, workgroups per split
 	unsigned acc2_off;          // first block of this scale in k_accumulate_parts (32 coefficients per block when split)
 	unsigned fuse_ok;           // 1: k_fwd_lds<FUSE> keeps this scale's linear / phase stacks in registers (no partials)
-	unsigned use_oct, pad2;     // 1: forward transform by k_fwd_oct (fwd_oct.h) together with the other voices of its octave
+	unsigned use_oct;           // 1: forward transform by k_fwd_oct (fwd_oct.h) together with the other voices of its octave
+	unsigned r16;               // 1: the direct kernel gives a thread 16 outputs of this scale (ngw counts 16-output groups)
 	unsigned long long part_off; // offset of this scale's [nsplit][Ns] partial block
 };
 
@@ -496,7 +497,7 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 			const unsigned NG = (d.Ns + R - 1) / R;
 			const bool pow2 = (d.D & (d.D - 1)) == 0;
 			d.use_lds = (kind != 0 && NG >= 8 && (d.D >= 64 || pow2)) ? 1u : 0u;
-			d.use_oct = 0; d.pad2 = 0;
+			d.use_oct = 0; d.r16 = 0;
 		}
 		// pass 2: octaves with D >= 64 whose voices all qualify go to the octave-fused kernel (one x window for all voices)
 		std::vector<char> is_oct(S, 0);
@@ -509,6 +510,10 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 			const unsigned NG = (d.Ns + R - 1) / R, GW = 64 / d.DL;
 			d.ngw = (NG + GW - 1) / GW;
 			if (is_oct[s]) { d.use_oct = 1; d.use_lds = 0; }
+			// direct kernel, 64 phase lanes, at least 16 outputs: 16 outputs per thread (half the operand bytes per FMA)
+			static int r16_on = -1;
+			if (r16_on < 0) { const char *e = getenv("TSPWS_POLY_R16"); r16_on = (e && *e == '0') ? 0 : 1; }
+			if (r16_on && kind != 3 && !d.use_lds && !d.use_oct && d.DL == 64 && d.Ns >= 16) { d.r16 = 1; d.ngw = (d.Ns + 15) / 16; }
 			unsigned cps;
 			if (d.use_lds || d.use_oct) cps = 1; // one 64-phase chunk per workgroup: its taps stay resident in LDS
 			else cps = std::max(1u, (FWD_STEPS + d.Q / 2) / std::max(1u, d.Q));
