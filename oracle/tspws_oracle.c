@@ -528,6 +528,9 @@ int orc_tspws_main(t_tsPWS *p, t_tsPWS_out *out, t_data *in)
 	}
 	if (!mtr) { orc_frame_destroy(f); return 0; }
 	if (!f) return 4;
+	/* a family without scales (J resolved to 0: fmin above the first scale) fails CheckWaveletFamily
+	 * (FWTa/wavelet_mem_v7.c:40-45: Ns <= 0), the container is NULL and the call returns 4 (:199-204) -- after fold / rm */
+	if (f->S == 0) { printf("Error: The waveletFamily variable is not nice.\n"); orc_frame_destroy(f); return 4; }
 
 	const size_t nc = orc_frame_ncoef(f);
 	cplx *Y = malloc(nc * sizeof(cplx)), *ST = calloc(nc, sizeof(cplx)), *PS = calloc(nc, sizeof(cplx));
@@ -752,6 +755,7 @@ int orc_tspws_main_mt(t_tsPWS *p, t_tsPWS_out *out, t_data *in)
 	orc_frame *f = orc_frame_create(p->type, p->J, p->V, (unsigned)max, p->s0, p->b0, p->w0, (int)p->uni);
 	if (!f) return 4;
 	if (!mtr) { orc_frame_destroy(f); return 0; }
+	if (f->S == 0) { orc_frame_destroy(f); return 4; } /* no scales: see orc_tspws_main */
 	const size_t nc = orc_frame_ncoef(f);
 	const int two_stage = !(!p->Kmax || p->Kmax > mtr);
 	const unsigned K = two_stage ? p->Kmax : (unsigned)mtr;

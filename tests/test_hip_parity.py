@@ -871,9 +871,9 @@ def test_random_parameter_sets_vs_oracle(lib, seed):
             assert getattr(a["params"], f) == getattr(b["params"], f), tag
         for f in ("s0", "b0", "w0"):
             assert getattr(a["params"], f) == getattr(b["params"], f), tag
+        np.testing.assert_array_equal(a["sigall"], b["sigall"], err_msg=tag)   # (also when the call fails: fold / rm come first)
         if a["rc"]:
             continue
-        np.testing.assert_array_equal(a["sigall"], b["sigall"], err_msg=tag)
         assert abi.relerr(a["ls"], b["ls"]) < TOL32, tag
         assert abi.relerr(a["tsPWS"], b["tsPWS"]) < TOL32, tag
 
@@ -968,3 +968,25 @@ def test_two_processes_share_the_gpu_over_gloo(lib, torch, tmp_path, monkeypatch
     for r in range(world):
         assert abi.relerr(np.load(tmp_path / f"ls{r}.npy"), ls.cpu().numpy()) < 1e-6
         assert abi.relerr(np.load(tmp_path / f"ts{r}.npy"), ts.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_frame_without_scales_fails_like_the_reference(lib):
+    """fmin above the first scale resolves J to 0: the reference's coefficient containers cannot be created and tspws_main
+    returns 4 (FWTa/wavelet_mem_v7.c:40-45, ts_pws1f_lib.c:199-204) -- after fold / mean removal have rewritten the
+    traces.  Found by tools/random_sweep.py (the oracle used to return 0 here)."""
+    kw = dict(type=-3, s0=4.823433067845736, fmin=0.04796741189352445, wu=1.5, Kmax=12, lrm=1)
+    X = abi.synth_traces(9, 1000, seed=3) + np.float32(0.25)
+    p = abi.default_params(**kw)
+    a = abi.run_main(lib.tspws_main, p, X)
+    b = abi.run_main(abi.oracle().orc_tspws_main, p, X)
+    assert a["params"].J == 0 and b["params"].J == 0
+    assert a["rc"] == 4 and b["rc"] == 4
+    np.testing.assert_array_equal(a["sigall"], b["sigall"])
+    assert not np.array_equal(a["sigall"], X)           # the mean WAS removed
+    assert not a["ls"].any() and not a["tsPWS"].any()   # outputs untouched
+    ref = abi.ref()
+    if ref is not None:
+        r = abi.run_main(ref.tspws_main, p, X)
+        assert r["rc"] == 4
+        np.testing.assert_array_equal(a["sigall"], r["sigall"])

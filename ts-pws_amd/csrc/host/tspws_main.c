@@ -83,15 +83,17 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 
 	if (!mtr) return 0; /* the reference builds the family and returns 0 without touching out (:194) */
 
-	rc = tspws_hip_plan_create(&plan, tspws->type, tspws->J, tspws->V, nsamp, tspws->s0, tspws->b0, tspws->w0, (int)tspws->uni, dev);
-	if (rc) {
+	int frame_rc = tspws_hip_plan_create(&plan, tspws->type, tspws->J, tspws->V, nsamp, tspws->s0, tspws->b0, tspws->w0, (int)tspws->uni, dev);
+	if (frame_rc) {
 		printf("tspws_main: cannot build the wavelet frame (%s)\n", tspws_hip_last_error());
-		/* CreateWaveletFamily failure surfaces as 4 in the reference (container creation fails, :199-204) */
-		return rc == TSPWS_E_NODEV ? rc : TSPWS_E_NOMEM;
+		if (frame_rc == TSPWS_E_NODEV) return frame_rc;
+		/* A frame that cannot be built (e.g. J resolved to 0: fmin above the first scale) surfaces as 4 in the reference,
+		 * when the coefficient containers are created (:199-204) -- i.e. AFTER fold and mean removal have rewritten
+		 * sigall (:71-88, :159-169): the prologue below still runs, then the call returns 4. */
+		if (!do_fold && !tspws->lrm) return TSPWS_E_NOMEM;
 	}
 
 	TRY(tspws_hip_alloc((void **)&d_sig, mtr * ld * sizeof(float), dev));
-	TRY(tspws_hip_alloc((void **)&d_out, 2 * ld * sizeof(float), dev));
 	TRY(tspws_hip_upload(d_sig, in->sigall, mtr * ld * sizeof(float), NULL));
 
 	/* in-place prologue on the device, then mirrored back: the caller sees the same mutated
@@ -99,6 +101,8 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 	if (do_fold) TRY(tspws_hip_fold(d_sig, mtr, (size_t)max, ld, NULL));
 	if (tspws->lrm) TRY(tspws_hip_remove_mean(d_sig, mtr, (size_t)max, ld, NULL));
 	if (do_fold || tspws->lrm) TRY(tspws_hip_download(in->sigall, d_sig, mtr * ld * sizeof(float), NULL));
+	if (frame_rc) { tspws_hip_free(d_sig); return TSPWS_E_NOMEM; }
+	TRY(tspws_hip_alloc((void **)&d_out, 2 * ld * sizeof(float), dev));
 
 	/* jackknife masks first (host, :385-430): announced to the engine, the stack below streams the traces once for its own
 	 * groups and for every replica */
