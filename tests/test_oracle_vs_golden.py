@@ -153,3 +153,21 @@ def test_parallel_restatement_is_bit_identical():
         b = abi.run_main(abi.oracle().orc_tspws_main_mt, p, X)
         np.testing.assert_array_equal(a["ls"], b["ls"])
         np.testing.assert_array_equal(a["tsPWS"], b["tsPWS"])
+
+
+def test_empty_frame_returns_4_like_the_reference():
+    """J resolved to 0 (fmin above the first scale): no scales -> CheckWaveletFamily fails (FWTa/wavelet_mem_v7.c:40-45), the
+    coefficient containers are NULL and tspws_main returns 4 (ts_pws1f_lib.c:199-204), after fold / rm rewrote the traces.
+    Known answer from the reference build: rc 4, outputs untouched; compared live when oracle/_ref is present."""
+    kw = dict(type=-3, s0=4.823433067845736, fmin=0.04796741189352445, wu=1.5, Kmax=12, lrm=1)
+    X = abi.synth_traces(9, 1000, seed=3) + np.float32(0.25)
+    p = abi.default_params(**kw)
+    b = abi.run_main(abi.oracle().orc_tspws_main, p, X)
+    assert b["params"].J == 0 and b["rc"] == 4
+    assert not b["ls"].any() and not b["tsPWS"].any()
+    assert not np.array_equal(b["sigall"], X)   # the mean was removed before the failure
+    ref = abi.ref()
+    if ref is not None:
+        r = abi.run_main(ref.tspws_main, p, X)
+        assert r["rc"] == 4 and r["params"].J == 0
+        np.testing.assert_array_equal(b["sigall"], r["sigall"])
