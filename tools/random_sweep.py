@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Extended seeded sweep over the parameter grammar (tests/test_hip_parity.py::_random_case, 360 cases): tspws_main of this
-engine against the oracle -- return codes, resolved parameters, mutated traces, both outputs.  usage: random_sweep.py"""
+engine against the oracle -- return codes, resolved parameters, mutated traces, both outputs.  usage: random_sweep.py [first_seed [n_seeds]]"""
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, importlib, abi
 import test_hip_parity as T
 tspws = importlib.import_module("ts-pws_amd"); lib = tspws.load()
 bad = 0; n = 0
-for seed in range(8, 68):
+_a = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+_n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+for seed in range(_a, _a + _n):
     rng = np.random.default_rng(1000 + seed)
     for it in range(6):
         kw, N, mtr, beg = T._random_case(rng)
