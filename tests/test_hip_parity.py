@@ -950,13 +950,13 @@ def _gpu_shard_worker(rank, world, port, kw, mtr, N, out_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shard_finish", ["1", "0"])
-def test_two_processes_share_the_gpu_over_gloo(lib, torch, tmp_path, monkeypatch, shard_finish):
+@pytest.mark.parametrize("shard_finish,world", [("1", 2), ("0", 2), ("1", 5)])
+def test_two_processes_share_the_gpu_over_gloo(lib, torch, tmp_path, monkeypatch, shard_finish, world):
     """The multi-GPU orchestration (stack_sharded: two-piece streaming + reductions, scale-sharded or redundant finish) with
     the real engine: two processes on this GPU, gloo as the collective.  Every rank must end with the one-process outputs."""
     import socket
     import torch.multiprocessing as mp
-    kw, mtr, N, world = dict(Kmax=10, unbiased=1), 200, 16384, 2
+    kw, mtr, N = dict(Kmax=10, unbiased=1), 203, 16384   # (203 traces: ragged shards; five ranks: shares of 2-3 octaves)
     monkeypatch.setenv("TSPWS_SHARD_FINISH", shard_finish)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
