@@ -990,3 +990,45 @@ def test_frame_without_scales_fails_like_the_reference(lib):
         r = abi.run_main(ref.tspws_main, p, X)
         assert r["rc"] == 4
         np.testing.assert_array_equal(a["sigall"], r["sigall"])
+
+
+def _gpu_jk_worker(rank, world, port, kw, mtr, N, out_dir):
+    import torch as th
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = tspws.resolve(abi.default_params(**kw), N)
+        pl = tspws.Plan(p, N)
+        Cn = abi.binomial(p.jackknife_n, p.jackknife_d)
+        times = (1262304000 + 86400 * np.sort(np.random.default_rng(4).integers(0, 2 * 365, mtr))).astype(np.int64)
+        sel = np.zeros((Cn, mtr), np.int8)
+        assert tspws.load().tspws_jackknife_plan(sel.ctypes.data, times.ctypes.data, mtr, p.jackknife_d, p.jackknife_n, Cn) == 0
+        first, count = tspws.shard_range(mtr, rank, world)
+        X = tspws.synth(count, N, seed=41, first=first)
+        ls, ts, jl, jt, jm = tspws.jackknife_sharded(pl, X, sel, first, mtr)
+        th.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"jk{rank}.npz"), ls=ls.cpu().numpy(), ts=ts.cpu().numpy(), jl=jl.cpu().numpy(), jt=jt.cpu().numpy(), jm=jm)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_jackknife_three_processes_over_gloo(lib, torch, tmp_path):
+    """jackknife_sharded with the real engine: three processes on this GPU (gloo as the collective), six replicas -> two per
+    rank; every rank must end with the oracle's main stack and replicas."""
+    import socket
+    import torch.multiprocessing as mp
+    kw, mtr, N, world = dict(Kmax=4, unbiased=1, jackknife_n=4, jackknife_d=2), 151, 4096, 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_gpu_jk_worker, args=(world, port, kw, mtr, N, str(tmp_path)), nprocs=world, join=True)
+    times = (1262304000 + 86400 * np.sort(np.random.default_rng(4).integers(0, 2 * 365, mtr))).astype(np.int64)
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), tspws.synth(mtr, N, seed=41).cpu().numpy(), times=times)
+    for r in range(world):
+        got = np.load(tmp_path / f"jk{r}.npz")
+        np.testing.assert_array_equal(got["jm"], want["jk_mtr"])
+        assert abi.relerr(got["ls"], want["ls"]) < TOL32 and abi.relerr(got["ts"], want["tsPWS"]) < TOL32
+        for c in range(len(want["jk_mtr"])):
+            assert abi.relerr(got["jl"][c], want["jk_ls"][c]) < TOL32 and abi.relerr(got["jt"][c], want["jk_ts"][c]) < TOL32
