@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- stacked samples/s of the ts-PWS hot path on MI355X.
 
-Workload (BASELINE.json `metric`: "Morlet ts-PWS, 10k x 131072", configs[2]): per GPU 10 000
-synthetic traces x 131 072 samples, default Morlet frame (V=4, J=14, 56 scales), two-stage stack
-with 10 groups + unbiased phase coherence.  One step = one whole tspws_main-equivalent call on
-HBM-resident traces: partial stacks -> (all-reduce when N>1) -> 10 forward frame CWTs + phase
-stack -> weight -> 2 inverse CWTs -> float outputs.  Weak scaling: every rank holds its own
-10 000-trace shard of a (N x 10 000)-trace ensemble (configs[4] at N=8 is 80k of its 100k).
+Workload (BASELINE.json `metric`: "Morlet ts-PWS, 10k x 131072", configs[2]): per GPU 10 000 synthetic traces x 131 072
+samples, default Morlet frame (V=4, J=14, 56 scales), two-stage stack with 10 groups + unbiased phase coherence.  One step =
+one whole tspws_main-equivalent call on HBM-resident traces: partial stacks -> (all-reduce when N>1) -> 10 forward frame
+CWTs + phase stack -> weight -> 2 inverse CWTs -> float outputs.  Weak scaling: every rank holds its own shard of an
+(N x traces)-trace ensemble.  `--config cfg5` is BASELINE configs[4]: 12 500 traces per GPU (100 000 at N=8).
 
-Prints ONE JSON line (see the driver contract); N=1 adds the CPU baseline timed on this host.
+    python bench.py                         one GPU: headline line + roofline + CPU baseline + the other configs
+    python bench.py --gpus 8                starts its own 8 ranks (torch.distributed.run, one per GPU, RCCL) -- no GPU call
+                                            is made in the parent; under an external torchrun (WORLD_SIZE set) it just runs
+    python bench.py --gpus 8 --config cfg5  BASELINE configs[4]
+
+Prints ONE JSON line (the driver contract).  N=1 adds: `cpu_baseline` (the reference OpenMP path on this host),
+`end_to_end_host_path` (the drop-in tspws_main on host buffers, PCIe included) and `other_configs` (cfg2 single-stage,
+cfg4 Mexican hat + jackknife, each with its roofline fraction and its error against the reference on a bounded sub-batch).
 """
 import argparse
 import ctypes as C
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,20 +30,65 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (same guide); ~62 TFLOP/s is what a dense v_fma_f64 stream sustains
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--traces", type=int, default=10000, help="traces per GPU")
+    ap.add_argument("--config", choices=["cfg3", "cfg5"], default="cfg3",
+                    help="cfg3: 10 000 traces per GPU (BASELINE configs[2], the metric's config); cfg5: 12 500 per GPU (configs[4]: 100k over 8)")
+    ap.add_argument("--traces", type=int, default=None, help="traces per GPU (overrides --config)")
     ap.add_argument("--samples", type=int, default=131072)
     ap.add_argument("--kmax", type=int, default=10)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    args = ap.parse_args()
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline, host-path and other-config legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip the host-path and other-config legs only")
+    return ap.parse_args()
 
+
+def self_launch(args):
+    """--gpus N without a launcher around us: start N ranks (one per GPU) BEFORE anything touches the GPU in this process,
+    pass their rank-0 JSON line through and exit with their code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver)
+    env["BENCH_SELF_LAUNCHED"] = "1"
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in out.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if line is not None:
+        print(line)
+    return out.returncode if out.returncode else (0 if line is not None else 1)
+
+
+def main():
+    args = parse()
+    world_env = int(os.environ.get("WORLD_SIZE", "1") or 1)
+    if args.gpus > 1 and world_env != args.gpus:
+        if os.environ.get("BENCH_SELF_LAUNCHED"):
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env} inside the launcher")
+        sys.exit(self_launch(args))
+    run(args)
+
+
+def stats(v):
+    import numpy as np
+    v = np.asarray(v, dtype=np.float64)
+    return {"median": float(np.median(v)), "min": float(v.min()), "max": float(v.max()), "mean": float(v.mean()), "n": int(v.size)} if v.size else None
+
+
+def run(args):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -56,7 +109,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    mtr_local, N, K = args.traces, args.samples, args.kmax
+    mtr_local = args.traces if args.traces is not None else (12500 if args.config == "cfg5" else 10000)
+    N, K = args.samples, args.kmax
     mtr_global = mtr_local * world
     first = rank * mtr_local
     params = tspws.resolve(abi.default_params(Kmax=K, unbiased=1), N)
@@ -66,64 +120,69 @@ def main():
     t_plan = time.perf_counter() - t_plan
     X = tspws.synth(mtr_local, N, seed=1, first=first, device=local)
     lib = tspws.load()
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     ls = torch.empty(N, dtype=torch.float32, device=X.device)
     ts = torch.empty(N, dtype=torch.float32, device=X.device)
     red = plan.reduce_buffer(mtr_global)
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     single = world == 1
-    # N > 1: share of the scales this rank finishes (None: plan without a sharded finish, or TSPWS_SHARD_FINISH=0)
-    shard = None
-    if world > 1 and os.environ.get("TSPWS_SHARD_FINISH", "1") != "0":
-        shard = plan.finish_shard(mtr_global, rank, world)
+    # N > 1: share of the scales this rank finishes (None: no sharded finish -- agreed across the ranks)
+    shard = tspws._finish_shard(plan, mtr_global) if world > 1 else None
     x2 = torch.empty(2 * N, dtype=torch.float64, device=X.device)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    launches = [0]
 
-    def step(i=None):
+    def piece(g0, g1, count):
+        plan.partial_stacks_range(X, first, mtr_global, g0, g1)
+        if count:
+            launches[0] += lib.tspws_hip_stream_launches(plan.h)
+
+    def step(i=None, count=False):
         if single:
-            # one GPU: tspws_hip_stack = stack_local + stack_finish in one C call (optionally pipelined with
-            # TSPWS_OVERLAP=1); HIP events inside the library bracket the streaming stage on the launch stream
+            # one GPU: tspws_hip_stack = stack_local + stack_finish in one C call; HIP events inside the library bracket the
+            # call and its streaming stage on the launch stream
             plan.stack_single(X, ls, ts)
             return
-        # N > 1: the streaming stage in two halves of the groups; the all-reduce of the first half (RCCL, its own
-        # stream) overlaps the streaming of the second -- one logical fp64 reduction of P[Kmax][N] (ts-pws_amd.stack_sharded)
+        # N > 1: the streaming stage in two pieces of the groups; the all-reduce of the first piece (RCCL, its own stream)
+        # overlaps the streaming of the second -- one logical fp64 reduction of P[Kmax][N] (ts-pws_amd.stack_sharded)
         half = tspws.split_groups(K, shard is not None)
         buf = red.view(K, N)
         if i is not None:
             ev[i][0].record()
         if half == 0:  # a single group: nothing to overlap
-            plan.partial_stacks_range(X, first, mtr_global, 0, K)
+            piece(0, K, count)
             if i is not None:
                 ev[i][1].record()
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
             plan.stack_finish(mtr_global, ls, ts)
-            return
-        plan.partial_stacks_range(X, first, mtr_global, 0, half)
-        w1 = dist.all_reduce(buf[:half], op=dist.ReduceOp.SUM, async_op=True)
-        plan.partial_stacks_range(X, first, mtr_global, half, K)
+        else:
+            piece(0, half, count)
+            w1 = dist.all_reduce(buf[:half], op=dist.ReduceOp.SUM, async_op=True)
+            piece(half, K, count)
+            if i is not None:
+                ev[i][1].record()
+            w2 = dist.all_reduce(buf[half:], op=dist.ReduceOp.SUM, async_op=True)
+            if shard is not None:
+                # scale-sharded finish: this rank transforms / weights / reconstructs its share of the scales only; the ranks
+                # add their partial reconstructions (2 N doubles) and every rank ends with the outputs
+                w1.wait()
+                w2.wait()
+                plan.stack_finish_scales(mtr_global, shard[0], shard[1], x2)
+                dist.all_reduce(x2, op=dist.ReduceOp.SUM)
+                plan.epilogue(x2, mtr_global, ls, ts)
+            else:
+                w1.wait()
+                plan.stack_finish_range(mtr_global, 0, half)   # transforms of the reduced half run beside the second reduction
+                w2.wait()
+                plan.stack_finish_range(mtr_global, half, K)
+                plan.stack_finish_tail(mtr_global, ls, ts)
         if i is not None:
-            ev[i][1].record()
-        w2 = dist.all_reduce(buf[half:], op=dist.ReduceOp.SUM, async_op=True)
-        if shard is not None:
-            # scale-sharded finish: this rank transforms / weights / reconstructs its share of the scales only; the ranks add
-            # their partial reconstructions (2 N doubles) and every rank ends with the outputs (ts-pws_amd.stack_sharded)
-            w1.wait()
-            w2.wait()
-            plan.stack_finish_scales(mtr_global, shard[0], shard[1], x2)
-            dist.all_reduce(x2, op=dist.ReduceOp.SUM)
-            plan.epilogue(x2, mtr_global, ls, ts)
-            return
-        w1.wait()
-        plan.stack_finish_range(mtr_global, 0, half)   # transforms of the reduced half run beside the second reduction
-        w2.wait()
-        plan.stack_finish_range(mtr_global, half, K)
-        plan.stack_finish_tail(mtr_global, ls, ts)
+            ev[i][2].record()
 
-    for _ in range(args.warmup):
-        step()
+    for w in range(max(1, args.warmup)):
+        step(count=(w == 0))
     torch.cuda.synchronize()
     if single:
-        tspws.check(lib.tspws_hip_profile_begin(plan.h, args.steps), "profile_begin")
+        plan.profile_begin(args.steps)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -141,21 +200,15 @@ def main():
         dt = float(t.item())
 
     if single:
-        ms, nc = C.c_double(), C.c_size_t()
-        tspws.check(lib.tspws_hip_profile_end(plan.h, C.byref(ms), C.byref(nc)), "profile_end")
-        stream_ms = ms.value
+        stage_ms, call_ms = plan.profile_read()
+        nlaunch = max(1, lib.tspws_hip_stream_launches(plan.h))
     else:
-        stream_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+        stage_ms = np.array([e[0].elapsed_time(e[1]) for e in ev])
+        call_ms = np.array([e[0].elapsed_time(e[2]) for e in ev])
+        nlaunch = max(1, launches[0])
+    stream_ms = float(np.mean(stage_ms))
     alg_bytes = 4.0 * mtr_local * N + 8.0 * K * N   # read every float32 sample once + write the K fp64 partials
     achieved = alg_bytes / (stream_ms * 1e-3) / 1e9
-    # the streaming stage is a few back-to-back k_partial launches (two groups each at this size: one workgroup per CU);
-    # the per-launch figures are the stage's figures divided by the number of launches of the last call
-    if single:
-        nlaunch = max(1, lib.tspws_hip_stream_launches(plan.h))
-    else:  # two pieces (split_groups), each launched two groups at a time; the library reports the last piece only
-        h = tspws.split_groups(K, shard is not None)
-        rpl = max(1, 256 // max(1, -(-N // 1024)))
-        nlaunch = (-(-h // rpl) if h else 0) + -(-(K - h) // rpl)
     traffic = None
     tf = os.path.join(ROOT, "profiles", "pmc_partial_stacks.json")
     if os.path.exists(tf) and (mtr_local, N, K) == (10000, 131072, 10):  # the PMC record is for this exact launch shape
@@ -165,6 +218,16 @@ def main():
         except Exception:
             traffic = None
 
+    which = ("BASELINE configs[4]: 100k traces over 8 GPUs" if (mtr_local == 12500) else
+             "BASELINE configs[2]" if (mtr_local, N, K) == (10000, 131072, 10) else "custom size")
+    if shard is not None:
+        par = (f"trace-sharded x{world}: fp64 all-reduce of P[K][N] in two pieces (the first, K-2 groups, overlaps the streaming of the last two), then a "
+               f"scale-sharded finish stage: every rank transforms / weights / reconstructs its share of the scales, all-reduce of the 2 N partial reconstructions")
+    elif world > 1:
+        par = (f"trace-sharded x{world}, fp64 all-reduce of P[K][N] in two halves: the first overlaps the streaming of the second, the second the "
+               f"transforms of the first; every rank finishes redundantly")
+    else:
+        par = "one GPU: no collective"
     res = {
         "metric": baseline_metric(),
         "value": mtr_global * N * args.steps / dt,
@@ -174,26 +237,41 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{mtr_local} traces/GPU x {N} samples, Morlet w0=pi*sqrt(2/ln2) V=4 J={params.J}, "
-                               f"two-stage K={K} + unbiased phase coherence (BASELINE configs[2]); HBM-resident float32 traces",
-                   "traces_total": mtr_global, "plan_create_ms": round(t_plan * 1e3, 3), "parallelism": (f"trace-sharded x{world}: fp64 all-reduce of P[K][N] in two pieces (the first, K-2 groups, overlaps the streaming of the last two), then a "
-                                   f"scale-sharded finish stage: every rank transforms / weights / reconstructs its share of the scales, all-reduce of the 2 N partial "
-                                   f"reconstructions" if shard is not None else
-                                   f"trace-sharded x{world}, fp64 all-reduce of P[K][N] in two halves: the first overlaps the streaming of the second, the second the "
-                                   f"transforms of the first; every rank finishes redundantly")},
+                               f"two-stage K={K} + unbiased phase coherence ({which}); HBM-resident float32 traces",
+                   "traces_total": mtr_global, "traces_per_gpu": mtr_local, "plan_create_ms": round(t_plan * 1e3, 3), "parallelism": par,
+                   "world_size": dist.get_world_size() if world > 1 else 1, "backend": (backend if world > 1 else None),
+                   "rccl_version": rccl_version(torch) if (world > 1 and backend == "nccl") else None},
+        "step_ms_gpu": stats(call_ms),   # per call, HIP events on the launch stream (rank 0): median / min / max over the timed steps
         "roofline": {"bound": "hbm", "kernel": "k_partial", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes / nlaunch, "ms_per_launch": stream_ms / nlaunch, "launches_per_call": nlaunch,
+                     "stage_ms": stats(stage_ms),
                      "note": "HIP events on the launch stream around the streaming stage of every timed call: back-to-back k_partial "
-                             "launches of two groups each (one workgroup per CU), every group written directly; per-launch = stage / launches"},
+                             "launches (one workgroup per CU), every group written directly; per-launch = stage / launches"},
         "whole_call_frac_of_hbm_roofline": (alg_bytes / (dt / args.steps) / 1e9) / HBM_PEAK_GBS,
     }
 
-    if world == 1 and rank == 0 and not args.no_cpu:
-        res["cpu_baseline"] = cpu_baseline(abi, X, params_in=abi.default_params(Kmax=K, unbiased=1), ls=ls, ts=ts, N=N, mtr=mtr_local)
+    if world == 1 and rank == 0:
+        res["with_output_d2h"] = with_d2h(torch, plan, X, ls, ts, N, mtr_local, args.steps)
+        if not args.no_cpu:
+            Xh = X.cpu().numpy()
+            res["cpu_baseline"], ref_out = cpu_baseline(abi, Xh, abi.default_params(Kmax=K, unbiased=1), ls, ts, N, mtr_local)
+            if not args.no_extra:
+                res["end_to_end_host_path"] = host_path(abi, lib, Xh, abi.default_params(Kmax=K, unbiased=1), N, mtr_local, ref_out,
+                                                        res["cpu_baseline"].get("seconds"))
+                del Xh
+                res["other_configs"] = other_configs(abi, tspws, lib, torch, X, N)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def rccl_version(torch):
+    try:
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        return None
 
 
 def baseline_metric():
@@ -201,52 +279,170 @@ def baseline_metric():
     try:
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except Exception:
-        return "stacked samples/s (Morlet ts-PWS, 10k\u00d7131072) + % HBM roofline, 1/2/4/8 GPU"
+        return "stacked samples/s (Morlet ts-PWS, 10k×131072) + % HBM roofline, 1/2/4/8 GPU"
 
 
-def cpu_baseline(abi, X, params_in, ls, ts, N, mtr):
-    """Time the CPU path on this host on the SAME traces: the reference itself when oracle/_ref
-    was built (kind "reference"), else this repo's restatement (kind "port").  Bounded sample:
-    at most 10 000 traces (the reference needs ~3 s for them on an 8-core Xeon)."""
+def with_d2h(torch, plan, X, ls, ts, N, mtr, steps):
+    """SURVEY 8d's protocol also moves the two float outputs to the host inside the step: the same loop with both copies
+    (pinned buffers, same stream) after every call.  A labelled second figure -- `value` stays the HBM-resident rate."""
+    hl = torch.empty(N, dtype=torch.float32).pin_memory()
+    ht = torch.empty(N, dtype=torch.float32).pin_memory()
+    for _ in range(2):
+        plan.stack_single(X, ls, ts)
+        hl.copy_(ls, non_blocking=True)
+        ht.copy_(ts, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.stack_single(X, ls, ts)
+        hl.copy_(ls, non_blocking=True)
+        ht.copy_(ts, non_blocking=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"ms_per_step": dt * 1e3, "value": mtr * N / dt, "unit": "samples/s", "note": "each step ends with the D2H copies of ls and tsPWS (2 x N floats)"}
+
+
+def call_main(abi, fn, params_in, Xh, N, mtr, times=None, C_rep=0):
+    """One tspws_main-shaped call on host traces WITHOUT copying them (the call may rewrite them: fold / rm are off here)."""
     import numpy as np
-    ref = abi.ref()
-    fn, kind = (ref.tspws_main, "reference") if ref is not None else (abi.oracle().orc_tspws_main, "port")
-    n = min(mtr, 10000)
-    Xh = X[:n].cpu().numpy()
-    import ctypes as C
-    x = Xh  # run_main copies; avoid a second 5 GB copy by calling directly
     p = abi.t_tsPWS.from_buffer_copy(params_in)
     out = abi.t_tsPWS_out()
     l = np.zeros(N, np.float32)
     t = np.zeros(N, np.float32)
-    out.ls = l.ctypes.data_as(C.POINTER(C.c_float))
-    out.tsPWS = t.ctypes.data_as(C.POINTER(C.c_float))
+    fp = C.POINTER(C.c_float)
+    out.ls, out.tsPWS = l.ctypes.data_as(fp), t.ctypes.data_as(fp)
+    out.N, out.mtr = N, mtr
+    keep = []
+    jl = jt = jm = None
+    if C_rep:
+        jl, jt, jm = np.zeros((C_rep, N), np.float32), np.zeros((C_rep, N), np.float32), np.zeros(C_rep, np.uint32)
+        rows_l = (fp * C_rep)(*[jl[c].ctypes.data_as(fp) for c in range(C_rep)])
+        rows_t = (fp * C_rep)(*[jt[c].ctypes.data_as(fp) for c in range(C_rep)])
+        keep += [rows_l, rows_t]
+        out.ls_subsmpl, out.tsPWS_subsmpl = C.cast(rows_l, C.POINTER(fp)), C.cast(rows_t, C.POINTER(fp))
+        out.mtr_subsmpl = jm.ctypes.data_as(C.POINTER(C.c_uint))
+        out.M = C_rep
     d = abi.t_data()
-    d.sigall = x.ctypes.data_as(C.POINTER(C.c_float))
-    d.hdr.max, d.hdr.mtr, d.hdr.dt, d.hdr.beg = N, n, 1.0, 0.0
+    d.sigall = Xh.ctypes.data_as(fp)
+    if times is not None:
+        d.time = times.ctypes.data_as(C.POINTER(abi.time_t))
+    d.hdr.max, d.hdr.mtr, d.hdr.dt, d.hdr.beg = N, mtr, 1.0, 0.0
     t0 = time.perf_counter()
     rc = fn(C.byref(p), C.byref(out), C.byref(d))
     sec = time.perf_counter() - t0
-    base = {"value": n * N / sec, "unit": "samples/s", "cores": os.cpu_count(), "kind": kind, "seconds": sec, "rc": rc,
+    return {"rc": rc, "seconds": sec, "ls": l, "tsPWS": t, "jk_ls": jl, "jk_ts": jt, "jk_mtr": jm}
+
+
+def cpu_baseline(abi, Xh, params_in, ls, ts, N, mtr):
+    """Time the CPU path on this host on the SAME traces: the reference itself when oracle/_ref was built (kind "reference"),
+    else this repo's restatement (kind "port").  Bounded sample: at most 10 000 traces (~1-3 s for the reference)."""
+    import numpy as np
+    ref = abi.ref()
+    fn, kind = (ref.tspws_main, "reference") if ref is not None else (abi.oracle().orc_tspws_main, "port")
+    n = min(mtr, 10000)
+    r = call_main(abi, fn, params_in, Xh[:n], N, n)
+    base = {"value": n * N / r["seconds"], "unit": "samples/s", "cores": os.cpu_count(), "kind": kind, "seconds": r["seconds"], "rc": r["rc"],
             "sample": f"{n} x {N} of the same synthetic traces (copied from HBM), whole tspws_main call, OpenMP team = all cores "
                       f"(the reference's trace loop is serial, so ~1 core does the work)"}
     if n == mtr:  # full-size parity of the GPU result against the CPU result on identical inputs
-        base["gpu_vs_cpu_relerr"] = {"ls": abi.relerr(ls.cpu().numpy(), l), "tsPWS": abi.relerr(ts.cpu().numpy(), t),
-                                     "max_abs_ls": float(np.abs(l).max()), "max_abs_tsPWS": float(np.abs(t).max())}
+        base["gpu_vs_cpu_relerr"] = {"ls": abi.relerr(ls.cpu().numpy(), r["ls"]), "tsPWS": abi.relerr(ts.cpu().numpy(), r["tsPWS"]),
+                                     "max_abs_ls": float(np.abs(r["ls"]).max()), "max_abs_tsPWS": float(np.abs(r["tsPWS"]).max())}
     # the honest stronger host baseline (BASELINE.md section 3, line ii): this repo's restatement with the trace loop,
     # the per-scale transforms and the inverse spread over all cores (bit-identical to the serial restatement)
-    p2 = abi.t_tsPWS.from_buffer_copy(params_in)
-    l2 = np.zeros(N, np.float32)
-    t2 = np.zeros(N, np.float32)
-    out.ls = l2.ctypes.data_as(C.POINTER(C.c_float))
-    out.tsPWS = t2.ctypes.data_as(C.POINTER(C.c_float))
-    t0 = time.perf_counter()
-    rc2 = abi.oracle().orc_tspws_main_mt(C.byref(p2), C.byref(out), C.byref(d))
-    sec2 = time.perf_counter() - t0
-    base["parallel_port"] = {"value": n * N / sec2, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "seconds": sec2, "rc": rc2,
+    r2 = call_main(abi, abi.oracle().orc_tspws_main_mt, params_in, Xh[:n], N, n)
+    base["parallel_port"] = {"value": n * N / r2["seconds"], "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "seconds": r2["seconds"], "rc": r2["rc"],
                              "sample": "same traces; trace-/scale-parallel OpenMP restatement (oracle/tspws_oracle.c: orc_tspws_main_mt)",
-                             "relerr_vs_reference": {"ls": abi.relerr(l2, l), "tsPWS": abi.relerr(t2, t)}}
-    return base
+                             "relerr_vs_reference": {"ls": abi.relerr(r2["ls"], r["ls"]), "tsPWS": abi.relerr(r2["tsPWS"], r["tsPWS"])}}
+    return base, (r if n == mtr else None)
+
+
+def host_path(abi, lib, Xh, params_in, N, mtr, ref_out, ref_seconds):
+    """The drop-in itself: tspws_main on HOST buffers -- frame creation, pinning + upload over PCIe, compute, download.  Two
+    calls: the first builds the frame, the second finds it (and the device trace buffer) in tspws_main's cache."""
+    a = call_main(abi, lib.tspws_main, params_in, Xh, N, mtr)
+    b = call_main(abi, lib.tspws_main, params_in, Xh, N, mtr)
+    lib.tspws_main_release()
+    res = {"first_call_s": a["seconds"], "cached_call_s": b["seconds"], "rc": [a["rc"], b["rc"]],
+           "value": mtr * N / b["seconds"], "unit": "samples/s", "input_GBps": 4.0 * mtr * N / b["seconds"] / 1e9,
+           "note": "whole tspws_main call on host memory (PCIe-bound: 4 B per sample must cross the link); never the headline value"}
+    if ref_out is not None:
+        res["relerr_vs_reference"] = {"ls": abi.relerr(b["ls"], ref_out["ls"]), "tsPWS": abi.relerr(b["tsPWS"], ref_out["tsPWS"])}
+        if ref_seconds:
+            res["speedup_vs_reference_host_path"] = ref_seconds / b["seconds"]
+    return res
+
+
+def timeit(torch, fn, n, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def other_configs(abi, tspws, lib, torch, X, N):
+    """The other single-GPU configs of BASELINE.json, after the headline timing: cfg2 (configs[1], single-stage, FP64-bound) and
+    cfg4 (configs[3], Mexican hat + jackknife), each with its roofline fraction and its error against the reference (or the
+    restatement where oracle/_ref is absent) on a bounded sub-batch of the same traces."""
+    import numpy as np
+    ref = abi.ref()
+    cpu_fn, kind = (ref.tspws_main, "reference") if ref is not None else (abi.oracle().orc_tspws_main, "port")
+    out = {}
+    # ---- cfg2: 1024 x 32768, w0 = 2 pi, single-stage, wu = 2 biased -----------------------------------------------------
+    N2, m2 = 32768, 1024
+    pin = abi.default_params(w0=2 * np.pi)
+    p2 = tspws.resolve(pin, N2)
+    pl2 = tspws.Plan(p2, N2)
+    X2 = tspws.synth(m2, N2, seed=1)
+    l2 = torch.empty(N2, dtype=torch.float32, device="cuda")
+    t2 = torch.empty(N2, dtype=torch.float32, device="cuda")
+    sec = timeit(torch, lambda: pl2.stack_single(X2, l2, t2), 5, 2)
+    tab = pl2.tables()
+    macs = float(np.sum(tab["L"].astype(np.float64) * tab["Ns"].astype(np.float64)))  # complex-real MACs per transformed trace
+    flops = 4.0 * macs * m2
+    nsub = 128
+    g = pl2.stack_single(X2[:nsub])
+    torch.cuda.synchronize()
+    r = call_main(abi, cpu_fn, pin, X2[:nsub].cpu().numpy(), N2, nsub)
+    out["cfg2_single_stage_1024x32768_w2pi"] = {
+        "ms_per_call": sec * 1e3, "value": m2 * N2 / sec, "unit": "samples/s", "V": p2.V, "J": p2.J, "scales": pl2.S,
+        "roofline": {"bound": "fp64 vector", "flops_per_call": flops, "achieved": flops / sec / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flops / sec / 1e12 / FP64_PEAK_TFLOPS, "hbm_frac": 4.0 * m2 * N2 / sec / 1e9 / HBM_PEAK_GBS,
+                     "note": "forward transforms only: 4 flop per complex-real MAC x MACs per trace x traces (SURVEY 8d); the call is FP64-bound"},
+        "check": {"kind": kind, "sample": f"first {nsub} traces, whole call", "cpu_seconds": r["seconds"],
+                  "relerr": {"ls": abi.relerr(g[0].cpu().numpy(), r["ls"]), "tsPWS": abi.relerr(g[1].cpu().numpy(), r["tsPWS"])}}}
+    del X2, pl2
+    # ---- cfg4: 10k x 131072, Mexican hat, two-stage K = 10 + jackknife n = 10, d = 1 ---------------------------------------
+    mtr = X.shape[0]
+    pin = abi.default_params(type=-3, Kmax=10, jackknife_n=10, jackknife_d=1)
+    p4 = tspws.resolve(pin, N)
+    pl4 = tspws.Plan(p4, N)
+    Cn = 10
+    times = (1262304000 + 86400 * np.arange(mtr)).astype(np.int64)   # 2010-01-01 + i days (SURVEY 8d)
+    sel = np.zeros((Cn, mtr), np.int8)
+    assert lib.tspws_jackknife_plan(sel.ctypes.data, times.ctypes.data, mtr, 1, 10, Cn) == 0
+    sec = timeit(torch, lambda: pl4.stack_jackknife(X, sel), 3, 1)
+    alg = 4.0 * mtr * N + 8.0 * N + 8.0 * 10 * N + 8.0 * Cn * N
+    nsub = min(mtr, 1000)
+    sel_s = np.zeros((Cn, nsub), np.int8)
+    assert lib.tspws_jackknife_plan(sel_s.ctypes.data, times.ctypes.data, nsub, 1, 10, Cn) == 0
+    g = pl4.stack_jackknife(X[:nsub], sel_s)
+    torch.cuda.synchronize()
+    r = call_main(abi, cpu_fn, pin, X[:nsub].cpu().numpy(), N, nsub, times=times[:nsub].copy(), C_rep=Cn)
+    out["cfg4_mexhat_twostage_jackknife_n10_d1"] = {
+        "ms_per_call": sec * 1e3, "value": mtr * N / sec, "unit": "samples/s", "replicas": Cn, "traces": mtr, "V": p4.V, "J": p4.J, "scales": pl4.S,
+        "roofline": {"bound": "hbm", "algorithmic_bytes": alg, "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg / sec / 1e9 / HBM_PEAK_GBS,
+                     "note": "every sample read once (the stack and all replicas share ONE pass) + K partials + outputs; the 110 transforms "
+                             "(3.6e10 flop) are as long as the stream"},
+        "check": {"kind": kind, "sample": f"first {nsub} traces, stack + {Cn} replicas", "cpu_seconds": r["seconds"],
+                  "relerr": {"ls": abi.relerr(g[0].cpu().numpy(), r["ls"]), "tsPWS": abi.relerr(g[1].cpu().numpy(), r["tsPWS"]),
+                             "jk_ls": abi.relerr(g[2].cpu().numpy(), r["jk_ls"]), "jk_ts": abi.relerr(g[3].cpu().numpy(), r["jk_ts"]),
+                             "jk_mtr_equal": bool(np.array_equal(g[4], r["jk_mtr"]))}}}
+    return out
 
 
 if __name__ == "__main__":

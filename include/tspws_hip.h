@@ -150,15 +150,15 @@ int  tspws_hip_stack_finish_range(tspws_hip_plan *plan, const t_tsPWS *p, size_t
 int  tspws_hip_stack_finish_tail(tspws_hip_plan *plan, const t_tsPWS *p, size_t mtr_global,
                                  float *d_ls, float *d_tsPWS, void *stream);
 
-/* Single-GPU convenience: _local + _finish in one call.  With TSPWS_OVERLAP=1 a two-stage request is pipelined
- * instead: the partial stacks are streamed group by group on `stream` while an internal second stream transforms
- * each finished batch of groups (opt-in: on MI355X the co-running kernels currently slow each other as much as the
- * overlap gains).  On return all work is ordered on `stream`. */
+/* Single-GPU convenience: _local + _finish in one call; on return all work is ordered on `stream`. */
 int  tspws_hip_stack(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_sigall, size_t ld, size_t mtr,
                      float *d_ls, float *d_tsPWS, void *stream);
-/* Optional timing of the streaming stage inside tspws_hip_stack (HIP events on `stream` around the partial-stack
- * launches of up to max_calls calls); _end synchronises the device and returns the mean per call. */
+/* Optional timing inside tspws_hip_stack: HIP events on `stream` at the start of the call, after its streaming stage (the
+ * partial-stack launches) and at its end, for up to max_calls calls.  _read synchronises the device and returns the per-call
+ * durations in ms (either array may be NULL; *ncalls = calls recorded); _end returns the mean of the streaming stage and
+ * resets the recorder. */
 int  tspws_hip_profile_begin(tspws_hip_plan *plan, size_t max_calls);
+int  tspws_hip_profile_read(tspws_hip_plan *plan, double *stage_ms, double *call_ms, size_t cap, size_t *ncalls);
 int  tspws_hip_profile_end(tspws_hip_plan *plan, double *mean_ms, size_t *ncalls);
 /* Number of streaming-kernel (k_partial) launches the last partial-stack / stack_local call issued: the traces are walked a
  * few groups at a time so that every launch puts one workgroup on every CU. */
@@ -188,11 +188,13 @@ int  tspws_hip_jackknife(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_
                          size_t mtr, const char *h_sel, unsigned C,
                          float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *stream);
 
-/* Optional: announce, BEFORE the two-stage tspws_hip_stack_local of the whole ensemble, the jackknife that will follow on
- * the same device-resident traces.  That stack_local then streams the traces ONCE for its own groups and for every
- * replica (the reference walks them 1 + C times, :719-831), and tspws_hip_jackknife with the same selection reuses the
- * class sums.  The traces must not change between the two calls.  No-op for single-stage parameters. */
-int  tspws_hip_jackknife_prepare(tspws_hip_plan *plan, const t_tsPWS *p, const char *h_sel, unsigned C, size_t mtr);
+/* The two-stage stack AND its C jackknife replicas from ONE pass over the device-resident traces (the reference walks them
+ * 1 + C times, :216 and :758-772): same outputs as tspws_hip_stack followed by tspws_hip_jackknife, except that the stack's
+ * groups are summed class by class (last-bit differences in the FP64 partial stacks).  Falls back to tspws_hip_stack for
+ * single-stage parameters or C == 0. */
+int  tspws_hip_stack_jackknife(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_sigall, size_t ld, size_t mtr,
+                               float *d_ls, float *d_tsPWS, const char *h_sel, unsigned C,
+                               float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *stream);
 
 /* Trace-sharded jackknife (one shard per GPU; the reference has no counterpart -- its replicas, :735-813, walk one host
  * array).  h_sel is the selection over the WHOLE ensemble, [C][mtr_global]; a trace's group in a replica is its rank among
@@ -227,6 +229,11 @@ int  tspws_hip_subsample(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_
 int  tspws_hip_convergence(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_sigall, size_t ld, size_t mtr,
                            const float *d_ref_ts, const float *d_ref_ls, double *h_ts_sim, double *h_ts_misfit,
                            double *h_ls_sim, double *h_ls_misfit, float *d_ts_steps, float *d_ls_steps, void *stream);
+
+/* ---- the drop-in's cache ---------------------------------------------------------------------------
+ * tspws_main keeps the frame and the device trace buffer of its last call for the next one (same parameters: nothing to
+ * rebuild).  This frees them; TSPWS_PLAN_CACHE=0 in the environment disables the cache altogether. */
+void tspws_main_release(void);
 
 /* ---- synthetic ensembles for bench / tests ------------------------------------ */
 /* trace i = first+local, sample n: 0.2 sin(2pi(n-N/2)/200) exp(-((n-N/2)/(0.05N))^2/2) + U(-.5,.5) */

@@ -112,3 +112,45 @@ def test_nmax_beyond_the_trace_count_is_clamped(sac_list, golden):
     # Nmax below the count still selects a prefix
     run_cli(sac_list, "list.txt", "osac=n8", "Nmax=8")
     assert abi.read_sac(sac_list / "ts_pws_n8.sac")["f"][40] == 8.0
+
+
+def _bench(args, env_extra=None, timeout=600):
+    import json
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(abi.ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`bench.py --gpus 2` without a launcher around it: the parent starts two ranks before touching the GPU (here both on the
+    one GPU of the box, collectives over gloo), rank 0's JSON line comes back through the parent."""
+    r = _bench(["--gpus", "2", "--traces", "64", "--samples", "4096", "--steps", "3", "--warmup", "1", "--no-cpu"], {"BENCH_BACKEND": "gloo"})
+    assert r["n_gpus"] == 2 and r["config"]["world_size"] == 2 and r["config"]["backend"] == "gloo"
+    assert r["config"]["traces_total"] == 128 and r["config"]["traces_per_gpu"] == 64
+    assert r["value"] > 0 and r["scaling"] == "weak" and r["roofline"]["launches_per_call"] >= 1
+    assert r["step_ms_gpu"]["n"] == 3 and r["step_ms_gpu"]["min"] <= r["step_ms_gpu"]["median"] <= r["step_ms_gpu"]["max"]
+    r5 = _bench(["--gpus", "2", "--config", "cfg5", "--samples", "2048", "--kmax", "4", "--steps", "2", "--warmup", "1", "--no-cpu"], {"BENCH_BACKEND": "gloo"})
+    assert r5["config"]["traces_per_gpu"] == 12500 and r5["config"]["traces_total"] == 25000 and "configs[4]" in r5["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_has_the_contract_keys():
+    """One GPU, small size: the line carries the contract keys, the roofline object, the per-step statistics, the D2H-inclusive
+    figure and the CPU baseline with the full-size comparison against it."""
+    r = _bench(["--traces", "200", "--samples", "8192", "--steps", "5", "--warmup", "2", "--no-extra"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "step_ms_gpu", "with_output_d2h"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["dtype"] == "f64" and r["vs_baseline"] is None and r["unit"] == "samples/s"
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r["roofline"])
+    assert r["cpu_baseline"]["rc"] == 0 and r["cpu_baseline"]["gpu_vs_cpu_relerr"]["tsPWS"] < 1e-5 and r["cpu_baseline"]["gpu_vs_cpu_relerr"]["ls"] < 1e-5
+    assert r["step_ms_gpu"]["n"] == 5

@@ -377,6 +377,64 @@ def test_full_size_properties(lib, torch):
     assert abi.relerr(tsc.cpu().numpy(), lsc.cpu().numpy()) < 1e-6
 
 
+def test_full_size_jackknife_properties(lib, torch):
+    """BASELINE configs[3] at its full size (10 000 x 131 072, Mexican hat, two-stage K = 10, jackknife n = 10, d = 1: ten
+    replicas; ts_pws1f_lib.c:719-831) through the one-pass call: the deletion plan and the replica sizes against the oracle's
+    plan, every replica's K partial-stack rows against direct FP64 sums of the selected traces (group of the k-th selected
+    trace: floor(k K / K_c), :766), two replicas against the plain stack of the gathered subset, the time-domain linear
+    stacks, and exact scaling with a power of two."""
+    mtr, N, K, n, Cn = 10000, 131072, 10, 10, 10
+    p = tspws.resolve(abi.default_params(type=-3, Kmax=K, jackknife_n=n, jackknife_d=1), N)
+    pl = tspws.Plan(p, N)
+    Xd = tspws.synth(mtr, N, seed=1)
+    times = (1262304000 + 86400 * np.arange(mtr)).astype(np.int64)   # 2010-01-01 + i days (SURVEY 8d)
+    sel = np.zeros((Cn, mtr), np.int8)
+    sel_o = np.zeros((Cn, mtr), np.int8)
+    assert lib.tspws_jackknife_plan(sel.ctypes.data, times.ctypes.data, mtr, 1, n, Cn) == 0
+    assert abi.oracle().orc_jackknife_plan(sel_o.ctypes.data, times.ctypes.data, mtr, 1, n, Cn) == 0
+    np.testing.assert_array_equal(sel, sel_o)
+    ls, ts, jl, jt, jm = pl.stack_jackknife(Xd, sel)
+    torch.cuda.synchronize()
+    ls, ts, jl, jt = ls.clone(), ts.clone(), jl.clone(), jt.clone()
+    np.testing.assert_array_equal(jm, sel.sum(axis=1).astype(np.uint32))
+    assert 0 < jm.min() and jm.max() < mtr
+    # the stack itself: same as the plain call up to the rounding of class sums vs chunk sums
+    ls0, ts0 = pl.stack(Xd)
+    torch.cuda.synchronize()
+    assert abi.relerr(ls.cpu().numpy(), ls0.cpu().numpy()) < 1e-6 and abi.relerr(ts.cpu().numpy(), ts0.cpu().numpy()) < 1e-6
+    # rows of every replica (one pass over the "shard" that is the whole ensemble) against direct sums
+    pl.jackknife_local(Xd, 0, mtr, sel)
+    torch.cuda.synchronize()
+    rows = pl.jackknife_buffer(Cn).view(Cn, K, N)
+    for c in range(Cn):
+        idx = np.flatnonzero(sel[c] == 1)
+        Kc = idx.size
+        grp = np.floor(np.arange(Kc) * K / Kc).astype(np.int64)
+        for g in range(K):
+            want = Xd[torch.as_tensor(idx[grp == g], device="cuda")].double().sum(dim=0)
+            assert float((rows[c, g] - want).abs().max()) <= 1e-9, (c, g)
+        # time-domain linear stack of the replica (:799-811): (sum of its rows) * (1 / K_c), cast to float
+        lin = (rows[c].sum(dim=0) * (1.0 / Kc)).float()
+        assert float((jl[c] - lin).abs().max()) <= 1e-6 * float(lin.abs().max())
+    # a replica IS the two-stage stack of its selected traces
+    for c in (0, 7):
+        idx = torch.as_tensor(np.flatnonzero(sel[c] == 1), device="cuda")
+        Xc = Xd[idx].contiguous()
+        lc, tc = pl.stack(Xc)
+        torch.cuda.synchronize()
+        assert abi.relerr(jt[c].cpu().numpy(), tc.cpu().numpy()) < 1e-6, c
+        del Xc
+    # linearity: a power-of-two factor scales every intermediate exactly
+    Xd *= 0.25
+    ls4, ts4, jl4, jt4, jm4 = pl.stack_jackknife(Xd, sel)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal((ls4 * 4).cpu().numpy(), ls.cpu().numpy())
+    np.testing.assert_array_equal((ts4 * 4).cpu().numpy(), ts.cpu().numpy())
+    np.testing.assert_array_equal((jt4 * 4).cpu().numpy(), jt.cpu().numpy())
+    np.testing.assert_array_equal((jl4 * 4).cpu().numpy(), jl.cpu().numpy())
+    np.testing.assert_array_equal(jm4, jm)
+
+
 def test_full_size_single_stage_properties(lib, torch):
     """BASELINE configs[1] at its full size (1024 x 32768, w0 = 2 pi, single stage): a two-stage call with one trace per
     group is the same computation, and the result is invariant under a permutation of the traces (up to summation order)."""
@@ -477,35 +535,6 @@ def test_plan_reuse_and_argument_errors(lib, torch):
     assert lib.tspws_hip_plan_create(C.byref(h), -1, 4, 4, N, 2.0, 1.0, abi.W0_DEFAULT, 0, 99) == 5    # no such device
     assert lib.tspws_hip_partial_stacks(pl.h, None, N, 4, 0, 4, 2, None, N, None) == -1
     assert b"partial_stacks" in lib.tspws_hip_last_error()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("kw,N,ntr", [
-    (dict(), 4096, 3), (dict(), 16501, 5), (dict(type=-3), 8192, 2), (dict(w0=2 * np.pi), 32768, 9),
-    (dict(s0=3.7, J=5), 3001, 2), (dict(), 131072, 2), (dict(J=2), 64, 3), (dict(b0=4.0), 65536, 2),
-    (dict(b0=0.25), 32768, 2),  # filters longer than the matrix kernel accepts: the plan must fall back to the VALU kernels
-])
-def test_forward_matrix_pipe_kernel(lib, torch, kw, N, ntr, monkeypatch):
-    """Opt-in FP64-MFMA forward kernel (csrc/fwd_mfma.h, TSPWS_FWD_KERNEL=mfma): same coefficients as the oracle,
-    float and double inputs, whole two-stage call included."""
-    monkeypatch.setenv("TSPWS_FWD_KERNEL", "mfma")
-    p = abi.resolve(abi.default_params(**kw), N)
-    f = abi.OracleFrame.from_params(p, N)
-    pl = tspws.Plan(p, N)
-    X = abi.synth_traces(ntr, N, seed=33)
-    Y = dev_forward(torch, pl, X.astype(np.float64))
-    Y32 = dev_forward(torch, pl, X)
-    for t in range(ntr):
-        Yo = f.forward(X[t].astype(np.float64))
-        assert abi.relerr(Y[t], Yo) < TOL64
-        assert abi.relerr(Y32[t], Yo) < TOL64
-    pk = tspws.resolve(abi.default_params(Kmax=2, unbiased=1, **kw), N)
-    plk = tspws.Plan(pk, N)
-    Xd = torch.as_tensor(X, device="cuda")
-    ls, ts = plk.stack(Xd)
-    torch.cuda.synchronize()
-    b = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(Kmax=2, unbiased=1, **kw), X)
-    assert abi.relerr(ts.cpu().numpy(), b["tsPWS"]) < TOL32
 
 
 @pytest.mark.gpu
@@ -622,41 +651,10 @@ def test_reduce_buffer_survives_growth(lib, torch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["1", "2"])
-@pytest.mark.parametrize("kw,N,ntr", [
-    (dict(), 16384, 3), (dict(), 16501, 5), (dict(type=-3), 32768, 2), (dict(w0=2 * np.pi), 32768, 9),
-    (dict(s0=3.7, J=8), 30010, 2), (dict(), 131072, 2), (dict(b0=4.0), 65536, 2),
-])
-def test_forward_octave_fused_kernels(lib, torch, kw, N, ntr, mode, monkeypatch):
-    """Opt-in octave-fused forward kernels for D >= 64 (csrc/fwd_oct.h, TSPWS_FWD_OCT=1): mode 1 = voice subsets, two workgroups
-    per CU; mode 2 = two-team software pipeline.  Same coefficients as the oracle for float and double inputs (strided and
-    chunk-major windows, circular seams, decimations that do not divide N, partially filled residue chunks), and the whole
-    two-stage call on top."""
-    monkeypatch.setenv("TSPWS_FWD_OCT", "1")
-    monkeypatch.setenv("TSPWS_OCT_MODE", mode)
-    p = abi.resolve(abi.default_params(**kw), N)
-    f = abi.OracleFrame.from_params(p, N)
-    pl = tspws.Plan(p, N)
-    X = abi.synth_traces(ntr, N, seed=35)
-    Y = dev_forward(torch, pl, X.astype(np.float64))
-    Y32 = dev_forward(torch, pl, X)
-    for t in range(ntr):
-        Yo = f.forward(X[t].astype(np.float64))
-        assert abi.relerr(Y[t], Yo) < TOL64
-        assert abi.relerr(Y32[t], Yo) < TOL64
-    pk = tspws.resolve(abi.default_params(Kmax=2, unbiased=1, **kw), N)
-    plk = tspws.Plan(pk, N)
-    ls, ts = plk.stack(torch.as_tensor(X, device="cuda"))
-    torch.cuda.synchronize()
-    b = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(Kmax=2, unbiased=1, **kw), X)
-    assert abi.relerr(ts.cpu().numpy(), b["tsPWS"]) < TOL32 and abi.relerr(ls.cpu().numpy(), b["ls"]) < TOL32
-
-
-@pytest.mark.gpu
-def test_prepared_jackknife_shares_the_streaming_pass(lib, torch):
-    """tspws_hip_jackknife_prepare: the two-stage stack streams the traces once for its own groups and for every replica; the
-    jackknife that follows reuses the class sums.  Same replicas as the stand-alone jackknife (which streams again), same
-    main outputs as the plain call, and a selection that does not match falls back to its own pass."""
+def test_stack_and_jackknife_share_the_streaming_pass(lib, torch):
+    """tspws_hip_stack_jackknife: ONE pass over the traces for the stack's own groups and for every replica.  Same replicas
+    as the stand-alone jackknife (which streams by itself), same main outputs as the plain call (class sums instead of chunk
+    sums: rounding only), and everything against the oracle's tspws_main; single-stage parameters fall back to the plain stack."""
     mtr, N, K, n = 300, 4096, 6, 5
     p = tspws.resolve(abi.default_params(Kmax=K, unbiased=1, jackknife_n=n, jackknife_d=1), N)
     pl = tspws.Plan(p, N)
@@ -678,21 +676,31 @@ def test_prepared_jackknife_shares_the_streaming_pass(lib, torch):
 
     ls0, ts0 = [t.cpu().numpy() for t in pl.stack(Xd)]       # plain call, stand-alone jackknife
     l0, t0, m0 = jack(sel)
-    tspws.check(lib.tspws_hip_jackknife_prepare(pl.h, C.byref(pl.params), sel.ctypes.data, Cn, mtr), "prepare")
-    ls1, ts1 = [t.cpu().numpy() for t in pl.stack(Xd)]       # prepared: one pass for groups + replicas
-    l1, t1, m1 = jack(sel)
+    ls1, ts1, l1, t1, m1 = pl.stack_jackknife(Xd, sel)       # one pass for groups + replicas
+    torch.cuda.synchronize()
+    ls1, ts1, l1, t1 = [t.cpu().numpy() for t in (ls1, ts1, l1, t1)]
     np.testing.assert_array_equal(m0, m1)
     assert abi.relerr(ls1, ls0) < 1e-6 and abi.relerr(ts1, ts0) < 1e-6   # class sums instead of chunk sums: rounding only
-    np.testing.assert_array_equal(l1, l0)                                  # replicas: the same class sums either way
-    np.testing.assert_array_equal(t1, t0)
+    assert abi.relerr(l1, l0) < 1e-6 and abi.relerr(t1, t0) < 1e-6       # (the plain groups split some classes: rounding only)
     want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(Kmax=K, unbiased=1, jackknife_n=n, jackknife_d=1), Xd.cpu().numpy(), times=times)
-    assert abi.relerr(ts1, want["tsPWS"]) < TOL32 and max(abi.relerr(t1[c], want["jk_ts"][c]) for c in range(Cn)) < TOL32
-    # a different selection after a prepared stack: not the cached classes
+    assert abi.relerr(ts1, want["tsPWS"]) < TOL32 and abi.relerr(ls1, want["ls"]) < TOL32
+    assert max(abi.relerr(t1[c], want["jk_ts"][c]) for c in range(Cn)) < TOL32 and max(abi.relerr(l1[c], want["jk_ls"][c]) for c in range(Cn)) < TOL32
+    np.testing.assert_array_equal(m1, want["jk_mtr"])
+    # a second call with another selection on the same plan: nothing is carried over
     sel2 = sel[::-1].copy()
-    tspws.check(lib.tspws_hip_jackknife_prepare(pl.h, C.byref(pl.params), sel.ctypes.data, Cn, mtr), "prepare")
-    pl.stack(Xd)
-    l2, t2, m2 = jack(sel2)
-    np.testing.assert_array_equal(t2, t0[::-1])
+    _, _, l2, t2, m2 = pl.stack_jackknife(Xd, sel2)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(t2.cpu().numpy(), t1[::-1])
+    np.testing.assert_array_equal(m2, m1[::-1])
+    # single-stage parameters: the plain stack, replica outputs untouched
+    p1 = tspws.resolve(abi.default_params(), N)
+    pl1 = tspws.Plan(p1, N)
+    a, b, jl, jt, jm = pl1.stack_jackknife(Xd[:40], sel[:, :40])
+    a0, b0 = pl1.stack(Xd[:40])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(a.cpu().numpy(), a0.cpu().numpy())
+    np.testing.assert_array_equal(b.cpu().numpy(), b0.cpu().numpy())
+    assert not jm.any()
 
 
 @pytest.mark.gpu

@@ -47,17 +47,12 @@ times = (1262304000 + 86400 * np.arange(mtr)).astype(np.int64)
 Cn = 10
 sel = np.zeros((Cn, mtr), np.int8)
 assert lib.tspws_jackknife_plan(sel.ctypes.data, times.ctypes.data, mtr, 1, 10, Cn) == 0
-jl = torch.empty((Cn, N), dtype=torch.float32, device="cuda")
-jt = torch.empty((Cn, N), dtype=torch.float32, device="cuda")
-jm = np.zeros(Cn, np.uint32)
 
 
 def jk():
-    # announce the replicas first: the stack then streams the traces once for its groups and all replicas
-    tspws.check(lib.tspws_hip_jackknife_prepare(pl.h, C.byref(pl.params), sel.ctypes.data, Cn, mtr), "jackknife_prepare")
-    pl.stack(X)
-    tspws.check(lib.tspws_hip_jackknife(pl.h, C.byref(pl.params), X.data_ptr(), N, mtr, sel.ctypes.data, Cn, jl.data_ptr(), jt.data_ptr(),
-                                        jm.ctypes.data, None))
+    # the stack and its ten replicas from ONE pass over the traces
+    pl.stack_jackknife(X, sel)
+
 
 
 t = timeit(jk, n=3, warm=1)

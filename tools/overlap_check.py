@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""One process = one setting of the environment switches: times the north-star call and prints a digest of both float
-outputs, so that schedules can be compared across processes (the switches are read once per process).
-usage: [TSPWS_OVERLAP=2 ...] overlap_check.py [mtr] [N] [K] [steps]"""
+"""One process = one build / one setting of the environment: times the north-star call and prints a digest of both float
+outputs (and of two calls on CHANGED traces: a schedule that read stale partial stacks would show), so that variants can be
+compared across processes.  Used for the round-3 overlap experiments (profiles/r03_overlap_experiments.txt).
+usage: [TSPWS_LIB_PATH=... ] overlap_check.py [mtr] [N] [K] [steps]"""
 import hashlib
 import importlib
 import os

@@ -102,11 +102,13 @@ SYMBOLS = {
     "tspws_hip_stack_finish_tail": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "tspws_hip_stack": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "tspws_hip_profile_begin": (_i, [_vp, _sz]),
+    "tspws_hip_profile_read": (_i, [_vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "tspws_hip_profile_end": (_i, [_vp, C.POINTER(_d), C.POINTER(_sz)]),
     "tspws_hip_stream_launches": (_i, [_vp]),
     "tspws_jackknife_plan": (_i, [_vp, _vp, _sz, _u, _u, _u]),
     "tspws_hip_jackknife": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _u, _vp, _vp, _vp, _vp]),
-    "tspws_hip_jackknife_prepare": (_i, [_vp, _vp, _vp, _u, _sz]),
+    "tspws_hip_stack_jackknife": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp]),
+    "tspws_main_release": (None, []),
     "tspws_hip_finish_shard": (_i, [_vp, _vp, _sz, _u, _u, C.POINTER(_u), C.POINTER(_u)]),
     "tspws_hip_stack_finish_scales": (_i, [_vp, _vp, _sz, _u, _u, _vp, _vp]),
     "tspws_hip_jackknife_buffer": (_i, [_vp, _vp, _u, C.POINTER(_vp), C.POINTER(_sz)]),
@@ -265,7 +267,9 @@ class Plan:
         return sel
 
     def jackknife_buffer(self, C_):
-        """torch view (float64, [C * Kmax * N]) of the replicas' partial-stack rows a multi-GPU caller reduces."""
+        """torch view (float64, [C * Kmax * N]) of the replicas' partial-stack rows a multi-GPU caller reduces.  Like
+        reduce_buffer the view aliases library scratch of THIS (C, Kmax) shape: an outgrown block stays alive until the plan is
+        destroyed (an in-flight collective on it is safe), but later calls use the new block -- fetch the view again."""
         import torch
         ptr, n = C.c_void_p(), C.c_size_t()
         check(self.lib.tspws_hip_jackknife_buffer(self.h, C.byref(self.params), C_, C.byref(ptr), C.byref(n)), "jackknife_buffer")
@@ -281,7 +285,10 @@ class Plan:
     def jackknife_finish(self, mtr_global, sel, c_begin, c_end, ls_out, ts_out, mtr_out):
         """Replicas [c_begin, c_end) from the reduced rows into rows of the [C][N] float32 tensors; sizes into mtr_out (uint32 numpy)."""
         import torch
+        import numpy as np
         sel = self._sel(sel, sel.shape[0], mtr_global)
+        if not isinstance(mtr_out, np.ndarray) or mtr_out.dtype != np.uint32 or mtr_out.shape != (sel.shape[0],) or not mtr_out.flags.c_contiguous:
+            raise TspwsError(f"mtr_out must be a contiguous uint32 numpy array of {sel.shape[0]} entries")
         for t, name in ((ls_out, "ls_out"), (ts_out, "ts_out")):
             if t.dtype != torch.float32 or tuple(t.shape) != (sel.shape[0], self.N) or not t.is_contiguous() or not t.is_cuda or \
                     (t.device.index or 0) != self.device:
@@ -309,6 +316,9 @@ class Plan:
 
     def epilogue(self, x2, mtr_global, ls, ts):
         """ls = (float)x2[N:] / mtr, ts = (float)x2[:N]  (reference epilogue, ts_pws1f_lib.c:233-241)."""
+        import torch
+        if x2.dtype != torch.float64 or x2.numel() != 2 * self.N or not x2.is_contiguous() or not x2.is_cuda or (x2.device.index or 0) != self.device:
+            raise TspwsError(f"x2 must be a contiguous float64 tensor of {2 * self.N} values on cuda:{self.device}")
         check(self.lib.tspws_hip_epilogue(self._out(ls, "ls"), self._out(ts, "ts"), x2.data_ptr() + 8 * self.N, x2.data_ptr(), self.N, mtr_global,
                                           self._stream()), "epilogue")
 
@@ -316,8 +326,39 @@ class Plan:
         """ls, tsPWS (float32 cuda tensors) of a shard of HBM-resident traces; see stack_sharded."""
         return stack_sharded(self, traces, first, mtr_global, group)
 
+    def stack_jackknife(self, traces, sel, ls=None, ts=None):
+        """Two-stage stack AND its jackknife replicas from ONE pass over the traces (tspws_hip_stack_jackknife).
+        `sel` = [C][mtr] int8 selection (tspws_jackknife_plan).  Returns ls, ts, ls_out[C][N], ts_out[C][N], mtr_out[C]."""
+        import numpy as np
+        import torch
+        mtr, ld = self._traces(traces)
+        sel = self._sel(sel, sel.shape[0], mtr)
+        Cn = sel.shape[0]
+        ls = torch.empty(self.N, dtype=torch.float32, device=traces.device) if ls is None else ls
+        ts = torch.empty(self.N, dtype=torch.float32, device=traces.device) if ts is None else ts
+        ls_out = torch.empty((Cn, self.N), dtype=torch.float32, device=traces.device)
+        ts_out = torch.empty((Cn, self.N), dtype=torch.float32, device=traces.device)
+        mtr_out = np.zeros(Cn, np.uint32)
+        check(self.lib.tspws_hip_stack_jackknife(self.h, C.byref(self.params), traces.data_ptr(), ld, mtr, self._out(ls, "ls"), self._out(ts, "ts"),
+                                                 sel.ctypes.data, Cn, ls_out.data_ptr(), ts_out.data_ptr(), mtr_out.ctypes.data, self._stream()),
+              "stack_jackknife")
+        return ls, ts, ls_out, ts_out, mtr_out
+
+    def profile_begin(self, max_calls):
+        """Record HIP events inside the next `max_calls` stack_single calls (start, end of the streaming stage, end)."""
+        check(self.lib.tspws_hip_profile_begin(self.h, max_calls), "profile_begin")
+
+    def profile_read(self):
+        """(stage_ms[], call_ms[]) of the recorded calls (numpy float64); synchronises the device."""
+        import numpy as np
+        n = C.c_size_t()
+        check(self.lib.tspws_hip_profile_read(self.h, None, None, 0, C.byref(n)), "profile_read")
+        st, ca = np.zeros(n.value), np.zeros(n.value)
+        check(self.lib.tspws_hip_profile_read(self.h, st.ctypes.data, ca.ctypes.data, n.value, C.byref(n)), "profile_read")
+        return st, ca
+
     def stack_single(self, traces, ls=None, ts=None):
-        """Whole call on ONE GPU through tspws_hip_stack (pipelined streaming + transforms)."""
+        """Whole call on ONE GPU through tspws_hip_stack (stack_local + stack_finish in one C call)."""
         import torch
         mtr, ld = self._traces(traces)
         ls = torch.empty(self.N, dtype=torch.float32, device=traces.device) if ls is None else ls
@@ -402,10 +443,10 @@ def jackknife_sharded(plan, traces, sel, first=0, mtr_global=None, group=None):
     walks its shard ONCE (plan.jackknife_local): the sums of its traces for the Kmax plain groups and for the Kmax groups of
     every replica -- group indices come from the GLOBAL trace order, so the shards' rows simply add.  The plain rows are
     all-reduced and every rank finishes the stack (as in stack_sharded).  The replicas are SHARDED for the finish stage,
-    which is where their time goes (Kmax transforms + an inverse each): replica c belongs to rank c % world, its Kmax rows
-    are reduced to that rank only (C reductions of Kmax x N doubles instead of one all-reduce of all C of them on every
-    rank), the owner finishes it, and one all-reduce of the [C][N] float outputs (zeros from the non-owners: exact)
-    hands every rank all replicas.  Returns ls, ts, ls_out[C][N], ts_out[C][N], mtr_out[C]."""
+    which is where their time goes (Kmax transforms + an inverse each): rank r owns the contiguous block of replicas
+    [r C / world, (r + 1) C / world), their rows are reduced to that rank only (one reduction per owner instead of one
+    all-reduce of all C x Kmax rows on every rank), the owner finishes its block in one batched call, and one all-reduce of
+    the [C][N] float outputs (zeros from the non-owners: exact) hands every rank all replicas.  Returns ls, ts, ls_out[C][N], ts_out[C][N], mtr_out[C]."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -423,28 +464,27 @@ def jackknife_sharded(plan, traces, sel, first=0, mtr_global=None, group=None):
     ls_out = torch.zeros((Cn, N), dtype=torch.float32, device=dev)
     ts_out = torch.zeros((Cn, N), dtype=torch.float32, device=dev)
     mtr_out = np.zeros(Cn, np.uint32)
+    # replica c belongs to the rank whose CONTIGUOUS block [r * C // world, (r + 1) * C // world) holds it: one reduction per
+    # owner covers all its rows, and the owner finishes its block in one batched call (forward launch, inverses in pairs)
+    def block(r):
+        return r * Cn // world, (r + 1) * Cn // world
     works = []
     if distributed:
         rows = plan.jackknife_buffer(Cn).view(Cn, K * N)
         works.append(dist.all_reduce(plan.reduce_buffer(mtr_global), op=dist.ReduceOp.SUM, group=group, async_op=True))
-        for c in range(Cn):
-            dst = c % world
-            works.append(dist.reduce(rows[c], dst=dist.get_global_rank(group, dst) if group is not None else dst, op=dist.ReduceOp.SUM,
-                                     group=group, async_op=True))
+        for r in range(world):
+            c0, c1 = block(r)
+            if c1 > c0:
+                works.append(dist.reduce(rows[c0:c1], dst=dist.get_global_rank(group, r) if group is not None else r, op=dist.ReduceOp.SUM,
+                                         group=group, async_op=True))
     for w in works[:1]:
         w.wait()
     plan.stack_finish(mtr_global, ls, ts)  # runs while the replicas' rows are still being reduced
     for w in works[1:]:
         w.wait()
-    mine = [c for c in range(Cn) if c % world == rank]
-    # owned replicas are finished in runs of consecutive indices (world 1: one run, batched like the single-GPU call)
-    i = 0
-    while i < len(mine):
-        j = i
-        while j + 1 < len(mine) and mine[j + 1] == mine[j] + 1:
-            j += 1
-        plan.jackknife_finish(mtr_global, sel, mine[i], mine[j] + 1, ls_out, ts_out, mtr_out)
-        i = j + 1
+    c0, c1 = block(rank)
+    if c1 > c0:
+        plan.jackknife_finish(mtr_global, sel, c0, c1, ls_out, ts_out, mtr_out)
     if distributed:
         dist.all_reduce(ls_out, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(ts_out, op=dist.ReduceOp.SUM, group=group)
@@ -455,14 +495,33 @@ def jackknife_sharded(plan, traces, sel, first=0, mtr_global=None, group=None):
 
 
 def _finish_shard(plan, mtr_global, group=None):
-    """This rank's share of the scales for the sharded finish stage, or None (plan without one, world 1, TSPWS_SHARD_FINISH=0)."""
+    """This rank's share of the scales for the sharded finish stage, or None (plan without one, world 1, TSPWS_SHARD_FINISH=0).
+    The decision is AGREED across the ranks: each one looks at its own environment and plan, so a rank that would not shard
+    (a different TSPWS_SHARD_FINISH, a check-kernel switch) would otherwise issue a different sequence of collectives and
+    hang the job -- one MIN all-reduce of a flag makes every rank take the redundant finish unless all of them can shard."""
+    import torch
     import torch.distributed as dist
-    if os.environ.get("TSPWS_SHARD_FINISH", "1") == "0" or not callable(getattr(plan, "finish_shard", None)):
-        return None
     world = dist.get_world_size(group)
     if world < 2:
         return None
-    return plan.finish_shard(mtr_global, dist.get_rank(group), world)
+    cache = getattr(plan, "_shard_agreed", None)  # agreed once per (ensemble size, group): no collective in later calls
+    key = (mtr_global, world, dist.get_rank(group), id(group))
+    if cache is not None and key in cache:
+        return cache[key]
+    mine = None
+    if os.environ.get("TSPWS_SHARD_FINISH", "1") != "0" and callable(getattr(plan, "finish_shard", None)):
+        mine = plan.finish_shard(mtr_global, dist.get_rank(group), world)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    flag = torch.tensor([1 if mine is not None else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    agreed = mine if int(flag.item()) == 1 else None
+    try:
+        if cache is None:
+            cache = plan._shard_agreed = {}
+        cache[key] = agreed
+    except AttributeError:
+        pass
+    return agreed
 
 
 def split_groups(K, sharded_finish=False):

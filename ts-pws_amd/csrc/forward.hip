@@ -1,0 +1,560 @@
+// forward.hip -- forward frame CWT and the linear / phase stacks in the time-scale domain.
+//
+//   few traces (the K partial stacks of a two-stage call, the per-trace API): k_fwd_lds (fwd_lds.h) + k_fwd_poly (fwd_poly.h)
+//   many traces (single-stage batches >= 64): k_fwd_tl (fwd_tl.h) on the transposed batch
+//   check kernel (TSPWS_FWD_GENERIC=1): one wave / workgroup per coefficient
+// Reference citations are relative to /root/reference/src.
+#include "tspws_internal.h"
+
+#ifndef FL_PASSES
+#define FL_PASSES 2
+#endif
+#ifndef FL_WAVES
+#define FL_WAVES 4
+#endif
+#ifndef FL_PASSES_FINE
+#define FL_PASSES_FINE 1
+#endif
+
+// ------------------------------------------------------------------------------------------
+// forward frame CWT, generic form (any D, any L <= N):
+//   Y_s[k] = conj( sum_l x[(k D - c + l) mod N] w_s[l] )          cdotx.c:44-70
+// Lanes run along the taps (coalesced x and tap reads), partial sums are combined with
+// wave shuffles.  WAVE_PER_OUT: one wave per coefficient; otherwise one 256-thread block.
+// ------------------------------------------------------------------------------------------
+template <typename TIn, bool BLOCK_PER_OUT>
+__global__ void __launch_bounds__(256) k_fwd_generic(const TIn *__restrict__ x, size_t ld, unsigned N, const ScaleDesc *__restrict__ sc,
+                                                     unsigned S, const double2 *__restrict__ w, double2 *__restrict__ Y, size_t ncoef,
+                                                     unsigned long long first_coef, unsigned long long n_items)
+{
+	__shared__ double red[8];
+	const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	unsigned long long item = BLOCK_PER_OUT ? blockIdx.x : (unsigned long long)blockIdx.x * 4 + wv;
+	if (item >= n_items) return;
+	const unsigned long long ci = first_coef + item;
+	const unsigned s = find_scale(sc, S, ci, false);
+	const ScaleDesc d = sc[s];
+	const unsigned k = (unsigned)(ci - d.coef_off);
+	const TIn *xr = x + (size_t)blockIdx.y * ld;
+	const double2 *ws = w + d.tap_off;
+	long long n0 = (long long)k * d.D - d.c;
+	if (n0 < 0) n0 += N;
+	double re = 0, im = 0;
+	const unsigned stride = BLOCK_PER_OUT ? 256 : 64;
+	for (unsigned l = BLOCK_PER_OUT ? threadIdx.x : lane; l < d.L; l += stride) {
+		unsigned long long idx = (unsigned long long)n0 + l;
+		if (idx >= N) idx -= N;
+		const double xv = (double)xr[idx];
+		const double2 t = ws[l];
+		re = fma(xv, t.x, re);
+		im = fma(xv, t.y, im);
+	}
+	re = wave_sum(re);
+	im = wave_sum(im);
+	double2 *out = Y + (size_t)blockIdx.y * ncoef + ci;
+	if (BLOCK_PER_OUT) {
+		if (lane == 0) { red[wv * 2] = re; red[wv * 2 + 1] = im; }
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			re = red[0] + red[2] + red[4] + red[6];
+			im = red[1] + red[3] + red[5] + red[7];
+			*out = make_double2(re, -im);
+		}
+	} else if (lane == 0) *out = make_double2(re, -im);
+}
+
+template <typename TIn>
+static int forward_generic(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_Y, hipStream_t st)
+{
+	if (!p || !d_x || !d_Y) return fail(TSPWS_E_ARG, "forward: NULL");
+	if (!ntr) return 0;
+	HIP_TRY(hipSetDevice(p->device));
+	// scales are ordered by growing L: coefficients of scales with L > 2048 go block-per-output
+	unsigned s_long = p->S;
+	for (unsigned s = 0; s < p->S; s++) if (p->sc[s].L > 2048) { s_long = s; break; }
+	const unsigned long long n_short = s_long < p->S ? p->sc[s_long].coef_off : p->ncoef;
+	const unsigned long long n_long = p->ncoef - n_short;
+	for (size_t t0 = 0; t0 < ntr; t0 += 65535) {
+		const unsigned ny = (unsigned)std::min<size_t>(ntr - t0, 65535);
+		const TIn *xx = d_x + t0 * ld;
+		double2 *yy = (double2 *)d_Y + t0 * p->ncoef;
+		if (n_long)
+			hipLaunchKernelGGL((k_fwd_generic<TIn, true>), dim3((unsigned)n_long, ny), dim3(256), 0, st, xx, ld, p->N, p->d_sc, p->S,
+			                   p->d_w, yy, p->ncoef, n_short, n_long);
+		if (n_short)
+			hipLaunchKernelGGL((k_fwd_generic<TIn, false>), dim3((unsigned)((n_short + 3) / 4), ny), dim3(256), 0, st, xx, ld, p->N,
+			                   p->d_sc, p->S, p->d_w, yy, p->ncoef, 0ull, n_short);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+#include "fwd_poly.h"
+#include "fwd_lds.h"
+#include "fwd_tl.h"
+
+static size_t tl_min_traces()
+{
+	static long v = -1;
+	if (v < 0) { const char *e = getenv("TSPWS_TL_MIN"); v = e ? std::max(1, atoi(e)) : 64; }
+	return (size_t)v;
+}
+
+static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS);
+
+// Work decomposition of the forward kernels.  Scales with >= 8 output groups and (D >= 64 or D a power of two) run on the
+// LDS-staged kernel; the rest (very coarse scales, odd small decimations) on the direct kernel, which aims at ~FWD_STEPS
+// tap steps per wave (more splits = shorter dependent load chains).
+int tspws_build_forward(tspws_hip_plan *p)
+{
+	const unsigned S = p->S;
+	const unsigned FWD_STEPS = 96;
+	const unsigned R = 8, FL_SLOTS_HOST = FL_WAVES * FL_PASSES;
+	unsigned woff = 0, boff = 0;
+	unsigned long long poff = 0;
+	for (unsigned s = 0; s < S; s++) {
+		ScaleDesc &d = p->sc[s];
+		d.Q = (d.L + d.D - 1) / d.D;
+		unsigned dl = 1, lg = 0;
+		while (dl < d.D && dl < 64) { dl <<= 1; lg++; }
+		d.DL = dl; d.logDL = lg;
+		d.MC = d.D > 64 ? (d.D + 63) / 64 : 1;
+		const unsigned NG = (d.Ns + R - 1) / R, GW = 64 / d.DL;
+		const bool pow2 = (d.D & (d.D - 1)) == 0;
+		d.use_lds = (NG >= 8 && (d.D >= 64 || pow2)) ? 1u : 0u;
+		d.ngw = (NG + GW - 1) / GW;
+		// direct kernel, 64 phase lanes, at least 16 outputs: 16 outputs per thread (half the operand bytes per FMA)
+		d.r16 = (!d.use_lds && d.DL == 64 && d.Ns >= 16) ? 1u : 0u;
+		if (d.r16) d.ngw = (d.Ns + 15) / 16;
+		unsigned cps;
+		if (d.use_lds) cps = 1; // one 64-phase chunk per workgroup: its taps stay resident in LDS
+		else cps = std::max(1u, (FWD_STEPS + d.Q / 2) / std::max(1u, d.Q));
+		d.cps = std::min(cps, d.MC);
+		d.nsplit = (d.MC + d.cps - 1) / d.cps;
+		d.wave_off = woff; d.lds_off = boff; d.part_off = poff;
+		const unsigned slots = (d.D <= 4) ? FL_WAVES * FL_PASSES_FINE : FL_SLOTS_HOST; // as dispatched in k_fwd_lds
+		d.lds_bps = (NG + slots * GW - 1) / (slots * GW);
+		if (d.use_lds) boff += d.lds_bps * d.nsplit; else woff += d.ngw * d.nsplit;
+		poff += (unsigned long long)d.nsplit * d.Ns;
+		d.fuse_ok = (d.use_lds && d.nsplit == 1) ? 1u : 0u;
+		p->n_fusable += d.fuse_ok;
+	}
+	p->fwd_waves = woff; p->lds_blocks = boff; p->npart = poff;
+	return build_tl_forward(p, FWD_STEPS);
+}
+
+// Decomposition for many-trace batches (fwd_tl.h): octaves (runs of scales with the same D and Ns) with at least TL_MINNS
+// outputs become trace-lane work items (voice subsets of <= TL_VMAX voices), the rest stays on the direct kernel; sc_tl is
+// the scale table of that decomposition (partial layout, fused flags, accumulate geometry).
+static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS)
+{
+	const unsigned MINNS = 17, TLSTEPS = 96; // >= 3 of the 4 waves of an output block busy; ~96 residue steps per workgroup (sweeps on 1024 x 32768 and 499 x 16501)
+	p->sc_tl = p->sc;
+	std::vector<TLItem> items;
+	std::vector<char> is_tl(p->S, 0);
+	unsigned wg = 0;
+	for (unsigned s = 0; s < p->S;) {
+		unsigned e = s + 1;
+		while (e < p->S && p->sc[e].D == p->sc[s].D && p->sc[e].Ns == p->sc[s].Ns) e++;
+		const unsigned D = p->sc[s].D, Ns = p->sc[s].Ns, nv = e - s;
+		bool ok = Ns >= MINNS;
+		std::vector<unsigned> a(nv), b(nv), qr(nv);
+		for (unsigned v = 0; v < nv && ok; v++) {
+			const ScaleDesc &d = p->sc[s + v];
+			a[v] = (unsigned)d.c / D; b[v] = (unsigned)d.c % D;
+			const long long num = (long long)d.L - 1 - (long long)b[v];
+			const long long fl = num >= 0 ? num / (long long)D : -1;
+			qr[v] = ((unsigned)(fl + 2) + 3) & ~3u;
+			if (qr[v] > TL_QMAX) ok = false;
+		}
+		if (ok) {
+			const unsigned nsub = (nv + TL_VMAX - 1) / TL_VMAX, per = (nv + nsub - 1) / nsub;
+			std::vector<TLItem> sub;
+			for (unsigned v0 = 0; v0 < nv && ok; v0 += per) {
+				const unsigned n = std::min(per, nv - v0);
+				TLItem o;
+				memset(&o, 0, sizeof o);
+				o.nv = n; o.D = D; o.Ns = Ns; o.nkb = (Ns + 31) / 32;
+				o.nsplit = (D + TL_PMAX - 1) / TL_PMAX; o.pps = (D + o.nsplit - 1) / o.nsplit; o.fused = o.nsplit == 1;
+				unsigned amax = 0, amin = ~0u, qmax = 0, rows = 0;
+				for (unsigned i = 0; i < n; i++) {
+					const unsigned v = v0 + i;
+					o.sc[i] = s + v; o.QR[i] = qr[v]; o.trow[i] = rows; o.a[i] = a[v]; o.b[i] = b[v]; o.L[i] = p->sc[s + v].L;
+					o.tap_off[i] = p->sc[s + v].tap_off; o.coef_off[i] = p->sc[s + v].coef_off;
+					rows += qr[v]; amax = std::max(amax, a[v]); amin = std::min(amin, a[v]); qmax = std::max(qmax, qr[v]);
+				}
+				o.amax = amax; o.trows = rows;
+				o.XR = (31 + qmax + (amax - amin) + 3) & ~3u;
+				if (o.XR > TL_XRMAX || rows > TL_NT) ok = false;
+				sub.push_back(o);
+			}
+			if (ok) {
+				for (TLItem &o : sub) {
+					// a workgroup should walk >= ~64 residue steps: with few residues per output block it takes several blocks
+					o.kbw = std::max(1u, std::min(o.nkb, TLSTEPS / std::max(1u, o.pps)));
+					o.wg_off = wg; wg += ((o.nkb + o.kbw - 1) / o.kbw) * o.nsplit;
+					p->tl_lds = std::max(p->tl_lds, 2 * ((size_t)o.XR * 64 * sizeof(double) + (size_t)o.trows * sizeof(double2)));
+					items.push_back(o);
+				}
+				for (unsigned v = s; v < e; v++) is_tl[v] = 1;
+			}
+		}
+		s = e;
+	}
+	// scale table of the decomposition: partial layout, direct-kernel waves, accumulate geometry
+	unsigned woff = 0, ablk = 0;
+	unsigned long long poff = 0;
+	for (unsigned s = 0; s < p->S; s++) {
+		ScaleDesc &d = p->sc_tl[s];
+		d.use_lds = 0; d.lds_off = 0;
+		if (is_tl[s]) {
+			d.nsplit = (d.D + TL_PMAX - 1) / TL_PMAX; d.cps = 1;
+			d.fuse_ok = d.nsplit == 1 ? 1u : 0u;
+		} else { // direct kernel, as in the few-trace table
+			const unsigned cps = std::max(1u, (FWD_STEPS + d.Q / 2) / std::max(1u, d.Q));
+			d.cps = std::min(cps, d.MC);
+			d.nsplit = (d.MC + d.cps - 1) / d.cps;
+			d.fuse_ok = 0;
+		}
+		d.wave_off = woff;
+		if (!is_tl[s]) woff += d.ngw * d.nsplit;
+		d.part_off = poff;
+		if (!(is_tl[s] && d.fuse_ok)) poff += (unsigned long long)d.nsplit * d.Ns; // fused scales never write partials
+		d.acc2_off = ablk;
+		ablk += d.nsplit > 1 ? (d.Ns + 3) / 4 : (d.Ns + 255) / 256; // split scales: 4 coefficients per block (k_accumulate_parts, many)
+	}
+	for (TLItem &o : items) for (unsigned i = 0; i < o.nv; i++) o.part_off[i] = p->sc_tl[o.sc[i]].part_off;
+	p->tl_n = (unsigned)items.size(); p->tl_wgs = wg; p->tl_waves = woff; p->tl_acc2_blocks = ablk; p->tl_npart = poff;
+	if (!p->tl_n) return 0;
+	HIP_TRY(hipMalloc(&p->d_sc_tl, p->S * sizeof(ScaleDesc)));
+	HIP_TRY(hipMemcpy(p->d_sc_tl, p->sc_tl.data(), p->S * sizeof(ScaleDesc), hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc(&p->d_tl, items.size() * sizeof(TLItem)));
+	HIP_TRY(hipMemcpy(p->d_tl, items.data(), items.size() * sizeof(TLItem), hipMemcpyHostToDevice));
+	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_tl<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_tl<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// few-trace forward transform into split partials (+ fused stacks)
+// ------------------------------------------------------------------------------------------
+// launch ranges of a scale range: the launch lists are ordered by scale, so a range is one run of workgroups / waves / blocks
+struct LaunchRange { unsigned lds0, lds1, wav0, wav1, acc0, acc1; };
+static LaunchRange launch_range(const tspws_hip_plan *p, ScaleRange rg)
+{
+	LaunchRange r;
+	r.lds0 = rg.on() ? p->sc[rg.s0].lds_off : 0u;
+	r.lds1 = rg.on() && rg.s1 < p->S ? p->sc[rg.s1].lds_off : p->lds_blocks;
+	r.wav0 = rg.on() ? p->sc[rg.s0].wave_off : 0u;
+	r.wav1 = rg.on() && rg.s1 < p->S ? p->sc[rg.s1].wave_off : p->fwd_waves;
+	r.acc0 = rg.on() ? p->sc[rg.s0].acc2_off : 0u;
+	r.acc1 = rg.on() && rg.s1 < p->S ? p->sc[rg.s1].acc2_off : p->acc2_blocks;
+	return r;
+}
+
+// Two independent kernels transform disjoint sets of scales: the LDS kernel (FP64-bound) and the direct kernel (coarse
+// scales, latency-bound).  They run side by side: a side stream is forked from and joined back into the caller's stream.
+template <typename TIn>
+static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double2 *d_part, hipStream_t st, FuseOut *fz, ScaleRange rg)
+{
+	if (fz) fz->applied = false;
+	const LaunchRange lr = launch_range(p, rg);
+	const bool has_lds = lr.lds1 > lr.lds0, has_poly = lr.wav1 > lr.wav0;
+	hipStream_t sp = st; // stream of the direct kernel
+	if (has_lds && has_poly) {
+		const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence; // device-local ordering only
+		if (!p->side) HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+		if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, evf));
+		if (!p->ev_join) HIP_TRY(hipEventCreateWithFlags(&p->ev_join, evf));
+		HIP_TRY(hipEventRecord(p->ev_fork, st));
+		HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+		sp = p->side;
+	}
+	// the direct kernel first: its few hundred long, latency-bound workgroups (no LDS, 116 VGPRs) get their slots and the
+	// LDS kernel's workgroups fill in beside them
+	if (has_poly) {
+		const unsigned nb = (lr.wav1 - lr.wav0 + 3) / 4;
+		if (ntr == 1) {
+			hipLaunchKernelGGL((k_fwd_poly<TIn, 1>), dim3(nb, 1), dim3(256), 0, sp, d_x, ld, 1u, p->N, p->d_sc, p->S, p->d_w, d_part,
+			                   p->npart, lr.wav1, lr.wav0);
+		} else {
+			for (size_t t0 = 0; t0 < ntr; t0 += 2 * 32768) {
+				const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, 2 * 32768);
+				hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nb, (nt + 1) / 2), dim3(256), 0, sp, d_x + t0 * ld, ld, nt, p->N, p->d_sc,
+				                   p->S, p->d_w, d_part + t0 * p->npart, p->npart, lr.wav1, lr.wav0);
+			}
+		}
+	}
+	if (has_lds) {
+		const bool fuse = fz && fz->accST && p->n_fusable;
+		// traces per workgroup: enough slices to fill the GPU (>= ~2048 workgroups), at most 32 traces per slice
+		unsigned tps = (unsigned)std::min<size_t>(ntr, 32);
+		while (tps > 1 && (size_t)p->lds_blocks * ((ntr + tps - 1) / tps) < 2048) tps = (tps + 1) / 2;
+		if (fuse) tps = fz->tps; // the caller sized the slice planes
+		const size_t per_launch = (size_t)tps * 65535;
+		for (size_t t0 = 0; t0 < ntr; t0 += per_launch) {
+			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, per_launch);
+			if (fuse)
+				hipLaunchKernelGGL((k_fwd_lds<TIn, true>), dim3(lr.lds1 - lr.lds0, (nt + tps - 1) / tps), dim3(FL_NT), FL_LDS_BYTES, st, d_x + t0 * ld, ld,
+				                   nt, tps, p->N, p->d_sc, p->S, p->d_w, d_part + t0 * p->npart, p->npart, fz->accST + (t0 / tps) * fz->stride,
+				                   fz->accPS + (t0 / tps) * fz->stride, fz->stride, lr.lds0);
+			else
+				hipLaunchKernelGGL((k_fwd_lds<TIn, false>), dim3(lr.lds1 - lr.lds0, (nt + tps - 1) / tps), dim3(FL_NT), FL_LDS_BYTES, st, d_x + t0 * ld, ld,
+				                   nt, tps, p->N, p->d_sc, p->S, p->d_w, d_part + t0 * p->npart, p->npart, (double2 *)nullptr, (double2 *)nullptr, (size_t)0, lr.lds0);
+		}
+		if (fuse) fz->applied = true;
+	}
+	if (sp != st) {
+		HIP_TRY(hipEventRecord(p->ev_join, sp));
+		HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int tspws_forward_parts_f32(tspws_hip_plan *p, const float *d_x, size_t ntr, size_t ld, double2 *d_part, hipStream_t st, FuseOut *fz, ScaleRange rg)
+{
+	return forward_parts<float>(p, d_x, ntr, ld, d_part, st, fz, rg);
+}
+int tspws_forward_parts_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, size_t ld, double2 *d_part, hipStream_t st, FuseOut *fz, ScaleRange rg)
+{
+	return forward_parts<double>(p, d_x, ntr, ld, d_part, st, fz, rg);
+}
+
+#if FL_TIMING
+// debug build only: device buffer of the per-phase wave timers of k_fwd_lds
+extern "C" int tspws_hip_fwd_timing(unsigned long long *h_out, int reset)
+{
+	static unsigned long long *d_buf = nullptr;
+	if (!d_buf) {
+		HIP_TRY(hipMalloc(&d_buf, 56 * sizeof(unsigned long long)));
+		HIP_TRY(hipMemset(d_buf, 0, 56 * sizeof(unsigned long long)));
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(fl_timing_out), &d_buf, sizeof d_buf));
+	}
+	HIP_TRY(hipDeviceSynchronize());
+	if (h_out) HIP_TRY(hipMemcpy(h_out, d_buf, 56 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	if (reset) HIP_TRY(hipMemset(d_buf, 0, 56 * sizeof(unsigned long long)));
+	return 0;
+}
+#endif
+
+// scratch for the split partials of one batch of transformed traces (bigger batches = fewer, fuller launches)
+size_t tspws_part_budget_bytes()
+{
+	static size_t v = 0;
+	if (!v) { const char *e = getenv("TSPWS_PART_MB"); v = (size_t)(e ? std::max(16, atoi(e)) : 2048) << 20; }
+	return v;
+}
+
+bool tspws_generic_forward()
+{
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("TSPWS_FWD_GENERIC"); v = (e && *e == '1') ? 1 : 0; }
+	return v == 1;
+}
+
+bool tspws_fused_forward(const tspws_hip_plan *p) { return p->n_fusable != 0; }
+
+bool tspws_many_trace_path(const tspws_hip_plan *p, size_t ntr) { return ntr >= tl_min_traces() && p->tl_n && !tspws_generic_forward(); }
+
+template <typename TIn>
+static int forward_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_Y, hipStream_t st)
+{
+	if (!p || !d_x || !d_Y) return fail(TSPWS_E_ARG, "forward: NULL");
+	if (!ntr) return 0;
+	HIP_TRY(hipSetDevice(p->device));
+	if (tspws_generic_forward()) return forward_generic<TIn>(p, d_x, ntr, ld, d_Y, st);
+	const size_t batch = std::min<size_t>(ntr, std::max<size_t>(2, ((tspws_part_budget_bytes()) / (p->npart * sizeof(double2))) & ~(size_t)1));
+	void *v;
+	int rc = scratch(p, SCR_PART, batch * p->npart * sizeof(double2), &v);
+	if (rc) return rc;
+	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
+		const size_t nb = std::min(batch, ntr - t0);
+		if ((rc = forward_parts<TIn>(p, d_x + t0 * ld, nb, ld, (double2 *)v, st, nullptr, ScaleRange()))) return rc;
+		hipLaunchKernelGGL(k_gather_parts, dim3((unsigned)((p->ncoef + 255) / 256), (unsigned)nb), dim3(256), 0, st, (const double2 *)v,
+		                   p->npart, p->d_sc, p->S, (double2 *)d_Y + t0 * p->ncoef, p->ncoef);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+extern "C" int tspws_hip_forward_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, size_t ld, double *d_Y, void *s)
+{
+	return forward_impl<double>(p, d_x, ntr, ld, d_Y, S_(s));
+}
+extern "C" int tspws_hip_forward_f32(tspws_hip_plan *p, const float *d_x, size_t ntr, size_t ld, double *d_Y, void *s)
+{
+	return forward_impl<float>(p, d_x, ntr, ld, d_Y, S_(s));
+}
+
+// ------------------------------------------------------------------------------------------
+// stack accumulation: ST += Y, PS += Y/|Y| unless the quotient is not a unit phasor
+// (ts_pws1f_lib.c:489-492).  One thread per coefficient, traces walked in order.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_accumulate(const double2 *__restrict__ Y, size_t ncoef, unsigned ntr, double2 *__restrict__ ST,
+                                                    double2 *__restrict__ PS, int zero_first)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= ncoef) return;
+	double2 st = zero_first ? make_double2(0, 0) : ST[i];
+	double2 ps = zero_first ? make_double2(0, 0) : PS[i];
+	for (unsigned b = 0; b < ntr; b++) {
+		const double2 v = Y[(size_t)b * ncoef + i];
+		st.x += v.x; st.y += v.y;
+		add_unit_phasor(ps, v);
+	}
+	ST[i] = st; PS[i] = ps;
+}
+
+extern "C" int tspws_hip_accumulate(tspws_hip_plan *p, const double *d_Y, size_t ntr, double *d_ST, double *d_PS, int zero_first, void *s)
+{
+	if (!p || !d_ST || !d_PS || (ntr && !d_Y)) return fail(TSPWS_E_ARG, "accumulate: NULL");
+	HIP_TRY(hipSetDevice(p->device));
+	hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((p->ncoef + 255) / 256)), dim3(256), 0, S_(s), (const double2 *)d_Y, p->ncoef,
+	                   (unsigned)ntr, (double2 *)d_ST, (double2 *)d_PS, zero_first);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// launches k_accumulate_parts for `nb` transformed traces; fz = what the forward launch left behind (may be NULL / not applied)
+void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb, double2 *ST, double2 *PS, int zero_first, const FuseOut *fz,
+                             unsigned nslices, hipStream_t st, unsigned nbatch, size_t y_part, size_t y_stack, bool tl, const WeightArgs *wa,
+                             ScaleRange rg)
+{
+	WeightArgs w0; w0.OUT = nullptr; w0.mode = 0; w0.K = w0.M = w0.wu = 0;
+	const bool on = fz && fz->applied;
+	const bool direct = on && fz->accST == ST; // the single slice went straight into ST / PS
+	// tl: the many-trace decomposition's scale table (partial layout, fused flags, block geometry)
+	const LaunchRange lr = launch_range(p, rg);
+	const unsigned a0 = tl ? 0u : lr.acc0, a1 = tl ? p->tl_acc2_blocks : lr.acc1;
+	if (a1 <= a0) return;
+	hipLaunchKernelGGL(k_accumulate_parts, dim3(a1 - a0, nbatch), dim3(256), 0, st, part, tl ? p->tl_npart : p->npart,
+	                   tl ? p->d_sc_tl : p->d_sc, p->S, nb, ST, PS, zero_first,
+	                   on ? (direct ? 1 : 2) : 0, on ? (const double2 *)fz->accST : nullptr, on ? (const double2 *)fz->accPS : nullptr,
+	                   on ? fz->stride : (size_t)0, nslices, y_part, y_stack, tl ? 1 : 0, wa ? *wa : w0, a0);
+}
+
+// slice length of the fused forward kernel for a batch of nb traces: whole batch when it is small (two-stage: the K
+// partial stacks -> ONE slice that writes ST / PS directly), else 32 traces per slice
+static unsigned fuse_tps(size_t nb) { return (unsigned)std::min<size_t>(nb, 32); }
+
+// Many traces (single-stage stacks): trace-lane kernel on the transposed batch (fwd_tl.h); the stacks of the fused scales
+// come back as one plane pair per 64-trace block, the split / coarse scales as per-trace partials in the tl layout.
+template <typename TIn>
+static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, hipStream_t st, bool keep,
+                     const WeightArgs *wa, bool *weighted)
+{
+	int rc;
+	void *v;
+	// traces per batch: transposed copy <= 1 GiB, at most 4096 (64 plane pairs), a multiple of 64
+	size_t batch = std::min<size_t>(4096, std::max<size_t>(64, (((size_t)1 << 30) / ((size_t)p->N * sizeof(TIn))) & ~(size_t)63));
+	if (p->tl_npart) batch = std::min(batch, std::max<size_t>(64, (tspws_part_budget_bytes() / (p->tl_npart * sizeof(double2))) & ~(size_t)63));
+	if (const char *e = getenv("TSPWS_TL_BATCH")) batch = std::max<size_t>(64, (size_t)atoi(e) & ~(size_t)63); // tests: force several batches
+	batch = std::min(batch, (ntr + 63) & ~(size_t)63);
+	const size_t nblk_max = batch / 64;
+	if ((rc = scratch(p, SCR_XT, (size_t)p->N * batch * sizeof(TIn), &v))) return rc;
+	TIn *xT = (TIn *)v;
+	if ((rc = scratch(p, SCR_FZ, nblk_max * 2 * p->ncoef * sizeof(double2), &v))) return rc;
+	double2 *planes = (double2 *)v;
+	double2 *part = nullptr;
+	if (p->tl_npart) { if ((rc = scratch(p, SCR_PART, batch * p->tl_npart * sizeof(double2), &v))) return rc; part = (double2 *)v; }
+	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
+		const unsigned nb = (unsigned)std::min(batch, ntr - t0), nblk = (nb + 63) / 64, TP = nblk * 64;
+		const TIn *xb = d_x + t0 * ld;
+		hipLaunchKernelGGL((k_transpose_traces<TIn>), dim3((p->N + 63) / 64, nblk), dim3(256), 0, st, xb, ld, nb, p->N, TP, xT);
+		hipLaunchKernelGGL((k_fwd_tl<TIn>), dim3(p->tl_wgs, nblk), dim3(TL_NT), p->tl_lds, st, (const TIn *)xT, TP, nb, p->N, p->d_tl, p->tl_n, p->d_w,
+		                   planes, planes + p->ncoef, 2 * p->ncoef, part, p->tl_npart);
+		if (p->tl_waves) { // scales with too few outputs for the trace-lane kernel: direct kernel, tl partial layout
+			const unsigned nbw = (p->tl_waves + 3) / 4;
+			for (size_t u0 = 0; u0 < nb; u0 += 2 * 32768) {
+				const unsigned nt = (unsigned)std::min<size_t>(nb - u0, 2 * 32768);
+				hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nbw, (nt + 1) / 2), dim3(256), 0, st, xb + u0 * ld, ld, nt, p->N, p->d_sc_tl, p->S, p->d_w,
+				                   part + u0 * p->tl_npart, p->tl_npart, p->tl_waves);
+			}
+		}
+		FuseOut fz;
+		fz.accST = planes; fz.accPS = planes + p->ncoef; fz.stride = 2 * p->ncoef; fz.tps = 64; fz.applied = true;
+		const bool last = t0 + batch >= ntr; // the launch that completes the stacks also weights them (wa)
+		tspws_launch_accumulate(p, part, nb, (double2 *)d_ST, (double2 *)d_PS, (t0 == 0 && !keep) ? 1 : 0, &fz, nblk, st, 1, 0, 0, true, last && !keep ? wa : nullptr, ScaleRange());
+		if (last && !keep && wa && wa->OUT && weighted) *weighted = true;
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+
+template <typename TIn>
+static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, hipStream_t st, bool keep,
+                       const WeightArgs *wa, bool *weighted, ScaleRange rg)
+{ // keep: add to the stacks already in d_ST / d_PS instead of starting from zero
+  // wa: weighting to apply where the stacks are completed (same kernel launch); *weighted tells whether that happened
+	HIP_TRY(hipSetDevice(p->device));
+	if (weighted) *weighted = false;
+	if (!rg.on() && tspws_many_trace_path(p, ntr)) return stacks_tl<TIn>(p, d_x, ntr, ld, d_ST, d_PS, st, keep, wa, weighted);
+	if (!ntr) { if (!keep) { HIP_TRY(hipMemsetAsync(d_ST, 0, p->ncoef * 16, st)); HIP_TRY(hipMemsetAsync(d_PS, 0, p->ncoef * 16, st)); } return 0; }
+	int rc;
+	if (tspws_generic_forward()) {
+		size_t batch = std::max<size_t>(1, ((size_t)256 << 20) / (p->ncoef * sizeof(double2)));
+		batch = std::min(batch, ntr);
+		void *d_Y = nullptr;
+		if ((rc = scratch(p, SCR_Y, batch * p->ncoef * sizeof(double2), &d_Y))) return rc;
+		for (size_t t0 = 0; t0 < ntr; t0 += batch) {
+			const size_t nb = std::min(batch, ntr - t0);
+			if ((rc = forward_generic<TIn>(p, d_x + t0 * ld, nb, ld, (double *)d_Y, st))) return rc;
+			if ((rc = tspws_hip_accumulate(p, (const double *)d_Y, nb, d_ST, d_PS, t0 == 0 && !keep, (void *)st))) return rc;
+		}
+		return 0;
+	}
+	// trace batch sized to the partial-coefficient scratch budget (even, for the 2-trace tiles)
+	const size_t batch = std::min<size_t>(ntr, std::max<size_t>(2, ((tspws_part_budget_bytes()) / (p->npart * sizeof(double2))) & ~(size_t)1));
+	void *v;
+	if ((rc = scratch(p, SCR_PART, batch * p->npart * sizeof(double2), &v))) return rc;
+	const bool fuse = p->n_fusable != 0;
+	void *vz = nullptr;
+	if (fuse) { // slice planes of the largest batch (unused when the only slice writes ST / PS directly)
+		const unsigned tps = fuse_tps(batch);
+		const size_t nsl = (batch + tps - 1) / tps;
+		if (!(nsl == 1 && !keep && batch >= ntr) && (rc = scratch(p, SCR_FZ, nsl * 2 * p->ncoef * sizeof(double2), &vz))) return rc;
+	}
+	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
+		const size_t nb = std::min(batch, ntr - t0);
+		const int zero_first = (t0 == 0 && !keep) ? 1 : 0;
+		FuseOut fz;
+		unsigned nsl = 0;
+		if (fuse) {
+			fz.tps = fuse_tps(nb);
+			nsl = (unsigned)((nb + fz.tps - 1) / fz.tps);
+			if (nsl == 1 && zero_first) { fz.accST = (double2 *)d_ST; fz.accPS = (double2 *)d_PS; fz.stride = 0; }
+			else { fz.accST = (double2 *)vz; fz.accPS = (double2 *)vz + p->ncoef; fz.stride = 2 * p->ncoef; }
+		}
+		if ((rc = forward_parts<TIn>(p, d_x + t0 * ld, nb, ld, (double2 *)v, st, fuse ? &fz : nullptr, rg))) return rc;
+		const bool all = nb == ntr && !keep; // one batch holds every trace: the accumulation completes the stacks
+		tspws_launch_accumulate(p, (const double2 *)v, (unsigned)nb, (double2 *)d_ST, (double2 *)d_PS, zero_first, &fz, nsl, st, 1, 0, 0, false, all ? wa : nullptr, rg);
+		if (all && wa && wa->OUT && weighted) *weighted = true;
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int tspws_stacks_f32(tspws_hip_plan *p, const float *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, hipStream_t st, bool keep,
+                     const WeightArgs *wa, bool *weighted, ScaleRange rg)
+{
+	return stacks_impl<float>(p, d_x, ntr, ld, d_ST, d_PS, st, keep, wa, weighted, rg);
+}
+int tspws_stacks_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, hipStream_t st, bool keep,
+                     const WeightArgs *wa, bool *weighted, ScaleRange rg)
+{
+	return stacks_impl<double>(p, d_x, ntr, ld, d_ST, d_PS, st, keep, wa, weighted, rg);
+}
+
+extern "C" int tspws_hip_stacks_double(tspws_hip_plan *p, const double *d_P, unsigned K, size_t ldP, double *d_ST, double *d_PS, void *s)
+{
+	if (!p || !d_P || !d_ST || !d_PS) return fail(TSPWS_E_ARG, "stacks_double: NULL");
+	return stacks_impl<double>(p, d_P, K, ldP, d_ST, d_PS, S_(s), false, nullptr, nullptr, ScaleRange());
+}
+
+extern "C" int tspws_hip_stacks_float(tspws_hip_plan *p, const float *d_x, size_t mtr, size_t ld, double *d_ST, double *d_PS, void *s)
+{
+	if (!p || !d_x || !d_ST || !d_PS) return fail(TSPWS_E_ARG, "stacks_float: NULL");
+	return stacks_impl<float>(p, d_x, mtr, ld, d_ST, d_PS, S_(s), false, nullptr, nullptr, ScaleRange());
+}

@@ -1,4 +1,4 @@
-// fwd_lds.h -- LDS-staged polyphase forward frame CWT for gfx950 (included by tspws_hip.hip).
+// fwd_lds.h -- LDS-staged polyphase forward frame CWT for gfx950 (included by forward.hip).
 //
 // Same decomposition as fwd_poly.h (thread = 8 consecutive outputs of one phase, sliding register window),
 // but the operands come from LDS: a 256-thread workgroup owns 8 "group slots" (4 waves x 2 passes) of ONE
@@ -543,13 +543,13 @@ template <typename TIn, bool FUSE>
 __global__ void __launch_bounds__(FL_NT, 2) k_fwd_lds(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
                                                  const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
                                                  double2 *__restrict__ part, size_t npart, double2 *__restrict__ accST,
-                                                 double2 *__restrict__ accPS, size_t acc_stride, unsigned rev, unsigned bid0)
+                                                 double2 *__restrict__ accPS, size_t acc_stride, unsigned bid0)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	// Workgroups are dispatched in blockIdx order and a launch is a few rounds of ~46 us workgroups, so the LAST round sets
 	// the tail: walk the scales from coarse to fine -- the fine scales (D <= 4: one slot per wave, half the work) finish
 	// the launch with short workgroups.
 	// bid0: first workgroup of the launch in the plan's list (a launch may cover a sub-range of the scales: sharded finish)
-	const unsigned bid = bid0 + (rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x);
+	const unsigned bid = bid0 + (gridDim.x - 1u - blockIdx.x);
 	fwd_lds_workgroup<TIn, FUSE>(bid, blockIdx.y, smem, x, ld, ntr, tps, N, sc, S, w, part, npart, accST, accPS, acc_stride);
 }

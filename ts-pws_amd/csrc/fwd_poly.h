@@ -1,4 +1,4 @@
-// fwd_poly.h -- register-tiled polyphase forward frame CWT for gfx950 (included by tspws_hip.hip).
+// fwd_poly.h -- register-tiled polyphase forward frame CWT for gfx950 (included by forward.hip).
 //
 //   Y_s[k] = conj( sum_l x[(k D - c + l) mod N] w_s[l] )                  (cdotx.c:44-70)
 //
@@ -391,23 +391,6 @@ __global__ void __launch_bounds__(256) k_fwd_poly(const TIn *__restrict__ x, siz
 	else fwd_poly_wave<TIn, B, FWD_R, FWD_R>(x, ld, ntr, N, d, w, part, npart, wid - d.wave_off, lane);
 }
 
-// PS += Y/|Y| unless the quotient is not a unit phasor (Y == 0 gives NaN and is skipped), ts_pws1f_lib.c:491-492.
-// Fast path: one rsqrt instead of hypot + two divisions whenever |Y|^2 is comfortably inside the double range;
-// the literal form handles the rest (zeros, subnormals, huge values).
-__device__ __forceinline__ void add_unit_phasor(double2 &ps, const double2 v)
-{
-	const double r2 = fma(v.x, v.x, v.y * v.y);
-	if (r2 > 1e-280 && r2 < 1e280) {
-		const double inv = rsqrt(r2);
-		ps.x = fma(v.x, inv, ps.x);
-		ps.y = fma(v.y, inv, ps.y);
-	} else {
-		const double r = hypot(v.x, v.y);
-		const double ux = v.x / r, uy = v.y / r;
-		if (ux * ux + uy * uy <= 1.001) { ps.x += ux; ps.y += uy; }
-	}
-}
-
 // Y[b][coef] = sum over the scale's split partials (plain coefficient layout; API / tests)
 __global__ void __launch_bounds__(256) k_gather_parts(const double2 *__restrict__ part, size_t npart, const ScaleDesc *__restrict__ sc,
                                                       unsigned S, double2 *__restrict__ Y, size_t ncoef)
@@ -420,36 +403,6 @@ __global__ void __launch_bounds__(256) k_gather_parts(const double2 *__restrict_
 	double2 a = p[0];
 	for (unsigned sp = 1; sp < d.nsplit; sp++) { const double2 t = p[(size_t)sp * d.Ns]; a.x += t.x; a.y += t.y; }
 	Y[(size_t)blockIdx.y * ncoef + i] = a;
-}
-
-// Phase weighting of one coefficient (tspws_biased :909-943, tspws_unbiased :965-984).
-// mode 0: wu == 2 biased, 1: wu == 1, 2: general power, 3: unbiased (K > 1); K = stacked units, M = traces.
-struct WeightArgs {
-	double2 *OUT;   // nullptr: no weighting
-	int mode;
-	double K, M, wu;
-};
-__device__ __forceinline__ double2 weight_value(const double2 st, const double2 ps, const int mode, const double K, const double M, const double wu)
-{
-	double a;
-	if (mode == 0) {
-		const double g = 1. / (K * K * M);
-		a = (ps.x * ps.x + ps.y * ps.y) * g;
-		return make_double2(a * st.x, a * st.y);
-	} else if (mode == 1) {
-		const double g = 1. / (K * M);
-		const double r = hypot(ps.x, ps.y);
-		return make_double2(st.x * r * g, st.y * r * g);
-	} else if (mode == 2) {
-		a = hypot(ps.x, ps.y) / K;
-		a = pow(a, wu);
-		return make_double2(st.x * a / M, st.y * a / M);
-	}
-	const double iK = 1. / K, iK1 = 1. / (K - 1), iM = 1. / M;
-	const double px = ps.x * iK, py = ps.y * iK;
-	a = px * px + py * py;
-	a = (K * a - 1) * iK1;
-	return make_double2(st.x * a * iM, st.y * a * iM);
 }
 
 // ST += sum_b Y_b ; PS += sum_b Y_b/|Y_b|  straight from the split partials (ts_pws1f_lib.c:489-492); scales the fused

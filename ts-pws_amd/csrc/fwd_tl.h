@@ -1,4 +1,4 @@
-// fwd_tl.h -- "trace-lane" forward frame CWT + phase stack for MANY traces (included by tspws_hip.hip).
+// fwd_tl.h -- "trace-lane" forward frame CWT + phase stack for MANY traces (included by forward.hip).
 //
 //   Y_s[k] = conj( sum_l x[(k D - c_s + l) mod N] w_s[l] )                  (cdotx.c:44-70)
 //   ST += Y,  PS += Y / |Y|                                                 (ts_pws1f_lib.c:489-492)

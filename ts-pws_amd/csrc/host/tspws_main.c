@@ -11,6 +11,11 @@
  * (:159-169), single- and two-stage stacks (:194-242), biased / unbiased
  * weighting (:226-228), convergence curves (:247-314), random subsampling
  * (:324-333), two-stage jackknife (:335-345).
+ *
+ * The frame (plan) and the device trace buffer of the last call are kept: a
+ * caller that stacks many ensembles of the same length with the same wavelet
+ * parameters (the CLI in a loop, the MATLAB gateway) pays for the frame once.
+ * tspws_main_release() frees them; TSPWS_PLAN_CACHE=0 disables the cache.
  */
 #include <math.h>
 #include <stdio.h>
@@ -26,6 +31,60 @@ static int device_from_env(void)
 }
 
 #define TRY(call) do { rc = (call); if (rc) goto done; } while (0)
+
+/* ---- frame / trace-buffer cache (one entry: the last call's) ------------------------------------------------------ */
+static struct {
+	tspws_hip_plan *plan;
+	int type, uni, dev;
+	unsigned J, V, N;
+	double s0, b0, w0;
+	float *d_sig;          /* device trace buffer, grown on demand */
+	size_t sig_bytes;
+} g_cache;
+
+static int cache_enabled(void)
+{
+	const char *e = getenv("TSPWS_PLAN_CACHE");
+	return !(e && *e == '0');
+}
+
+void tspws_main_release(void)
+{
+	tspws_hip_plan_destroy(g_cache.plan);
+	tspws_hip_free(g_cache.d_sig);
+	memset(&g_cache, 0, sizeof g_cache);
+}
+
+/* the frame of (type, J, V, N, s0, b0, w0, uni) on `dev`: the cached one when every parameter matches bit for bit */
+static int get_plan(tspws_hip_plan **plan, const t_tsPWS *p, unsigned N, int dev)
+{
+	if (g_cache.plan && g_cache.type == p->type && g_cache.J == p->J && g_cache.V == p->V && g_cache.N == N && g_cache.s0 == p->s0 &&
+	    g_cache.b0 == p->b0 && g_cache.w0 == p->w0 && g_cache.uni == (int)p->uni && g_cache.dev == dev) {
+		*plan = g_cache.plan;
+		return 0;
+	}
+	tspws_hip_plan *fresh = NULL;
+	int rc = tspws_hip_plan_create(&fresh, p->type, p->J, p->V, N, p->s0, p->b0, p->w0, (int)p->uni, dev);
+	if (rc) return rc;
+	tspws_hip_plan_destroy(g_cache.plan);
+	g_cache.plan = fresh;
+	g_cache.type = p->type; g_cache.J = p->J; g_cache.V = p->V; g_cache.N = N; g_cache.s0 = p->s0; g_cache.b0 = p->b0; g_cache.w0 = p->w0;
+	g_cache.uni = (int)p->uni; g_cache.dev = dev;
+	*plan = fresh;
+	return 0;
+}
+
+static int get_trace_buffer(float **d_sig, size_t bytes, int dev)
+{
+	if (g_cache.d_sig && (g_cache.sig_bytes < bytes || g_cache.dev != dev)) { tspws_hip_free(g_cache.d_sig); g_cache.d_sig = NULL; g_cache.sig_bytes = 0; }
+	if (!g_cache.d_sig) {
+		int rc = tspws_hip_alloc((void **)&g_cache.d_sig, bytes, dev);
+		if (rc) return rc;
+		g_cache.sig_bytes = bytes;
+	}
+	*d_sig = g_cache.d_sig;
+	return 0;
+}
 
 int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 {
@@ -78,12 +137,13 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 	tspws_hip_plan *plan = NULL;
 	float *d_sig = NULL, *d_out = NULL, *d_jk = NULL, *d_ref = NULL, *d_steps_ts = NULL, *d_steps_ls = NULL;
 	char *sel = NULL;
+	unsigned *jk_mtr = NULL;
 	float *stage = NULL;
 	const size_t ld = (size_t)max;
 
 	if (!mtr) return 0; /* the reference builds the family and returns 0 without touching out (:194) */
 
-	int frame_rc = tspws_hip_plan_create(&plan, tspws->type, tspws->J, tspws->V, nsamp, tspws->s0, tspws->b0, tspws->w0, (int)tspws->uni, dev);
+	int frame_rc = get_plan(&plan, tspws, nsamp, dev);
 	if (frame_rc) {
 		printf("tspws_main: cannot build the wavelet frame (%s)\n", tspws_hip_last_error());
 		if (frame_rc == TSPWS_E_NODEV) return frame_rc;
@@ -93,7 +153,7 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 		if (!do_fold && !tspws->lrm) return TSPWS_E_NOMEM;
 	}
 
-	TRY(tspws_hip_alloc((void **)&d_sig, mtr * ld * sizeof(float), dev));
+	TRY(get_trace_buffer(&d_sig, mtr * ld * sizeof(float), dev));
 	TRY(tspws_hip_upload(d_sig, in->sigall, mtr * ld * sizeof(float), NULL));
 
 	/* in-place prologue on the device, then mirrored back: the caller sees the same mutated
@@ -101,24 +161,26 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 	if (do_fold) TRY(tspws_hip_fold(d_sig, mtr, (size_t)max, ld, NULL));
 	if (tspws->lrm) TRY(tspws_hip_remove_mean(d_sig, mtr, (size_t)max, ld, NULL));
 	if (do_fold || tspws->lrm) TRY(tspws_hip_download(in->sigall, d_sig, mtr * ld * sizeof(float), NULL));
-	if (frame_rc) { tspws_hip_free(d_sig); return TSPWS_E_NOMEM; }
+	if (frame_rc) { rc = TSPWS_E_NOMEM; goto done_quiet; }
 	TRY(tspws_hip_alloc((void **)&d_out, 2 * ld * sizeof(float), dev));
 
-	/* jackknife masks first (host, :385-430): announced to the engine, the stack below streams the traces once for its own
-	 * groups and for every replica */
+	/* jackknife masks first (host, :385-430): the stack below then streams the traces ONCE for its own groups and for every
+	 * replica; the replicas stay on the device until the point where the reference computes them (:335-345) */
 	int jk_ready = 0;
 	if (tspws->jackknife_n > 0 && tspws->jackknife_d > 0 && tspws->Kmax && tspws->Kmax <= mtr && out->M && out->ls_subsmpl &&
 	    out->tsPWS_subsmpl && out->mtr_subsmpl) {
-		sel = (char *)malloc((size_t)out->M * mtr);
-		if (!sel) { rc = TSPWS_E_NOMEM; goto done; }
-		if (tspws_jackknife_plan(sel, in->time, mtr, tspws->jackknife_d, tspws->jackknife_n, out->M) == 0) {
+		const unsigned C = out->M;
+		sel = (char *)malloc((size_t)C * mtr);
+		jk_mtr = (unsigned *)malloc((size_t)C * sizeof(unsigned));
+		if (!sel || !jk_mtr) { rc = TSPWS_E_NOMEM; goto done; }
+		if (tspws_jackknife_plan(sel, in->time, mtr, tspws->jackknife_d, tspws->jackknife_n, C) == 0) {
 			jk_ready = 1;
-			TRY(tspws_hip_jackknife_prepare(plan, tspws, sel, out->M, mtr));
+			rc = tspws_hip_alloc((void **)&d_jk, 2 * (size_t)C * ld * sizeof(float), dev);
+			if (!rc) rc = tspws_hip_stack_jackknife(plan, tspws, d_sig, ld, mtr, d_out, d_out + ld, sel, C, d_jk, d_jk + (size_t)C * ld, jk_mtr, NULL);
+			if (rc) goto done;
 		}
 	}
-
-	TRY(tspws_hip_stack_local(plan, tspws, d_sig, ld, mtr, 0, mtr, NULL));
-	TRY(tspws_hip_stack_finish(plan, tspws, mtr, d_out, d_out + ld, NULL));
+	if (!jk_ready) TRY(tspws_hip_stack(plan, tspws, d_sig, ld, mtr, d_out, d_out + ld, NULL));
 	TRY(tspws_hip_download(out->ls, d_out, ld * sizeof(float), NULL));
 	TRY(tspws_hip_download(out->tsPWS, d_out + ld, ld * sizeof(float), NULL));
 
@@ -141,31 +203,31 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 	/* random subsampling, :324-333 */
 	if (tspws->subsmpl_N > 0 && tspws->subsmpl_p > 0 && out->ls_subsmpl && out->tsPWS_subsmpl) {
 		const unsigned M = tspws->subsmpl_N;
-		TRY(tspws_hip_alloc((void **)&d_jk, 2 * (size_t)M * ld * sizeof(float), dev));
-		TRY(tspws_hip_subsample(plan, tspws, d_sig, ld, mtr, M, d_jk, d_jk + (size_t)M * ld, NULL));
-		stage = (float *)malloc(2 * (size_t)M * ld * sizeof(float));
-		if (!stage) { rc = TSPWS_E_NOMEM; goto done; }
-		TRY(tspws_hip_download(stage, d_jk, 2 * (size_t)M * ld * sizeof(float), NULL));
+		float *d_sub = NULL;
+		rc = tspws_hip_alloc((void **)&d_sub, 2 * (size_t)M * ld * sizeof(float), dev);
+		if (!rc) rc = tspws_hip_subsample(plan, tspws, d_sig, ld, mtr, M, d_sub, d_sub + (size_t)M * ld, NULL);
+		if (!rc) { stage = (float *)malloc(2 * (size_t)M * ld * sizeof(float)); if (!stage) rc = TSPWS_E_NOMEM; }
+		if (!rc) rc = tspws_hip_download(stage, d_sub, 2 * (size_t)M * ld * sizeof(float), NULL);
+		tspws_hip_free(d_sub);
+		if (rc) goto done;
 		for (unsigned m = 0; m < M; m++) {
 			memcpy(out->ls_subsmpl[m], stage + (size_t)m * ld, ld * sizeof(float));
 			memcpy(out->tsPWS_subsmpl[m], stage + ((size_t)M + m) * ld, ld * sizeof(float));
 		}
 		free(stage); stage = NULL;
-		tspws_hip_free(d_jk); d_jk = NULL;
 	}
 
 	if (tspws->jackknife_n > 0 && tspws->jackknife_d > 0 && tspws->Kmax && tspws->Kmax <= mtr) {
 		const unsigned C = out->M;
 		if (C && out->ls_subsmpl && out->tsPWS_subsmpl && out->mtr_subsmpl) {
-			if (jk_ready) {
-				TRY(tspws_hip_alloc((void **)&d_jk, 2 * (size_t)C * ld * sizeof(float), dev));
-				TRY(tspws_hip_jackknife(plan, tspws, d_sig, ld, mtr, sel, C, d_jk, d_jk + (size_t)C * ld, out->mtr_subsmpl, NULL));
+			if (jk_ready) { /* computed with the stack (one pass over the traces); handed over here, where the reference does */
 				stage = (float *)malloc(2 * (size_t)C * ld * sizeof(float));
 				if (!stage) { rc = TSPWS_E_NOMEM; goto done; }
 				TRY(tspws_hip_download(stage, d_jk, 2 * (size_t)C * ld * sizeof(float), NULL));
 				for (unsigned c = 0; c < C; c++) {
 					memcpy(out->ls_subsmpl[c], stage + (size_t)c * ld, ld * sizeof(float));
 					memcpy(out->tsPWS_subsmpl[c], stage + ((size_t)C + c) * ld, ld * sizeof(float));
+					out->mtr_subsmpl[c] = jk_mtr[c];
 				}
 			} else
 				printf("tspws_main: jackknife needs trace start times (binary input); replicas left untouched.\n");
@@ -174,14 +236,15 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 
 done:
 	if (rc) printf("tspws_main: HIP path failed (%d: %s)\n", rc, tspws_hip_last_error());
+done_quiet:
 	free(stage);
+	free(jk_mtr);
 	free(sel);
 	tspws_hip_free(d_steps_ls);
 	tspws_hip_free(d_steps_ts);
 	tspws_hip_free(d_ref);
 	tspws_hip_free(d_jk);
 	tspws_hip_free(d_out);
-	tspws_hip_free(d_sig);
-	tspws_hip_plan_destroy(plan);
+	if (!cache_enabled()) tspws_main_release(); /* else: the frame and the trace buffer serve the next call */
 	return rc;
 }

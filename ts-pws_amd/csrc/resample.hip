@@ -1,0 +1,553 @@
+// resample.hip -- jackknife (two-stage), random subsampling, convergence curves.
+// Reference citations are relative to /root/reference/src.
+#include "tspws_internal.h"
+
+#define is_two_stage tspws_is_two_stage
+
+// ------------------------------------------------------------------------------------------
+// jackknife (TwoStage_jackknife_float, ts_pws1f_lib.c:719-831)
+// ------------------------------------------------------------------------------------------
+extern "C" int tspws_jackknife_plan(char *sel, const time_t *tm, size_t mtr, unsigned d, unsigned n, unsigned C)
+{
+	if (!sel || !tm) return 1;
+	if (tm[0] == 0) return -2;
+	std::vector<unsigned> bin(mtr), comb(d);
+	for (size_t i = 0; i < mtr; i++) {
+		struct tm g;
+		gmtime_r(tm + i, &g);
+		bin[i] = (unsigned)floor((double)(g.tm_yday * (int)n) / 365.); // day-of-year bin, :398-401
+	}
+	for (unsigned i = 0; i < d; i++) comb[i] = i;
+	for (unsigned c = 0; c < C; c++) {
+		if (c) { // lexicographic successor of the deleted-bin set, :405-414
+			int i = (int)d - 1;
+			while (i >= 0 && comb[i] >= n - d + (unsigned)i) i--;
+			if (i < 0) break;
+			comb[i]++;
+			for (unsigned j = (unsigned)i + 1; j < d; j++) comb[j] = comb[j - 1] + 1;
+		}
+		char *row = sel + (size_t)c * mtr;
+		for (size_t t = 0; t < mtr; t++) {
+			row[t] = 1;
+			for (unsigned i = 0; i < d; i++) if (bin[t] == comb[i]) row[t] = 0;
+		}
+	}
+	return 0;
+}
+
+// P_c[g][n] = sum of class sums whose signature sends them to group g of replica c.
+// cls_of[(c*Kmax+g)] lists are given as CSR: row_ptr / cols.
+__global__ void __launch_bounds__(256) k_combine_classes(const double *__restrict__ cls, size_t ldc, const unsigned *__restrict__ row_ptr,
+                                                         const unsigned *__restrict__ cols, double *__restrict__ P, size_t N)
+{
+	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (n >= N) return;
+	const unsigned row = blockIdx.y;
+	double acc = 0;
+	for (unsigned j = row_ptr[row]; j < row_ptr[row + 1]; j++) acc += cls[(size_t)cols[j] * ldc + n];
+	P[(size_t)row * N + n] = acc;
+}
+
+// replica linear stack in the time domain, :799-811: (sum_g P[g]) * (1/K)
+__global__ void __launch_bounds__(256) k_jk_linear(const double *__restrict__ P, unsigned Kmax, size_t N, const double *__restrict__ Mv,
+                                                   float *__restrict__ out)
+{
+	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (n >= N) return;
+	P += (size_t)blockIdx.y * Kmax * N; out += (size_t)blockIdx.y * N; // blockIdx.y = replica
+	const double invK = 1. / Mv[blockIdx.y];
+	double acc = P[n];
+	for (unsigned g = 1; g < Kmax; g++) acc += P[(size_t)g * N + n];
+	out[n] = (float)(acc * invK);
+}
+
+// ONE pass over the traces for any number of masked two-stage replicas: traces with the same destination group in every
+// replica form a class (maximal runs of consecutive traces; equal signatures of separate runs share a class), the
+// streaming kernel sums every class once, and each (replica, group) partial stack is a sum of class sums.
+// with_main: the plain two-stage groups of ALL traces (ts_pws1f_lib.c:876) are one more signature column.
+// Sharded ensembles: d_x holds traces [first, first + mtr_local) of the mtr the selection refers to; signatures come from
+// the GLOBAL trace index (a trace's group in a replica is its rank among ALL selected traces, :766), the sums run over the
+// shard's traces only, so the rows of all shards add up to the rows of the whole ensemble.
+//
+// A ClassSums object belongs to ONE call: it owns the host tables whose uploads may still be in flight, so the call
+// synchronises its stream before the object goes out of scope (cs_done).
+struct ClassSums {
+	unsigned C = 0, KM = 0, ncls = 0;
+	std::vector<std::vector<unsigned short>> sig;   // per class: group in each replica (0xFFFF = deleted) [+ plain group]
+	std::vector<size_t> Kc;                         // traces per replica
+	std::vector<Chunk> chunks;
+	std::vector<unsigned> row_first;
+	std::vector<std::vector<unsigned>> tabs;        // CSR tables of the combine passes (row_ptr | cols), one per pass
+	size_t tab_used = 0;                            // unsigneds of SCR_JKTAB handed out so far
+};
+
+static int cs_done(hipStream_t st) { HIP_TRY(hipStreamSynchronize(st)); return 0; }
+
+static int class_sums(tspws_hip_plan *pl, ClassSums &cs, unsigned KM, const float *d_x, size_t ld, size_t mtr, const char *h_sel, unsigned C,
+                      bool with_main, hipStream_t st, size_t first, size_t mtr_local)
+{
+	if (first > mtr || mtr_local > mtr - first) return fail(TSPWS_E_ARG, "class sums: shard outside the ensemble");
+	const size_t lo = first, hi = first + mtr_local;
+	const size_t N = pl->N;
+	const unsigned W = C + (with_main ? 1u : 0u);
+	// signature of trace i: group index in every replica (0xFFFF = deleted)
+	cs.Kc.assign(C, 0);
+	for (unsigned c = 0; c < C; c++) for (size_t i = 0; i < mtr; i++) if (h_sel[(size_t)c * mtr + i] == 1) cs.Kc[c]++;
+	std::vector<unsigned short> sig((size_t)mtr * W);
+	for (unsigned c = 0; c < C; c++) {
+		size_t k = 0;
+		for (size_t i = 0; i < mtr; i++) {
+			if (h_sel[(size_t)c * mtr + i] == 1) {
+				sig[i * W + c] = (unsigned short)floor((double)(k * KM) / (double)cs.Kc[c]); // :766
+				k++;
+			} else sig[i * W + c] = 0xFFFF;
+		}
+	}
+	if (with_main) for (size_t i = 0; i < mtr; i++) sig[i * W + C] = (unsigned short)std::min<size_t>((size_t)floor((double)(i * KM) / (double)mtr), KM - 1);
+	cs.sig.clear(); cs.chunks.clear();
+	std::vector<std::vector<Chunk>> cls_chunks;
+	const unsigned clen = tspws_chunk_len_for(N, std::max<size_t>(mtr_local, 1));
+	for (size_t i = lo; i < hi;) {
+		size_t j = i + 1;
+		while (j < hi && !memcmp(&sig[i * W], &sig[j * W], W * sizeof(unsigned short))) j++;
+		std::vector<unsigned short> sg(sig.begin() + i * W, sig.begin() + (i + 1) * W);
+		size_t id = 0;
+		for (; id < cs.sig.size(); id++) if (cs.sig[id] == sg) break;
+		if (id == cs.sig.size()) { cs.sig.push_back(sg); cls_chunks.emplace_back(); }
+		for (size_t t = i; t < j; t += clen) {
+			Chunk c; c.t0 = t - lo; c.count = (unsigned)std::min<size_t>(clen, j - t); c.row = (unsigned)id; // t0: row of d_x
+			cls_chunks[id].push_back(c);
+		}
+		i = j;
+	}
+	const unsigned ncls = (unsigned)cs.sig.size();
+	cs.row_first.assign(ncls + 1, 0);
+	for (unsigned id = 0; id < ncls; id++) {
+		cs.row_first[id] = (unsigned)cs.chunks.size();
+		cs.chunks.insert(cs.chunks.end(), cls_chunks[id].begin(), cls_chunks[id].end());
+	}
+	cs.row_first[ncls] = (unsigned)cs.chunks.size();
+	int rc;
+	void *v;
+	if ((rc = scratch(pl, SCR_CLS, std::max<size_t>((size_t)ncls * N, 1) * sizeof(double), &v))) return rc;
+	if (ncls && (rc = tspws_run_chunks(pl, d_x, ld, N, cs.chunks, cs.row_first, ncls, (double *)v, N, st, false))) return rc; // own table: not the cached one
+	// room for the CSR tables of every combine pass of this call (each pass gets its own piece of the block)
+	const size_t tab_max = 2 * ((size_t)W * KM + 2 + (size_t)W * ncls);
+	if ((rc = scratch(pl, SCR_JKTAB, tab_max * sizeof(unsigned), &v))) return rc;
+	cs.C = C; cs.KM = KM; cs.ncls = ncls; cs.tab_used = 0;
+	return 0;
+}
+
+// d_P[(col - col0) * KM + g][n] = sum of the class sums whose signature column `col` is g, for col in [col0, col1)
+static int combine_classes(tspws_hip_plan *pl, ClassSums &cs, unsigned col0, unsigned col1, double *d_P, hipStream_t st)
+{
+	const unsigned KM = cs.KM, nrow = (col1 - col0) * KM;
+	const size_t N = pl->N;
+	cs.tabs.emplace_back();
+	std::vector<unsigned> &tab = cs.tabs.back(); // [nrow + 1] row pointers, then the columns
+	tab.assign((size_t)nrow + 1, 0);
+	for (unsigned c = col0; c < col1; c++)
+		for (unsigned g = 0; g < KM; g++) {
+			tab[(size_t)(c - col0) * KM + g] = (unsigned)(tab.size() - (nrow + 1));
+			for (unsigned id = 0; id < cs.ncls; id++) if (cs.sig[id][c] == g) tab.push_back(id);
+		}
+	tab[nrow] = (unsigned)(tab.size() - (nrow + 1));
+	if ((cs.tab_used + tab.size()) * sizeof(unsigned) > pl->scr_bytes[SCR_JKTAB]) return fail(TSPWS_E_ARG, "combine_classes: table block too small");
+	unsigned *d_rp = (unsigned *)pl->scr[SCR_JKTAB] + cs.tab_used, *d_cols = d_rp + nrow + 1;
+	cs.tab_used += tab.size();
+	HIP_TRY(hipMemcpyAsync(d_rp, tab.data(), tab.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+	for (unsigned r0 = 0; r0 < nrow; r0 += 65535) {
+		const unsigned ny = std::min(nrow - r0, 65535u);
+		hipLaunchKernelGGL(k_combine_classes, dim3((unsigned)((N + 255) / 256), ny), dim3(256), 0, st, (const double *)pl->scr[SCR_CLS], N, d_rp + r0, d_cols,
+		                   d_P + (size_t)r0 * N, N);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// Rows of the masked replicas: d_P[c * KM + g][N] (SCR_JKP; the replicas' trace counts follow the rows).
+static int replica_rows_buffer(tspws_hip_plan *pl, unsigned KM, unsigned C, double **d_P)
+{
+	void *v;
+	int rc = scratch(pl, SCR_JKP, ((size_t)C * KM * pl->N + C) * sizeof(double), &v);
+	if (rc) return rc;
+	*d_P = (double *)v;
+	return 0;
+}
+
+// Replicas [c_begin, c_end) from their partial-stack rows: transforms, phase stacks, weights, time-domain linear stacks,
+// inverses.  Outputs land in rows c_begin.. of d_ls_out / d_ts_out / h_mtr_out ([C][N] arrays indexed by replica).
+// Synchronises the stream before returning (host tables go out of scope).
+static int finish_replicas(tspws_hip_plan *pl, const t_tsPWS *p, double *d_P, const std::vector<size_t> &Kc, unsigned C, unsigned c_begin,
+                           unsigned c_end, float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s)
+{
+	hipStream_t st = S_(s);
+	const unsigned KM = p->Kmax;
+	const size_t N = pl->N;
+	int rc;
+	void *v;
+	double *d_Mv = d_P + (size_t)C * KM * N;
+	std::vector<double> h_Mv(C);
+	for (unsigned c = 0; c < C; c++) h_Mv[c] = (double)Kc[c];
+	HIP_TRY(hipMemcpyAsync(d_Mv, h_Mv.data(), C * sizeof(double), hipMemcpyHostToDevice, st));
+	// Replicas are processed in batches: ONE forward launch transforms the KM partials of a whole batch of replicas (the
+	// kernels fill the GPU far better with 100 traces than with 10), then per replica the phase accumulation and the
+	// weight (KM, K_c), and the inverses two replicas at a time.
+	const size_t nc = pl->ncoef;
+	const unsigned nrep = c_end - c_begin;
+	unsigned RB = (unsigned)std::max<size_t>(1, std::min<size_t>(nrep, tspws_part_budget_bytes() / std::max<size_t>(1, (size_t)KM * pl->npart * sizeof(double2))));
+	if (RB > 1) RB &= ~1u; // pairs for the two-set inverse
+	if ((rc = scratch(pl, SCR_PART, (size_t)RB * KM * pl->npart * sizeof(double2), &v))) return rc;
+	double2 *part = (double2 *)v;
+	// per replica of the batch: OUT (2 nc doubles) | ST | PS, then the reconstructions
+	if ((rc = scratch(pl, SCR_JKOUT, ((size_t)RB * 6 * nc + (size_t)RB * N) * sizeof(double), &v))) return rc;
+	double *OUT = (double *)v, *STr = OUT + (size_t)RB * 2 * nc, *xr = STr + (size_t)RB * 4 * nc;
+	const bool fuse = tspws_fused_forward(pl);
+	for (unsigned c0 = c_begin; c0 < c_end; c0 += RB) {
+		const unsigned nr = std::min(RB, c_end - c0);
+		// one slice of the fused forward kernel = the KM partial stacks of one replica: its stacks land in the replica's planes
+		FuseOut fz;
+		fz.accST = (double2 *)STr; fz.accPS = (double2 *)STr + nc; fz.stride = 2 * nc; fz.tps = KM;
+		if ((rc = tspws_forward_parts_f64(pl, d_P + (size_t)c0 * KM * N, (size_t)nr * KM, N, part, st, fuse ? &fz : nullptr, ScaleRange()))) return rc;
+		for (unsigned j = 0; j < nr; j++) h_mtr_out[c0 + j] = (unsigned)Kc[c0 + j];
+		// the replicas of the batch side by side in every launch (grid.y): stacks of the scales the fused kernel left out,
+		// weights with each replica's trace count, time-domain linear stacks, inverses two replicas per tap read, outputs
+		FuseOut fj = fz; // replica j's slice went straight into its ST / PS planes
+		tspws_launch_accumulate(pl, (const double2 *)part, KM, (double2 *)STr, (double2 *)STr + nc, 1, &fj, 1, st, nr, (size_t)KM * pl->npart, 2 * nc, false, nullptr,
+		                        ScaleRange());
+		tspws_weight_batched(pl, (double2 *)OUT, (const double2 *)STr, (const double2 *)STr + nc, tspws_weight_mode(p->wu, p->unbiased, KM), (double)KM, p->wu,
+		                     (const double *)(d_Mv + c0), nr, nc, 2 * nc, st);
+		hipLaunchKernelGGL(k_jk_linear, dim3((unsigned)((N + 255) / 256), nr), dim3(256), 0, st, d_P + (size_t)c0 * KM * N, KM, N, (const double *)(d_Mv + c0),
+		                   d_ls_out + (size_t)c0 * N);
+		if ((rc = tspws_hip_inverse(pl, OUT, nr, xr, s))) return rc;
+		tspws_epilogue_rows(d_ts_out + (size_t)c0 * N, xr, N, nr, st);
+	}
+	HIP_TRY(hipGetLastError());
+	return cs_done(st); // host tables above go out of scope
+}
+
+// All C masked two-stage replicas from ONE pass over the traces (shared by the jackknife and the two-stage
+// random subsampling, whose per-replica bodies are identical in the reference: :758-811 and :642-691).
+// with_stack: the two-stage stack of ALL traces as well, from the same pass (the reference walks the traces 1 + C times).
+static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, const char *h_sel, unsigned C,
+                            float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s, bool with_stack, float *d_ls, float *d_ts)
+{
+	HIP_TRY(hipSetDevice(pl->device));
+	hipStream_t st = S_(s);
+	const unsigned KM = p->Kmax;
+	int rc;
+	ClassSums cs;
+	if ((rc = class_sums(pl, cs, KM, d_x, ld, mtr, h_sel, C, with_stack, st, 0, mtr))) { (void)cs_done(st); return rc; }
+	double *d_P;
+	if ((rc = replica_rows_buffer(pl, KM, C, &d_P))) { (void)cs_done(st); return rc; }
+	if (with_stack) {
+		double *main_rows; size_t nd;
+		if ((rc = tspws_hip_reduce_buffer(pl, p, mtr, &main_rows, &nd)) || (rc = combine_classes(pl, cs, C, C + 1, main_rows, st)) ||
+		    (rc = tspws_hip_stack_finish(pl, p, mtr, d_ls, d_ts, s))) { (void)cs_done(st); return rc; }
+	}
+	if ((rc = combine_classes(pl, cs, 0, C, d_P, st))) { (void)cs_done(st); return rc; }
+	rc = finish_replicas(pl, p, d_P, cs.Kc, C, 0, C, d_ls_out, d_ts_out, h_mtr_out, s);
+	(void)cs_done(st);
+	return rc;
+}
+
+extern "C" int tspws_hip_jackknife(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, const char *h_sel,
+                                   unsigned C, float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s)
+{
+	if (!pl || !p || !d_x || !h_sel || !d_ls_out || !d_ts_out || !h_mtr_out) return fail(TSPWS_E_ARG, "jackknife: NULL");
+	if (!is_two_stage(p, mtr) || !C) return 0; // single-stage variant is an empty stub in the reference (:711-716)
+	return masked_two_stage(pl, p, d_x, ld, mtr, h_sel, C, d_ls_out, d_ts_out, h_mtr_out, s, false, nullptr, nullptr);
+}
+
+// The two-stage stack AND its C jackknife replicas from ONE pass over the device-resident traces: tspws_hip_stack followed by
+// tspws_hip_jackknife, with the traces streamed once instead of twice (the reference: 1 + C times, :216 and :758-772).  The
+// stack's groups are then sums of class sums instead of chunk sums: the FP64 rounding of the partial stacks differs in the
+// last bits from tspws_hip_stack's.
+extern "C" int tspws_hip_stack_jackknife(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, float *d_ls, float *d_ts,
+                                         const char *h_sel, unsigned C, float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s)
+{
+	if (!pl || !p || !d_x || !mtr || !d_ls || !d_ts) return fail(TSPWS_E_ARG, "stack_jackknife: bad argument");
+	if (!is_two_stage(p, mtr) || !C || !h_sel) return tspws_hip_stack(pl, p, d_x, ld, mtr, d_ls, d_ts, s); // no replicas to share the pass with
+	if (!d_ls_out || !d_ts_out || !h_mtr_out) return fail(TSPWS_E_ARG, "stack_jackknife: NULL replica outputs");
+	return masked_two_stage(pl, p, d_x, ld, mtr, h_sel, C, d_ls_out, d_ts_out, h_mtr_out, s, true, d_ls, d_ts);
+}
+
+// ---- trace-sharded jackknife: shard-local rows -> the caller's reduction -> replicas finished where they are owned ----
+extern "C" int tspws_hip_jackknife_buffer(tspws_hip_plan *pl, const t_tsPWS *p, unsigned C, double **d_buf, size_t *nd)
+{
+	if (!pl || !p || !d_buf || !nd) return fail(TSPWS_E_ARG, "jackknife_buffer: NULL");
+	if (!p->Kmax || !C) return fail(TSPWS_E_ARG, "jackknife_buffer: two-stage calls with C > 0");
+	HIP_TRY(hipSetDevice(pl->device));
+	*nd = (size_t)C * p->Kmax * pl->N;
+	return replica_rows_buffer(pl, p->Kmax, C, d_buf);
+}
+
+extern "C" int tspws_hip_jackknife_local(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr_local, size_t first,
+                                         size_t mtr_global, const char *h_sel, unsigned C, void *s)
+{
+	if (!pl || !p || !h_sel || (!d_x && mtr_local)) return fail(TSPWS_E_ARG, "jackknife_local: NULL");
+	if (!is_two_stage(p, mtr_global) || !C) return fail(TSPWS_E_ARG, "jackknife_local: two-stage calls with C > 0");
+	HIP_TRY(hipSetDevice(pl->device));
+	hipStream_t st = S_(s);
+	const unsigned KM = p->Kmax;
+	double *main_rows, *d_P;
+	size_t nd;
+	int rc;
+	if ((rc = tspws_hip_reduce_buffer(pl, p, mtr_global, &main_rows, &nd))) return rc;
+	if ((rc = replica_rows_buffer(pl, KM, C, &d_P))) return rc;
+	// ONE pass over the shard for the plain groups and for every replica (empty shard: all rows zero)
+	ClassSums cs;
+	if ((rc = class_sums(pl, cs, KM, d_x, ld, mtr_global, h_sel, C, true, st, first, mtr_local)) ||
+	    (rc = combine_classes(pl, cs, C, C + 1, main_rows, st)) || (rc = combine_classes(pl, cs, 0, C, d_P, st))) { (void)cs_done(st); return rc; }
+	return cs_done(st);
+}
+
+extern "C" int tspws_hip_jackknife_finish(tspws_hip_plan *pl, const t_tsPWS *p, size_t mtr_global, const char *h_sel, unsigned C, unsigned c_begin,
+                                          unsigned c_end, float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s)
+{
+	if (!pl || !p || !h_sel || !d_ls_out || !d_ts_out || !h_mtr_out) return fail(TSPWS_E_ARG, "jackknife_finish: NULL");
+	if (!is_two_stage(p, mtr_global) || !C || c_begin > c_end || c_end > C) return fail(TSPWS_E_ARG, "jackknife_finish: two-stage calls, 0 <= c_begin <= c_end <= C");
+	if (c_begin == c_end) return 0;
+	HIP_TRY(hipSetDevice(pl->device));
+	std::vector<size_t> Kc(C, 0);
+	for (unsigned c = 0; c < C; c++) for (size_t i = 0; i < mtr_global; i++) if (h_sel[(size_t)c * mtr_global + i] == 1) Kc[c]++;
+	double *d_P;
+	int rc;
+	if ((rc = replica_rows_buffer(pl, p->Kmax, C, &d_P))) return rc;
+	return finish_replicas(pl, p, d_P, Kc, C, c_begin, c_end, d_ls_out, d_ts_out, h_mtr_out, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// random subsampling (SubsamplingPlan :355-383, tspws_subsmpl_float :501-610, TwoStage_subsmpl_float :612-709)
+// ------------------------------------------------------------------------------------------
+extern "C" int tspws_subsampling_plan(char *sel, size_t J, size_t K)
+{
+	if (!sel) return 1;
+	if (K > J) return 2;
+	size_t k = 0;
+	if (2 * K < J) { // fewer ones than zeros: switch ones on
+		memset(sel, 0, J);
+		while (k < K) { const size_t j = (size_t)rand() % J; if (!sel[j]) { k++; sel[j] = 1; } }
+	} else {         // otherwise switch zeros on
+		memset(sel, 1, J);
+		K = J - K;
+		while (k < K) { const size_t j = (size_t)rand() % J; if (sel[j]) { k++; sel[j] = 0; } }
+	}
+	return 0;
+}
+
+// ST_m += Y_b, PS_m += Y_b/|Y_b| for every mask m that contains trace b; one thread per coefficient, the
+// (<= 8) traces of the batch are normalised once and reused for all masks.
+__global__ void __launch_bounds__(256) k_accumulate_masked(const double2 *__restrict__ part, size_t npart, const ScaleDesc *__restrict__ sc,
+                                                           unsigned S, size_t ncoef, unsigned ntr, const char *__restrict__ sel, size_t mtr,
+                                                           size_t t0, unsigned M, double2 *__restrict__ ST, double2 *__restrict__ PS)
+{
+	unsigned lo = 0, hi = S;
+	while (hi - lo > 1) {
+		const unsigned mid = (lo + hi) >> 1;
+		if (sc[mid].acc_off <= blockIdx.x) lo = mid; else hi = mid;
+	}
+	const unsigned Ns = sc[lo].Ns, nsplit = sc[lo].nsplit;
+	const unsigned k = (blockIdx.x - sc[lo].acc_off) * 256 + threadIdx.x;
+	if (k >= Ns) return;
+	const size_t i = sc[lo].coef_off + k;
+	const double2 *p0 = part + sc[lo].part_off + k;
+	double2 v[8], u[8];
+#pragma unroll
+	for (int b = 0; b < 8; b++) {
+		v[b] = make_double2(0, 0); u[b] = make_double2(0, 0);
+		if ((unsigned)b < ntr) {
+			const double2 *p = p0 + (size_t)b * npart;
+			double2 a = p[0];
+			for (unsigned sp = 1; sp < nsplit; sp++) { const double2 t = p[(size_t)sp * Ns]; a.x += t.x; a.y += t.y; }
+			v[b] = a;
+			add_unit_phasor(u[b], a);
+		}
+	}
+	for (unsigned m = 0; m < M; m++) {
+		const char *row = sel + (size_t)m * mtr + t0;
+		double2 st = ST[(size_t)m * ncoef + i], ps = PS[(size_t)m * ncoef + i];
+		bool any = false;
+#pragma unroll
+		for (int b = 0; b < 8; b++)
+			if ((unsigned)b < ntr && row[b] == 1) { st.x += v[b].x; st.y += v[b].y; ps.x += u[b].x; ps.y += u[b].y; any = true; }
+		if (any) { ST[(size_t)m * ncoef + i] = st; PS[(size_t)m * ncoef + i] = ps; }
+	}
+}
+
+// time-domain linear stacks of the subsamples with the reference's FLOAT accumulator, traces in order
+// (ts_pws1f_lib.c:538-542), then the float scale W/K (:579-583).  grid.y = mask
+__global__ void __launch_bounds__(256) k_sub_linear(const float *__restrict__ x, size_t ld, size_t N, size_t mtr, const char *__restrict__ sel,
+                                                    float scale, float *__restrict__ out)
+{
+	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (n >= N) return;
+	const char *row = sel + (size_t)blockIdx.y * mtr;
+	float acc = 0.f;
+	for (size_t i = 0; i < mtr; i++)
+		if (row[i] == 1) acc = (float)((double)acc + (double)x[i * ld + n]);
+	out[(size_t)blockIdx.y * N + n] = acc * scale;
+}
+
+extern "C" int tspws_hip_subsample(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, unsigned M,
+                                   float *d_ls_out, float *d_ts_out, void *s)
+{
+	if (!pl || !p || !d_x || !d_ls_out || !d_ts_out) return fail(TSPWS_E_ARG, "subsample: NULL");
+	if (!M || !mtr) return 0;
+	HIP_TRY(hipSetDevice(pl->device));
+	hipStream_t st = S_(s);
+	const size_t K = (size_t)ceil((double)mtr * p->subsmpl_p);
+	std::vector<char> sel((size_t)M * mtr);
+	for (unsigned m = 0; m < M; m++) tspws_subsampling_plan(sel.data() + (size_t)m * mtr, mtr, K); // same rand() order as the reference
+	if (is_two_stage(p, mtr)) {
+		std::vector<unsigned> cnt(M);
+		return masked_two_stage(pl, p, d_x, ld, mtr, sel.data(), M, d_ls_out, d_ts_out, cnt.data(), s, false, nullptr, nullptr);
+	}
+	const size_t N = pl->N, nc = pl->ncoef;
+	int rc;
+	void *v;
+	if ((rc = scratch(pl, SCR_SEL, (size_t)M * mtr, &v))) return rc;
+	char *d_sel = (char *)v;
+	HIP_TRY(hipMemcpyAsync(d_sel, sel.data(), (size_t)M * mtr, hipMemcpyHostToDevice, st));
+	if ((rc = scratch(pl, SCR_SUBST, (size_t)M * nc * 2 * sizeof(double2), &v))) return rc;
+	double2 *STm = (double2 *)v, *PSm = STm + (size_t)M * nc;
+	HIP_TRY(hipMemsetAsync(STm, 0, (size_t)M * nc * 2 * sizeof(double2), st));
+	if ((rc = scratch(pl, SCR_PART, 8 * pl->npart * sizeof(double2), &v))) return rc;
+	double2 *part = (double2 *)v;
+	for (size_t t0 = 0; t0 < mtr; t0 += 8) {
+		const unsigned nb = (unsigned)std::min<size_t>(8, mtr - t0);
+		if ((rc = tspws_forward_parts_f32(pl, d_x + t0 * ld, nb, ld, part, st, nullptr, ScaleRange()))) return rc;
+		hipLaunchKernelGGL(k_accumulate_masked, dim3(pl->acc_blocks), dim3(256), 0, st, (const double2 *)part, pl->npart, pl->d_sc, pl->S, nc,
+		                   nb, d_sel, mtr, t0, M, STm, PSm);
+	}
+	const float scale = (float)(1. / (double)K); // fa1 = W[m]/K with W = 1 (:580)
+	hipLaunchKernelGGL(k_sub_linear, dim3((unsigned)((N + 255) / 256), M), dim3(256), 0, st, d_x, ld, N, mtr, d_sel, scale, d_ls_out);
+	if ((rc = scratch(pl, SCR_JKOUT, (2 * nc + N) * sizeof(double), &v))) return rc;
+	double *OUT = (double *)v, *xr = OUT + 2 * nc;
+	for (unsigned m = 0; m < M; m++) {
+		if ((rc = tspws_hip_weight(pl, OUT, (double *)(STm + (size_t)m * nc), (double *)(PSm + (size_t)m * nc), (unsigned)K, (unsigned)K, p->wu,
+		                           p->unbiased, s))) return rc;
+		if ((rc = tspws_hip_inverse(pl, OUT, 1, xr, s))) return rc;
+		if ((rc = tspws_hip_epilogue(nullptr, d_ts_out + (size_t)m * N, nullptr, xr, N, 1, s))) return rc;
+	}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(st)); // `sel` goes out of scope
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// convergence curves (ts_pws1f_lib.c:247-314, similarity :433-449, misfit :452-462)
+// ------------------------------------------------------------------------------------------
+// out[0] = sum d*r, out[1] = sum d*d, out[2] = sum (d-r)^2, out[3] = sum r*r ; one workgroup, fixed order
+__global__ void __launch_bounds__(1024) k_dot4(const double *__restrict__ d, const float *__restrict__ r, size_t N, double *__restrict__ out)
+{
+	__shared__ double red[16][4];
+	double a = 0, b = 0, c = 0, e = 0;
+	for (size_t n = threadIdx.x; n < N; n += 1024) {
+		const double dv = d[n], rv = (double)r[n], df = dv - rv;
+		a = fma(dv, rv, a); b = fma(dv, dv, b); c = fma(df, df, c); e = fma(rv, rv, e);
+	}
+	a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); e = wave_sum(e);
+	if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a; red[threadIdx.x >> 6][1] = b; red[threadIdx.x >> 6][2] = c; red[threadIdx.x >> 6][3] = e; }
+	__syncthreads();
+	if (threadIdx.x < 4) {
+		double t = 0;
+		for (int w = 0; w < 16; w++) t += red[w][threadIdx.x];
+		out[threadIdx.x] = t;
+	}
+}
+
+// running linear stack: d += x_i; d *= (float)(1/(i+1)); metrics; d *= (i+1)   (:288-308, literal FLOAT reciprocal)
+// every workgroup writes its partial sums of the three metrics per step; k_conv_lin_reduce adds them in order
+__global__ void __launch_bounds__(256) k_conv_linear(const float *__restrict__ x, size_t ld, size_t N, size_t mtr, const float *__restrict__ ref,
+                                                     double *__restrict__ partial, float *__restrict__ steps)
+{
+	__shared__ double red[4][3];
+	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+	const bool live = n < N;
+	const double rv = live ? (double)ref[n] : 0.0;
+	double d = 0;
+	for (size_t i = 0; i < mtr; i++) {
+		if (live) d += (double)x[i * ld + n];
+		const float inv = (float)(1.0 / (double)(i + 1));
+		d *= (double)inv;
+		const double df = d - rv;
+		double a = live ? d * rv : 0.0, b = live ? d * d : 0.0, c = live ? df * df : 0.0;
+		a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+		if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a; red[threadIdx.x >> 6][1] = b; red[threadIdx.x >> 6][2] = c; }
+		__syncthreads();
+		if (threadIdx.x < 3)
+			partial[((size_t)blockIdx.x * mtr + i) * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+		__syncthreads();
+		if (steps && live) steps[i * N + n] = (float)d;
+		d *= (double)(i + 1);
+	}
+}
+
+__global__ void __launch_bounds__(256) k_conv_lin_reduce(const double *__restrict__ partial, unsigned nblocks, size_t mtr, double *__restrict__ out)
+{
+	const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; // index into [mtr][3]
+	if (j >= mtr * 3) return;
+	double t = 0;
+	for (unsigned b = 0; b < nblocks; b++) t += partial[(size_t)b * mtr * 3 + j];
+	out[j] = t;
+}
+
+extern "C" int tspws_hip_convergence(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, const float *d_ref_ts,
+                                     const float *d_ref_ls, double *h_ts_sim, double *h_ts_misfit, double *h_ls_sim, double *h_ls_misfit,
+                                     float *d_ts_steps, float *d_ls_steps, void *s)
+{
+	if (!pl || !p || !d_x || !d_ref_ts || !d_ref_ls || !h_ts_sim || !h_ts_misfit || !h_ls_sim || !h_ls_misfit)
+		return fail(TSPWS_E_ARG, "convergence: NULL");
+	if (!mtr) return 0;
+	HIP_TRY(hipSetDevice(pl->device));
+	hipStream_t st = S_(s);
+	const size_t N = pl->N, nc = pl->ncoef;
+	int rc;
+	void *v;
+	if ((rc = scratch(pl, SCR_OUT, 6 * nc * sizeof(double), &v))) return rc;
+	double *OUT = (double *)v, *ST = OUT + 2 * nc, *PS = ST + 2 * nc;
+	if ((rc = scratch(pl, SCR_X2, 2 * N * sizeof(double), &v))) return rc;
+	double *xr = (double *)v;
+	const unsigned nblk = (unsigned)((N + 255) / 256);
+	if ((rc = scratch(pl, SCR_CONV, ((size_t)mtr * 4 + (size_t)nblk * mtr * 3 + mtr * 3) * sizeof(double), &v))) return rc;
+	double *d_ts = (double *)v, *d_lpart = d_ts + mtr * 4, *d_lin = d_lpart + (size_t)nblk * mtr * 3;
+	if ((rc = scratch(pl, SCR_PART, 2 * pl->npart * sizeof(double2), &v))) return rc;
+	double2 *part = (double2 *)v;
+	double *P = nullptr;
+	if (p->Kmax) { if ((rc = scratch(pl, SCR_P, (size_t)p->Kmax * N * sizeof(double), &v))) return rc; P = (double *)v; }
+	for (size_t i = 0; i < mtr; i++) {
+		const size_t Tr = i + 1;
+		unsigned K;
+		if (!p->Kmax || p->Kmax >= Tr) { // incremental single-stage step (tspws_stacks_float_1step, :835-863)
+			K = (unsigned)Tr;
+			if ((rc = tspws_forward_parts_f32(pl, d_x + i * ld, 1, ld, part, st, nullptr, ScaleRange()))) return rc;
+			tspws_launch_accumulate(pl, (const double2 *)part, 1u, (double2 *)ST, (double2 *)PS, i == 0 ? 1 : 0, nullptr, 0, st, 1, 0, 0, false, nullptr, ScaleRange());
+		} else { // two-stage over the first Tr traces, recomputed from scratch like the reference (:266-268)
+			K = p->Kmax;
+			if ((rc = tspws_hip_partial_stacks(pl, d_x, ld, Tr, 0, Tr, K, P, N, s))) return rc;
+			if ((rc = tspws_hip_stacks_double(pl, P, K, N, ST, PS, s))) return rc;
+		}
+		if ((rc = tspws_hip_weight(pl, OUT, ST, PS, K, (unsigned)Tr, p->wu, p->unbiased, s))) return rc;
+		if ((rc = tspws_hip_inverse(pl, OUT, 1, xr, s))) return rc;
+		hipLaunchKernelGGL(k_dot4, dim3(1), dim3(1024), 0, st, (const double *)xr, d_ref_ts, N, d_ts + i * 4);
+		if (d_ts_steps && (rc = tspws_hip_epilogue(nullptr, d_ts_steps + i * N, nullptr, xr, N, 1, s))) return rc;
+	}
+	hipLaunchKernelGGL(k_conv_linear, dim3(nblk), dim3(256), 0, st, d_x, ld, N, mtr, d_ref_ls, d_lpart, d_ls_steps);
+	hipLaunchKernelGGL(k_conv_lin_reduce, dim3((unsigned)((mtr * 3 + 255) / 256)), dim3(256), 0, st, (const double *)d_lpart, nblk, mtr, d_lin);
+	hipLaunchKernelGGL(k_dot4, dim3(1), dim3(1024), 0, st, (const double *)xr, d_ref_ls, N, d_lpart); // only out[3] = sum ref_ls^2 is used
+	HIP_TRY(hipGetLastError());
+	std::vector<double> hts(mtr * 4), hl(mtr * 3);
+	double lsq[4];
+	HIP_TRY(hipMemcpyAsync(hts.data(), d_ts, mtr * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(hl.data(), d_lin, mtr * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(lsq, d_lpart, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	for (size_t i = 0; i < mtr; i++) {
+		h_ts_sim[i] = hts[i * 4] / sqrt(hts[i * 4 + 1]) / sqrt(hts[i * 4 + 3]);
+		h_ts_misfit[i] = hts[i * 4 + 2];
+		h_ls_sim[i] = hl[i * 3] / sqrt(hl[i * 3 + 1]) / sqrt(lsq[3]);
+		h_ls_misfit[i] = hl[i * 3 + 2];
+	}
+	return 0;
+}

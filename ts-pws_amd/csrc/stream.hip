@@ -1,0 +1,291 @@
+// stream.hip -- trace prologue (fold, mean removal) and stage 1 of the two-stage stack: the HBM-streaming partial-stack pass.
+// Reference citations are relative to /root/reference/src.
+#include "tspws_internal.h"
+
+// ------------------------------------------------------------------------------------------
+// prologue kernels
+// ------------------------------------------------------------------------------------------
+// fold, ts_pws1f_lib.c:76-86.  grid.y = trace
+__global__ void __launch_bounds__(256) k_fold(float *__restrict__ x, size_t max, size_t ld)
+{
+	float *row = x + (size_t)blockIdx.y * ld;
+	const size_t half = max / 2;
+	for (size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x; n < half; n += (size_t)gridDim.x * blockDim.x) {
+		float v = row[n];
+		v += row[max - 1 - n];
+		v *= 0.5f;
+		row[max - 1 - n] = v;
+		row[n] = v;
+	}
+}
+
+// mean removal, ts_pws1f_lib.c:159-169: FP64 sum, mean rounded to float, float subtraction.
+// One workgroup per trace (the trace is re-read from L2 for the subtraction).
+__global__ void __launch_bounds__(1024) k_remove_mean(float *__restrict__ x, size_t max, size_t ld)
+{
+	__shared__ double part[16];
+	__shared__ float meanf;
+	float *row = x + (size_t)blockIdx.x * ld;
+	double acc = 0;
+	for (size_t n = threadIdx.x; n < max; n += blockDim.x) acc += (double)row[n];
+	acc = wave_sum(acc);
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double t = 0;
+		for (unsigned i = 0; i < blockDim.x / 64; i++) t += part[i];
+		meanf = (float)(t / (double)max);
+	}
+	__syncthreads();
+	const float m = meanf;
+	for (size_t n = threadIdx.x; n < max; n += blockDim.x) row[n] -= m;
+}
+
+extern "C" int tspws_hip_fold(float *d_x, size_t mtr, size_t max, size_t ld, void *s)
+{
+	if (!d_x) return fail(TSPWS_E_ARG, "fold: NULL");
+	if (!mtr || max < 2) return 0;
+	const unsigned bx = (unsigned)std::min<size_t>((max / 2 + 255) / 256, 64);
+	for (size_t t0 = 0; t0 < mtr; t0 += 65535) {
+		const unsigned ny = (unsigned)std::min<size_t>(mtr - t0, 65535);
+		hipLaunchKernelGGL(k_fold, dim3(bx, ny), dim3(256), 0, S_(s), d_x + t0 * ld, max, ld);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+extern "C" int tspws_hip_remove_mean(float *d_x, size_t mtr, size_t max, size_t ld, void *s)
+{
+	if (!d_x) return fail(TSPWS_E_ARG, "remove_mean: NULL");
+	if (!mtr || !max) return 0;
+	for (size_t t0 = 0; t0 < mtr; t0 += (1u << 30)) {
+		const unsigned nb = (unsigned)std::min<size_t>(mtr - t0, 1u << 30);
+		hipLaunchKernelGGL(k_remove_mean, dim3(nb), dim3(1024), 0, S_(s), d_x + t0 * ld, max, ld);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 1: partial linear stacks (the HBM-streaming kernel)
+//
+// Work item = (column block, chunk): a chunk is a run of consecutive traces that all add into
+// the same destination row.  Every thread owns 4 consecutive samples, walks the chunk's traces
+// with independent 16-byte non-temporal loads (8 in flight), accumulates in FP64 and writes one
+// partial row per chunk; k_reduce_chunks then adds the few chunk rows of each destination in a
+// fixed order, so the result is deterministic (no atomics).
+// Algorithmic bytes: 4 per input sample (+ 8 per output sample).
+// ------------------------------------------------------------------------------------------
+template <bool VEC4>
+__global__ void __launch_bounds__(256) k_partial(const float *__restrict__ x, size_t ld, size_t N,
+                                                 const Chunk *__restrict__ chunks, double *__restrict__ pc, size_t ldpc)
+{
+	const Chunk ck = chunks[blockIdx.y];
+	const size_t col = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+	if (col >= N) return;
+	const float *src = x + ck.t0 * ld + col;
+	double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+	if (VEC4) {
+		typedef float v4f __attribute__((ext_vector_type(4)));
+		unsigned t = 0;
+		for (; t + 8 <= ck.count; t += 8) {
+			v4f v[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)(t + j) * ld));
+#pragma unroll
+			for (int j = 0; j < 8; j++) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
+		}
+		for (; t < ck.count; t++) {
+			const v4f v = __builtin_nontemporal_load((const v4f *)(src + (size_t)t * ld));
+			a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+		}
+	} else {
+		const unsigned rem = (N - col) < 4 ? (unsigned)(N - col) : 4u;
+		for (unsigned t = 0; t < ck.count; t++) {
+			const float *r = src + (size_t)t * ld;
+			a0 += (double)r[0];
+			if (rem > 1) a1 += (double)r[1];
+			if (rem > 2) a2 += (double)r[2];
+			if (rem > 3) a3 += (double)r[3];
+		}
+	}
+	double *dst = pc + (size_t)blockIdx.y * ldpc + col;
+	if (VEC4) {
+		*(double2 *)dst = make_double2(a0, a1);
+		*(double2 *)(dst + 2) = make_double2(a2, a3);
+	} else {
+		const unsigned rem = (N - col) < 4 ? (unsigned)(N - col) : 4u;
+		dst[0] = a0;
+		if (rem > 1) dst[1] = a1;
+		if (rem > 2) dst[2] = a2;
+		if (rem > 3) dst[3] = a3;
+	}
+}
+
+// P[row][n] = sum over the row's chunks (in chunk order); rows without chunks become 0.
+__global__ void __launch_bounds__(256) k_reduce_chunks(const double *__restrict__ pc, size_t ldpc, const unsigned *__restrict__ row_first,
+                                                       double *__restrict__ P, size_t ldP, size_t N)
+{
+	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (n >= N) return;
+	const unsigned row = blockIdx.y;
+	double acc = 0;
+	for (unsigned c = row_first[row]; c < row_first[row + 1]; c++) acc += pc[(size_t)c * ldpc + n];
+	P[(size_t)row * ldP + n] = acc;
+}
+
+// Device copy of a chunk table.  `cached` = the plan's own group table (build_group_chunks): uploaded once, valid only
+// after the copy has been enqueued, and a call on another stream waits for that copy through ck_ev.  Any other table
+// (masked replicas) is uploaded every time and invalidates the cached device copy, which shares the scratch block.
+static int chunk_tables(tspws_hip_plan *p, const std::vector<Chunk> &chunks, const std::vector<unsigned> &row_first, unsigned rows,
+                        hipStream_t st, bool cached, Chunk **d_chunks, unsigned **d_rf)
+{
+	const size_t nck = chunks.size();
+	const size_t tab_bytes = nck * sizeof(Chunk) + (rows + 1) * sizeof(unsigned);
+	void *d_tab = nullptr;
+	int rc;
+	if ((rc = scratch(p, SCR_TAB, std::max<size_t>(tab_bytes, 16), &d_tab))) return rc;
+	*d_chunks = (Chunk *)d_tab;
+	*d_rf = (unsigned *)((char *)d_tab + nck * sizeof(Chunk));
+	if (cached && p->ck_dev) {
+		if (st != p->ck_stream) HIP_TRY(hipStreamWaitEvent(st, p->ck_ev, 0));
+		return 0;
+	}
+	p->ck_dev = false;
+	if (nck) HIP_TRY(hipMemcpyAsync(*d_chunks, chunks.data(), nck * sizeof(Chunk), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(*d_rf, row_first.data(), (rows + 1) * sizeof(unsigned), hipMemcpyHostToDevice, st));
+	if (cached) {
+		if (!p->ck_ev) HIP_TRY(hipEventCreateWithFlags(&p->ck_ev, hipEventDisableTiming));
+		HIP_TRY(hipEventRecord(p->ck_ev, st));
+		p->ck_stream = st;
+		p->ck_dev = true; // only now: a failed upload must not leave a table that looks valid
+	}
+	return 0;
+}
+
+// Launch the streaming pass for an arbitrary chunk table (rows destinations).
+int tspws_run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, const std::vector<Chunk> &chunks,
+                     const std::vector<unsigned> &row_first, unsigned rows, double *d_P, size_t ldP, hipStream_t st, bool cached,
+                     unsigned row_begin, unsigned row_end)
+{
+	row_end = std::min(row_end, rows);
+	const size_t nck = chunks.size();
+	const size_t ldpc = (N + 3) & ~(size_t)3;
+	void *d_pc = nullptr;
+	Chunk *d_chunks = nullptr;
+	unsigned *d_rf = nullptr;
+	int rc;
+	if ((rc = scratch(p, SCR_CHUNK, std::max<size_t>(nck * ldpc * sizeof(double), 16), &d_pc))) return rc;
+	if ((rc = chunk_tables(p, chunks, row_first, rows, st, cached, &d_chunks, &d_rf))) return rc;
+	const unsigned bx = (unsigned)((N + 1023) / 1024);
+	const bool vec = (N % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x & 15) == 0);
+	const size_t ck0 = row_first[row_begin], ck1 = row_first[row_end]; // chunks are sorted by destination row
+	// every destination row fed by exactly ONE chunk: the streaming kernel writes the rows themselves, no chunk reduction
+	bool direct = ck1 - ck0 == (size_t)(row_end - row_begin) && ck1 - ck0 <= 65535 && (!vec || ldP % 2 == 0);
+	for (unsigned r = row_begin; r < row_end && direct; r++) direct = row_first[r + 1] - row_first[r] == 1;
+	if (direct) {
+		// Rows per launch.  The HBM streams fastest when exactly ONE workgroup per CU marches down the traces and all of them
+		// start together: 256 workgroups per launch 0.730 ms (7.2 TB/s), 384 / 640 / 1280 per launch 0.80 / 0.80 / 0.79 ms,
+		// 128 (half the CUs) 1.05 ms; a persistent 256-workgroup kernel walking the same items without launch boundaries
+		// 0.76 ms -- the boundaries keep the column blocks of a trace row in step, so the chip reads whole 512-KB rows
+		// (gpurun_out/sweep_s12.txt, sweep_s13.txt).  Short chunks (class sums of masked replicas) stay in one launch:
+		// there the extra launch boundaries would cost more than the rate gains.
+		const unsigned wg_target = 256;
+		size_t rows_total = 0;
+		for (size_t c = ck0; c < ck1; c++) rows_total += chunks[c].count;
+		const bool long_runs = ck1 > ck0 && rows_total / (ck1 - ck0) >= 256;
+		const unsigned rpl = long_runs ? std::max(1u, wg_target / std::max(1u, bx)) : 65535u;
+		p->last_stream_launches = 0;
+		for (size_t c0 = ck0; c0 < ck1; c0 += rpl) {
+			p->last_stream_launches++;
+			const unsigned ny = (unsigned)std::min<size_t>(ck1 - c0, rpl);
+			double *dst = d_P + (size_t)(row_begin + (c0 - ck0)) * ldP;
+			if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, dst, ldP);
+			else hipLaunchKernelGGL(k_partial<false>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, dst, ldP);
+		}
+		HIP_TRY(hipGetLastError());
+		return 0;
+	}
+	p->last_stream_launches = 0;
+	for (size_t c0 = ck0; c0 < ck1; c0 += 65535) {
+		p->last_stream_launches++;
+		const unsigned ny = (unsigned)std::min<size_t>(ck1 - c0, 65535);
+		if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, (double *)d_pc + c0 * ldpc, ldpc);
+		else hipLaunchKernelGGL(k_partial<false>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, (double *)d_pc + c0 * ldpc, ldpc);
+	}
+	for (unsigned r0 = row_begin; r0 < row_end; r0 += 65535) {
+		const unsigned ny = std::min(row_end - r0, 65535u);
+		hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((N + 255) / 256), ny), dim3(256), 0, st, (const double *)d_pc, ldpc,
+		                   d_rf + r0, d_P + (size_t)r0 * ldP, ldP, N);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// Chunk length of the streaming pass.  Round-2 sweep (10 000 x 131 072, K = 10): one 1000-trace chunk per group (1280
+// workgroups, 5 per CU) streams at 0.795-0.80 ms, steadily; 2 / 3-4 chunks per group (2560 / 5120 workgroups) at 0.79-0.83 /
+// 0.81-0.89 ms from one process to the next -- long runs per workgroup beat a full complement of waves.  Target: ~1024
+// workgroups in all; a group that fits one chunk is written by the streaming kernel directly (no chunk reduction).
+unsigned tspws_chunk_len_for(size_t N, size_t mtr)
+{
+	const size_t colblocks = (N + 1023) / 1024;
+	const size_t want = std::max<size_t>(1, 1024 / std::max<size_t>(colblocks, 1));
+	size_t len = (mtr + want - 1) / want;
+	len = std::max<size_t>(len, 8);
+	return (unsigned)std::min<size_t>(len, 1u << 20);
+}
+
+// Chunk table of the two-stage streaming pass: every group's run of local traces is cut into equal pieces
+// (group of global trace i: floor(i*Kmax/mtr_global), ts_pws1f_lib.c:876).  Cached in the plan.
+static void build_group_chunks(tspws_hip_plan *p, size_t mtr_local, size_t first, size_t mtr_global, unsigned Kmax)
+{
+	if (p->ck_valid && p->ck_mtr == mtr_local && p->ck_first == first && p->ck_glob == mtr_global && p->ck_K == Kmax) return;
+	p->ck_dev = false;
+	p->chunks.clear();
+	p->row_first.assign(Kmax + 1, 0);
+	const unsigned clen = tspws_chunk_len_for(p->N, mtr_local);
+	std::vector<std::vector<Chunk>> per(Kmax);
+	size_t i = 0;
+	while (i < mtr_local) {
+		const size_t g = (size_t)floor((double)((first + i) * (size_t)Kmax) / (double)mtr_global);
+		size_t j = i + 1;
+		while (j < mtr_local && (size_t)floor((double)((first + j) * (size_t)Kmax) / (double)mtr_global) == g) j++;
+		const size_t n = j - i, pieces = (n + clen - 1) / clen, base = n / pieces, rem = n % pieces;
+		size_t t = i;
+		for (size_t k = 0; k < pieces; k++) {
+			Chunk c; c.t0 = t; c.count = (unsigned)(base + (k < rem ? 1 : 0)); c.row = (unsigned)g;
+			per[std::min<size_t>(g, Kmax - 1)].push_back(c);
+			t += c.count;
+		}
+		i = j;
+	}
+	for (unsigned g = 0; g < Kmax; g++) {
+		p->row_first[g] = (unsigned)p->chunks.size();
+		p->chunks.insert(p->chunks.end(), per[g].begin(), per[g].end());
+	}
+	p->row_first[Kmax] = (unsigned)p->chunks.size();
+	p->ck_mtr = mtr_local; p->ck_first = first; p->ck_glob = mtr_global; p->ck_K = Kmax; p->ck_valid = true;
+}
+
+extern "C" int tspws_hip_partial_stacks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t mtr_local, size_t first,
+                                        size_t mtr_global, unsigned Kmax, double *d_P, size_t ldP, void *stream)
+{
+	// an empty shard (mtr_local == 0, d_x may be NULL) is legal: its rows become zeros, so that every rank of a
+	// trace-sharded call reaches the collective
+	if (!p || (!d_x && mtr_local) || !d_P || !Kmax || !mtr_global || first + mtr_local > mtr_global)
+		return fail(TSPWS_E_ARG, "partial_stacks: bad argument");
+	HIP_TRY(hipSetDevice(p->device));
+	build_group_chunks(p, mtr_local, first, mtr_global, Kmax);
+	return tspws_run_chunks(p, d_x, ld, p->N, p->chunks, p->row_first, Kmax, d_P, ldP, S_(stream), true);
+}
+
+extern "C" int tspws_hip_partial_stacks_range(tspws_hip_plan *p, const float *d_x, size_t ld, size_t mtr_local, size_t first,
+                                              size_t mtr_global, unsigned Kmax, unsigned g_begin, unsigned g_end, double *d_P, size_t ldP,
+                                              void *stream)
+{
+	if (!p || (!d_x && mtr_local) || !d_P || !Kmax || !mtr_global || g_begin > g_end || g_end > Kmax || first + mtr_local > mtr_global)
+		return fail(TSPWS_E_ARG, "partial_stacks_range: bad argument");
+	HIP_TRY(hipSetDevice(p->device));
+	build_group_chunks(p, mtr_local, first, mtr_global, Kmax);
+	return tspws_run_chunks(p, d_x, ld, p->N, p->chunks, p->row_first, Kmax, d_P, ldP, S_(stream), true, g_begin, g_end);
+}

@@ -1,0 +1,264 @@
+// tspws_internal.h -- what the translation units of libtspws_hip.so share: the plan object, the per-scale descriptor,
+// error plumbing, a few device helpers and the host functions that cross unit boundaries.  Not installed; the public
+// surface is include/tspws_hip.h.
+//
+//   plan.hip      parameters, frame geometry, tap generation, runtime helpers, synthetic traces
+//   stream.hip    trace prologue + stage 1: the HBM-streaming partial-stack pass
+//   forward.hip   forward frame CWT (fwd_lds.h, fwd_poly.h, fwd_tl.h) + linear / phase stacks
+//   inverse.hip   phase weighting, inverse frame CWT (inv_poly.h), epilogue
+//   stack.hip     the whole call on device-resident traces: local half, finish stage (whole / in pieces / by scales)
+//   resample.hip  jackknife, random subsampling, convergence curves
+//   comm.hip      trace shards on several devices of one process: RCCL all-reduce, sharded tspws_main driver
+//
+// Layout in HBM
+//   traces       float   [mtr][ld]     row-major, one trace per row (the reference's sigall)
+//   partials     double  [Kmax][ldP]   stage-1 group sums of the two-stage stack
+//   taps         double2 [ntaps]       ragged per scale, tap_off[s] .. ; dual taps likewise
+//   coefficients double2 [ncoef]       ragged [S][N_s], coef_off[s] ..  (N_s = ceil(N/D_s))
+// All arithmetic on the path is FP64 (the reference is double / double complex throughout); MFMA is deliberately unused:
+// the per-scale FIRs are skinny 1-D correlations.  Reference citations are relative to /root/reference/src.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tspws_hip.h"
+
+#ifndef TSPWS_PI
+#define TSPWS_PI 3.14159265358979328
+#endif
+
+// ------------------------------------------------------------------------------------------
+// error plumbing (plan.hip owns the thread-local text)
+// ------------------------------------------------------------------------------------------
+int tspws_fail(int code, const char *what, hipError_t e = hipSuccess);
+#define fail tspws_fail
+
+#define HIP_TRY(expr)                                                              \
+	do {                                                                           \
+		hipError_t e_ = (expr);                                                    \
+		if (e_ != hipSuccess) return tspws_fail(e_ == hipErrorOutOfMemory ? TSPWS_E_NOMEM : TSPWS_E_HIP, #expr, e_); \
+	} while (0)
+
+static inline hipStream_t S_(void *s) { return (hipStream_t)s; }
+
+// ------------------------------------------------------------------------------------------
+// per-scale descriptor (host table sc / sc_tl, device copies d_sc / d_sc_tl)
+// ------------------------------------------------------------------------------------------
+struct ScaleDesc {
+	unsigned L, D, Ns;
+	int c, cd;
+	unsigned Q;                 // ceil(L / D): taps per phase
+	unsigned long long tap_off, coef_off;
+	double scale, gain;         // gain = ln2 / (2 Cpsi V scale), wavelet_v7.c:145
+	// work decomposition of the polyphase forward kernel (fwd_poly.h)
+	unsigned DL, logDL;         // phase lanes per output group (power of two <= 64)
+	unsigned MC, cps, nsplit;   // 64-phase chunks, chunks per wave, waves sharing one output group
+	unsigned ngw;               // group-blocks (waves) per split
+	unsigned wave_off;          // first wave of this scale in the launch
+	unsigned inv_fast;          // 1: D divides N, handled by the polyphase inverse (inv_poly.h)
+	unsigned acc_off;           // first 256-coefficient block of this scale in k_accumulate_masked
+	unsigned use_lds;           // 1: forward transform by k_fwd_lds (fwd_lds.h), 0: k_fwd_poly
+	unsigned lds_off, lds_bps;  // first workgroup of this scale in k_fwd_lds, workgroups per split
+	unsigned acc2_off;          // first block of this scale in k_accumulate_parts (32 coefficients per block when split)
+	unsigned fuse_ok;           // 1: k_fwd_lds<FUSE> keeps this scale's linear / phase stacks in registers (no partials)
+	unsigned r16;               // 1: the direct kernel gives a thread 16 outputs of this scale (ngw counts 16-output groups)
+	unsigned long long part_off; // offset of this scale's [nsplit][Ns] partial block
+};
+
+struct Chunk { // one streaming work item of the partial-stack kernel
+	unsigned long long t0; // first local trace
+	unsigned count;        // traces
+	unsigned row;          // destination row (group / class)
+};
+
+// A contiguous run of scales [s0, s1) a finish-stage launch is restricted to (scale-sharded finish); s1 == 0: all scales.
+struct ScaleRange {
+	unsigned s0 = 0, s1 = 0;
+	bool on() const { return s1 != 0; }
+};
+
+// Output of the fused forward + phase-stack kernel: slice j of the launch (traces [j*tps, (j+1)*tps)) leaves the linear and
+// phase stacks of every fuse_ok scale in accST / accPS + j*stride ([ncoef] planes).
+struct FuseOut {
+	double2 *accST = nullptr, *accPS = nullptr;
+	size_t stride = 0;
+	unsigned tps = 1;
+	bool applied = false; // set by the forward launch when the fused kernel ran
+};
+
+// Phase weighting of one coefficient (tspws_biased :909-943, tspws_unbiased :965-984).
+// mode 0: wu == 2 biased, 1: wu == 1, 2: general power, 3: unbiased (K > 1); K = stacked units, M = traces.
+struct WeightArgs {
+	double2 *OUT;   // nullptr: no weighting
+	int mode;
+	double K, M, wu;
+};
+
+enum { SCR_Y = 0, SCR_PART, SCR_XT, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_JKTAB, SCR_N };
+
+struct OctDesc; // inverse work items (inv_poly.h)
+struct TLItem;  // many-trace forward work items (fwd_tl.h)
+
+struct tspws_hip_plan {
+	int device = 0, type = -1;
+	unsigned S = 0, V = 0, J = 0, N = 0;
+	double s0 = 0, b0 = 0, w0 = 0, Cpsi = 0;
+	size_t ncoef = 0, ntaps = 0;
+	size_t npart = 0;          // complex partial coefficients per trace (sum of nsplit*Ns)
+	unsigned fwd_waves = 0;    // waves per trace batch of k_fwd_poly
+	unsigned acc_blocks = 0;   // blocks of k_accumulate_masked (256 coefficients each)
+	unsigned acc2_blocks = 0;  // blocks of k_accumulate_parts
+	unsigned lds_blocks = 0;   // workgroups per trace slice of k_fwd_lds
+	unsigned n_fusable = 0;    // scales whose stacks the fused forward kernel keeps in registers
+	// many-trace decomposition (fwd_tl.h): second scale table, trace-lane work items
+	std::vector<ScaleDesc> sc_tl;
+	ScaleDesc *d_sc_tl = nullptr;
+	TLItem *d_tl = nullptr;
+	unsigned tl_n = 0, tl_wgs = 0, tl_waves = 0, tl_acc2_blocks = 0; // items, workgroups per trace block, direct-kernel waves, accumulate blocks
+	size_t tl_npart = 0, tl_lds = 0;
+	std::vector<unsigned> oc_s0, oc_nv, oc_wave_off, oc_nwaves, oc_gen; // host copy of the inverse's octave items (launch order)
+	unsigned inv_waves = 0, inv_waves_fast = 0, inv_noct = 0, inv_ngeneric = 0; // polyphase inverse: waves (of the octaves whose D divides N first), octave items, scales left to the generic kernel
+	OctDesc *d_oc = nullptr;
+	std::vector<ScaleDesc> sc;
+	ScaleDesc *d_sc = nullptr;
+	double2 *d_w = nullptr, *d_wd = nullptr;
+	// lazily grown device scratch
+	void *scr[SCR_N] = {nullptr};
+	size_t scr_bytes[SCR_N] = {0};
+	// forward transform: the direct kernel (coarse scales, latency-bound) runs beside the LDS kernel (FP64-bound) on a
+	// side stream, forked from and joined back into the caller's stream
+	hipStream_t side = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	// optional timing inside tspws_hip_stack (bench.py): three events per call -- start, end of the streaming stage, end
+	std::vector<hipEvent_t> prof_ev;
+	size_t prof_used = 0;
+	// cached chunk table: the host copy is keyed on (mtr_local, first, mtr_global, K); the device copy becomes valid only
+	// once its upload has been enqueued (ck_dev), other streams order themselves behind it through ck_ev
+	std::vector<Chunk> chunks;
+	std::vector<unsigned> row_first; // per destination row: first chunk, rows+1 entries
+	size_t ck_mtr = 0, ck_first = 0, ck_glob = 0;
+	unsigned ck_K = 0;
+	bool ck_valid = false, ck_dev = false;
+	hipEvent_t ck_ev = nullptr;
+	hipStream_t ck_stream = nullptr;
+	unsigned last_stream_launches = 0; // k_partial launches of the last streaming pass (bench.py: per-launch roofline figures)
+	// blocks of exported slots (tspws_hip_reduce_buffer hands out SCR_P / SCR_STPS, tspws_hip_jackknife_buffer SCR_JKP) that
+	// were outgrown: a caller may still hold the old pointer (e.g. as the buffer of an in-flight collective), so they live
+	// until plan_destroy
+	std::vector<void *> retired;
+};
+
+int tspws_scratch(tspws_hip_plan *p, int slot, size_t bytes, void **out);
+#define scratch tspws_scratch
+
+// ------------------------------------------------------------------------------------------
+// device helpers shared by the kernels of several units
+// ------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned find_scale(const ScaleDesc *sc, unsigned S, unsigned long long idx, bool taps)
+{
+	unsigned lo = 0, hi = S; // last s with off[s] <= idx
+	while (hi - lo > 1) {
+		unsigned mid = (lo + hi) >> 1;
+		unsigned long long off = taps ? sc[mid].tap_off : sc[mid].coef_off;
+		if (off <= idx) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+
+__device__ __forceinline__ double wave_sum(double v) // wave = 64 lanes
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+	return v;
+}
+
+// PS += Y/|Y| unless the quotient is not a unit phasor (Y == 0 gives NaN and is skipped), ts_pws1f_lib.c:491-492.
+// Fast path: one rsqrt instead of hypot + two divisions whenever |Y|^2 is comfortably inside the double range;
+// the literal form handles the rest (zeros, subnormals, huge values).
+__device__ __forceinline__ void add_unit_phasor(double2 &ps, const double2 v)
+{
+	const double r2 = fma(v.x, v.x, v.y * v.y);
+	if (r2 > 1e-280 && r2 < 1e280) {
+		const double inv = rsqrt(r2);
+		ps.x = fma(v.x, inv, ps.x);
+		ps.y = fma(v.y, inv, ps.y);
+	} else {
+		const double r = hypot(v.x, v.y);
+		const double ux = v.x / r, uy = v.y / r;
+		if (ux * ux + uy * uy <= 1.001) { ps.x += ux; ps.y += uy; }
+	}
+}
+
+__device__ __forceinline__ double2 weight_value(const double2 st, const double2 ps, const int mode, const double K, const double M, const double wu)
+{
+	double a;
+	if (mode == 0) {
+		const double g = 1. / (K * K * M);
+		a = (ps.x * ps.x + ps.y * ps.y) * g;
+		return make_double2(a * st.x, a * st.y);
+	} else if (mode == 1) {
+		const double g = 1. / (K * M);
+		const double r = hypot(ps.x, ps.y);
+		return make_double2(st.x * r * g, st.y * r * g);
+	} else if (mode == 2) {
+		a = hypot(ps.x, ps.y) / K;
+		a = pow(a, wu);
+		return make_double2(st.x * a / M, st.y * a / M);
+	}
+	const double iK = 1. / K, iK1 = 1. / (K - 1), iM = 1. / M;
+	const double px = ps.x * iK, py = ps.y * iK;
+	a = px * px + py * py;
+	a = (K * a - 1) * iK1;
+	return make_double2(st.x * a * iM, st.y * a * iM);
+}
+#endif
+
+// ------------------------------------------------------------------------------------------
+// host functions that cross unit boundaries
+// ------------------------------------------------------------------------------------------
+// forward.hip
+int  tspws_build_forward(tspws_hip_plan *p);              // work decomposition of the forward kernels (few-trace and many-trace tables)
+int  tspws_forward_parts_f32(tspws_hip_plan *p, const float *d_x, size_t ntr, size_t ld, double2 *d_part, hipStream_t st, FuseOut *fz, ScaleRange rg);
+int  tspws_forward_parts_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, size_t ld, double2 *d_part, hipStream_t st, FuseOut *fz, ScaleRange rg);
+// ST / PS of ntr traces (keep: add to the stacks already there; wa: weighting applied by the launch that completes the
+// stacks, *weighted tells whether that happened; rg: only these scales)
+int  tspws_stacks_f32(tspws_hip_plan *p, const float *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, hipStream_t st, bool keep,
+                      const WeightArgs *wa, bool *weighted, ScaleRange rg);
+int  tspws_stacks_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, hipStream_t st, bool keep,
+                      const WeightArgs *wa, bool *weighted, ScaleRange rg);
+// k_accumulate_parts for nb transformed traces (nbatch independent stacks side by side: y_part / y_stack apart)
+void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb, double2 *ST, double2 *PS, int zero_first, const FuseOut *fz,
+                             unsigned nslices, hipStream_t st, unsigned nbatch, size_t y_part, size_t y_stack, bool tl, const WeightArgs *wa,
+                             ScaleRange rg);
+bool tspws_fused_forward(const tspws_hip_plan *p);        // the few-trace forward kernel stacks some scales in registers
+bool tspws_many_trace_path(const tspws_hip_plan *p, size_t ntr); // a batch this size goes to the trace-lane kernel
+size_t tspws_part_budget_bytes();
+bool tspws_generic_forward();
+// inverse.hip
+int  tspws_build_inverse(tspws_hip_plan *p);
+int  tspws_weight_mode(double wu, int unbiased, unsigned K);
+// OUT[j] = ST[j] * weight(PS[j]) for nb stacks side by side (y_out / y_stack doubles2 apart), trace counts d_Mv[j]
+void tspws_weight_batched(tspws_hip_plan *p, double2 *OUT, const double2 *ST, const double2 *PS, int mode, double K, double wu, const double *d_Mv,
+                          unsigned nb, size_t y_out, size_t y_stack, hipStream_t st);
+// the stack's pair of reconstructions (set 0 = OUT, set 1 = ST of Y) straight to the float outputs
+int  tspws_inverse_pair_out(tspws_hip_plan *p, const double2 *Y, float *d_ts, float *d_ls, float mtr, hipStream_t st);
+int  tspws_inverse_scales(tspws_hip_plan *p, const double2 *Y, double *x2, hipStream_t st, ScaleRange rg);
+bool tspws_generic_inverse();
+// ts rows: (float) x[j][n] for nb rows (replica outputs)
+void tspws_epilogue_rows(float *d_ts, const double *d_x, size_t N, unsigned nb, hipStream_t st);
+// stream.hip
+int  tspws_run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, const std::vector<Chunk> &chunks,
+                      const std::vector<unsigned> &row_first, unsigned rows, double *d_P, size_t ldP, hipStream_t st, bool cached,
+                      unsigned row_begin = 0, unsigned row_end = ~0u);
+unsigned tspws_chunk_len_for(size_t N, size_t mtr);
+// stack.hip
+bool tspws_is_two_stage(const t_tsPWS *p, size_t mtr_global);
