@@ -230,6 +230,51 @@ int  tspws_hip_convergence(tspws_hip_plan *plan, const t_tsPWS *p, const float *
                            const float *d_ref_ts, const float *d_ref_ls, double *h_ts_sim, double *h_ts_misfit,
                            double *h_ls_sim, double *h_ls_misfit, float *d_ts_steps, float *d_ls_steps, void *stream);
 
+/* ---- several devices of one process (single process, ncclCommInitAll, one stream per device) ---------------
+ * Traces shard contiguously by global index; what shards is the sum of partial_linear_stacks (ts_pws1f_lib.c:866-881) --
+ * single-stage: of ST || PS (:486-494).  The devices' buffers are added by ONE RCCL all-reduce (fp64, sum) over xGMI.
+ * RCCL is bound at run time (librccl.so.1), so single-device users never load it.
+ *   TSPWS_COMM=local  own reduction kernel instead of RCCL; also chosen when the device list names a device twice (RCCL
+ *                     refuses that) -- lets the N-way bookkeeping run on a one-GPU box; not a fallback
+ *   TSPWS_COMM=rccl   go through RCCL even for a single device */
+typedef struct tspws_hip_comm tspws_hip_comm;
+/* communicator over `ndev` devices of this process; devices == NULL: 0 .. ndev-1 */
+int   tspws_hip_comm_create(tspws_hip_comm **comm, int ndev, const int *devices);
+void  tspws_hip_comm_destroy(tspws_hip_comm *comm);
+int   tspws_hip_comm_size(const tspws_hip_comm *comm);
+int   tspws_hip_comm_device(const tspws_hip_comm *comm, int i);
+void *tspws_hip_comm_stream(const tspws_hip_comm *comm, int i);      /* the communicator's own stream on device i */
+const char *tspws_hip_comm_backend(const tspws_hip_comm *comm);      /* "rccl 2.x.y" or "local" */
+/* In-place sum: d_bufs[i] = `count` doubles on device i; ordered on streams[i] (NULL array / entry: the communicator's
+ * stream of that device).  One ncclAllReduce per device inside ncclGroupStart / ncclGroupEnd. */
+int   tspws_hip_allreduce_f64(tspws_hip_comm *comm, double *const *d_bufs, size_t count, void *const *streams);
+/* contiguous shard of `r` of `n`: traces [*first, *first + *count) */
+void  tspws_shard_range(size_t mtr, unsigned r, unsigned n, size_t *first, size_t *count);
+
+/* The whole call over trace shards: one plan per device + the communicator.  tspws_main uses it when TSPWS_DEVICES names
+ * several devices ("0,1,2,3" or "all").  d_shards[r] = the shard of device r (tspws_shard_range), row stride ld; d_ls /
+ * d_tsPWS live on the first device.  The finish stage is split by scales over the devices (tspws_hip_finish_shard) and a
+ * second small all-reduce adds the partial reconstructions.  Returns after synchronising the devices. */
+typedef struct tspws_hip_multi tspws_hip_multi;
+int   tspws_hip_multi_create(tspws_hip_multi **m, int ndev, const int *devices, int type, unsigned J, unsigned V, unsigned N,
+                             double s0, double b0, double w0, int uni);
+void  tspws_hip_multi_destroy(tspws_hip_multi *m);
+tspws_hip_comm *tspws_hip_multi_comm(tspws_hip_multi *m);
+tspws_hip_plan *tspws_hip_multi_plan(tspws_hip_multi *m, int i);
+/* host traces -> shards (the host array is pinned once, every device pulls its shard on its own stream: all PCIe links at
+ * once); *d_shards = per-device buffers owned by m, *d_ls / *d_tsPWS = output buffers on the first device */
+int   tspws_hip_multi_upload(tspws_hip_multi *m, const float *h_sigall, size_t ld, size_t mtr, const float *const **d_shards,
+                             float **d_ls, float **d_tsPWS);
+/* fold / mean removal on the uploaded shards, mirrored back into h_sigall (ts_pws1f_lib.c:71-88, :159-169) */
+int   tspws_hip_multi_prologue(tspws_hip_multi *m, float *h_sigall, size_t max, size_t ld, size_t mtr, int fold, int rm);
+int   tspws_hip_multi_stack(tspws_hip_multi *m, const t_tsPWS *p, const float *const *d_shards, size_t ld, size_t mtr,
+                            float *d_ls, float *d_tsPWS);
+/* ... and its C jackknife replicas (two-stage only): one pass per shard, the rows all-reduced, device r finishes replicas
+ * [r C / n, (r + 1) C / n) and writes its rows of the HOST arrays h_ls_out / h_ts_out ([C][max] floats). */
+int   tspws_hip_multi_stack_jackknife(tspws_hip_multi *m, const t_tsPWS *p, const float *const *d_shards, size_t ld, size_t mtr,
+                                      float *d_ls, float *d_tsPWS, const char *h_sel, unsigned C,
+                                      float *h_ls_out, float *h_ts_out, unsigned *h_mtr_out);
+
 /* ---- the drop-in's cache ---------------------------------------------------------------------------
  * tspws_main keeps the frame and the device trace buffer of its last call for the next one (same parameters: nothing to
  * rebuild).  This frees them; TSPWS_PLAN_CACHE=0 in the environment disables the cache altogether. */

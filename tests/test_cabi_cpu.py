@@ -99,3 +99,26 @@ def test_shard_ranges_cover_everything():
             f, c = tspws.shard_range(mtr, r, w)
             seen += list(range(f, f + c))
         assert seen == list(range(mtr))
+
+
+def test_shard_range_partitions_the_traces(lib):
+    """tspws_shard_range (the sharded tspws_main, csrc/comm.hip) and the Python orchestration's shard_range cut an ensemble the
+    same way: contiguous, in order, covering every trace once -- also when there are fewer traces than devices."""
+    for mtr, n in [(10000, 8), (100000, 8), (7, 3), (3, 8), (0, 4), (12345, 5), (1, 1)]:
+        nxt = 0
+        for r in range(n):
+            f, c = C.c_size_t(), C.c_size_t()
+            lib.tspws_shard_range(mtr, r, n, C.byref(f), C.byref(c))
+            assert (f.value, c.value) == tspws.shard_range(mtr, r, n)
+            assert f.value == nxt
+            nxt += c.value
+        assert nxt == mtr
+
+
+def test_comm_needs_a_device(lib):
+    """No HIP device: the communicator and the sharded call fail loudly like everything else (no CPU stand-in)."""
+    if lib.tspws_hip_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    h = C.c_void_p()
+    assert lib.tspws_hip_comm_create(C.byref(h), 2, None) == 5 and not h.value
+    assert lib.tspws_hip_multi_create(C.byref(h), 2, None, -1, 3, 4, 2048, 2.0, 1.0, 5.336, 0) == 5 and not h.value

@@ -1,0 +1,170 @@
+"""Several devices of one process (csrc/comm.hip): the all-reduce behind the C ABI and the sharded whole call that the
+drop-in tspws_main uses under TSPWS_DEVICES.  A one-GPU box can exercise (a) RCCL itself with a one-device communicator
+(ncclCommInitAll(1), TSPWS_COMM=rccl) and (b) the N-way bookkeeping -- shard ranges from the global trace index, zero rows
+of untouched groups, scale-sharded finish, replica blocks -- by naming the one device several times, which selects the
+library's own reduction kernel ("local" backend; RCCL refuses duplicate devices).  Everything is compared with the
+single-device engine and with the oracle's tspws_main (the reference sums the traces of one host array,
+/root/reference/src/ts_pws1f_lib.c:866-881)."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+import abi
+
+pytestmark = pytest.mark.gpu
+tspws = importlib.import_module("ts-pws_amd")
+TOL32 = 2e-6
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return tspws.load()
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _comm(lib, devs):
+    h = C.c_void_p()
+    arr = (C.c_int * len(devs))(*devs)
+    tspws.check(lib.tspws_hip_comm_create(C.byref(h), len(devs), arr), "comm_create")
+    return h
+
+
+def test_allreduce_through_rccl_on_one_device(lib, torch, monkeypatch):
+    monkeypatch.setenv("TSPWS_COMM", "rccl")
+    h = _comm(lib, [0])
+    try:
+        assert lib.tspws_hip_comm_size(h) == 1 and lib.tspws_hip_comm_device(h, 0) == 0
+        assert lib.tspws_hip_comm_backend(h).decode().startswith("rccl ")
+        x = torch.arange(100000, dtype=torch.float64, device="cuda") * 0.5
+        want = x.clone()
+        ptrs = (C.c_void_p * 1)(x.data_ptr())
+        torch.cuda.synchronize()
+        tspws.check(lib.tspws_hip_allreduce_f64(h, ptrs, x.numel(), None), "allreduce")
+        tspws.check(lib.tspws_hip_sync(lib.tspws_hip_comm_stream(h, 0)), "sync")
+        assert torch.equal(x, want)   # the sum over one rank
+    finally:
+        lib.tspws_hip_comm_destroy(h)
+
+
+def test_local_backend_adds_in_list_order(lib, torch):
+    h = _comm(lib, [0, 0, 0])
+    try:
+        assert lib.tspws_hip_comm_backend(h).decode() == "local" and lib.tspws_hip_comm_size(h) == 3
+        rng = np.random.default_rng(3)
+        host = [rng.standard_normal(70001) for _ in range(3)]
+        bufs = [torch.as_tensor(a, device="cuda") for a in host]
+        ptrs = (C.c_void_p * 3)(*[b.data_ptr() for b in bufs])
+        torch.cuda.synchronize()
+        tspws.check(lib.tspws_hip_allreduce_f64(h, ptrs, 70001, None), "allreduce")
+        for i in range(3):
+            tspws.check(lib.tspws_hip_sync(lib.tspws_hip_comm_stream(h, i)), "sync")
+        want = (host[0] + host[1]) + host[2]
+        for b in bufs:
+            np.testing.assert_array_equal(b.cpu().numpy(), want)
+    finally:
+        lib.tspws_hip_comm_destroy(h)
+
+
+def _multi_stack(lib, torch, params, X, devs, sel=None):
+    """tspws_hip_multi_stack(_jackknife) on shards of the device tensor X; returns numpy outputs."""
+    mtr, N = X.shape
+    p = tspws.resolve(params, N)
+    m = C.c_void_p()
+    arr = (C.c_int * len(devs))(*devs)
+    tspws.check(lib.tspws_hip_multi_create(C.byref(m), len(devs), arr, p.type, p.J, p.V, N, p.s0, p.b0, p.w0, int(p.uni)), "multi_create")
+    try:
+        shards = []
+        for r in range(len(devs)):
+            f, c = tspws.shard_range(mtr, r, len(devs))
+            shards.append(X[f:f + c].contiguous() if c else None)
+        ptrs = (C.c_void_p * len(devs))(*[s.data_ptr() if s is not None else None for s in shards])
+        ls = torch.empty(N, dtype=torch.float32, device="cuda")
+        ts = torch.empty(N, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        if sel is None:
+            tspws.check(lib.tspws_hip_multi_stack(m, C.byref(p), ptrs, N, mtr, ls.data_ptr(), ts.data_ptr()), "multi_stack")
+            return ls.cpu().numpy(), ts.cpu().numpy()
+        Cn = sel.shape[0]
+        jl, jt, jm = np.zeros((Cn, N), np.float32), np.zeros((Cn, N), np.float32), np.zeros(Cn, np.uint32)
+        tspws.check(lib.tspws_hip_multi_stack_jackknife(m, C.byref(p), ptrs, N, mtr, ls.data_ptr(), ts.data_ptr(), sel.ctypes.data, Cn,
+                                                       jl.ctypes.data, jt.ctypes.data, jm.ctypes.data), "multi_stack_jackknife")
+        return ls.cpu().numpy(), ts.cpu().numpy(), jl, jt, jm
+    finally:
+        lib.tspws_hip_multi_destroy(m)
+
+
+@pytest.mark.parametrize("kw,mtr,N,devs", [
+    (dict(Kmax=10, unbiased=1), 100, 4096, [0, 0, 0]),       # scale-sharded finish over three shares
+    (dict(Kmax=7), 53, 3001, [0, 0]),                          # odd N: no sharded finish, the first device finishes alone
+    (dict(), 40, 2048, [0, 0, 0, 0]),                          # single-stage: ST || PS are what the devices add
+    (dict(type=-3, Kmax=4, wu=1.0), 30, 4096, [0, 0, 0]),
+    (dict(Kmax=2, unbiased=1), 2, 2048, [0, 0, 0]),            # fewer traces than devices: empty shards add zeros
+    (dict(Kmax=10, unbiased=1), 64, 8192, [0] * 8),            # eight shares of the scales
+])
+def test_sharded_call_matches_the_single_device_engine(lib, torch, kw, mtr, N, devs):
+    X = tspws.synth(mtr, N, seed=61)
+    ls, ts = _multi_stack(lib, torch, abi.default_params(**kw), X, devs)
+    pl = tspws.Plan(tspws.resolve(abi.default_params(**kw), N), N)
+    ls0, ts0 = pl.stack_single(X)
+    torch.cuda.synchronize()
+    assert abi.relerr(ls, ls0.cpu().numpy()) < 1e-6 and abi.relerr(ts, ts0.cpu().numpy()) < 1e-6
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), X.cpu().numpy())
+    assert abi.relerr(ls, want["ls"]) < TOL32 and abi.relerr(ts, want["tsPWS"]) < TOL32
+
+
+def test_sharded_jackknife_matches_the_oracle(lib, torch):
+    mtr, N, K, n = 240, 4096, 6, 5
+    kw = dict(Kmax=K, unbiased=1, jackknife_n=n, jackknife_d=2)
+    Cn = abi.binomial(n, 2)
+    X = tspws.synth(mtr, N, seed=62)
+    rng = np.random.default_rng(9)
+    times = (1262304000 + 86400 * np.sort(rng.integers(0, 2 * 365, mtr))).astype(np.int64)
+    sel = np.zeros((Cn, mtr), np.int8)
+    assert lib.tspws_jackknife_plan(sel.ctypes.data, times.ctypes.data, mtr, 2, n, Cn) == 0
+    ls, ts, jl, jt, jm = _multi_stack(lib, torch, abi.default_params(**kw), X, [0, 0, 0], sel)   # replica blocks of 4 | 3 | 3
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), X.cpu().numpy(), times=times)
+    assert abi.relerr(ls, want["ls"]) < TOL32 and abi.relerr(ts, want["tsPWS"]) < TOL32
+    np.testing.assert_array_equal(jm, want["jk_mtr"])
+    for c in range(Cn):
+        assert abi.relerr(jt[c], want["jk_ts"][c]) < TOL32 and abi.relerr(jl[c], want["jk_ls"][c]) < TOL32, c
+
+
+@pytest.mark.parametrize("devices,comm", [("0,0,0", None), ("0", "rccl"), ("all", "rccl")])
+def test_tspws_main_over_a_device_list(lib, monkeypatch, devices, comm):
+    """The drop-in itself under TSPWS_DEVICES: host buffers in, shards uploaded per device, prologue mirrored back, outputs and
+    replicas out -- against the oracle's tspws_main, return codes and mutated traces included."""
+    monkeypatch.setenv("TSPWS_DEVICES", devices)
+    if comm:
+        monkeypatch.setenv("TSPWS_COMM", comm)
+    try:
+        X = abi.synth_traces(90, 2048, seed=71)
+        for kw, beg in ((dict(Kmax=5, unbiased=1), 0.0), (dict(), 0.0), (dict(Kmax=4, lrm=1, fold=1), -0.5 * 2047), (dict(type=-3, lrm=1), 0.0)):
+            got = abi.run_main(lib.tspws_main, abi.default_params(**kw), X, beg=beg)
+            want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), X, beg=beg)
+            assert got["rc"] == want["rc"] == 0
+            assert abi.relerr(got["sigall"], want["sigall"]) < 1e-6
+            assert abi.relerr(got["ls"], want["ls"]) < TOL32 and abi.relerr(got["tsPWS"], want["tsPWS"]) < TOL32, kw
+            assert got["params"].fold == want["params"].fold and got["params"].J == want["params"].J
+        times = (1262304000 + 86400 * 3 * np.arange(90)).astype(np.int64)
+        kw = dict(Kmax=5, unbiased=1, jackknife_n=4, jackknife_d=1)
+        got = abi.run_main(lib.tspws_main, abi.default_params(**kw), X, times=times)
+        want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), X, times=times)
+        assert got["rc"] == 0 and abi.relerr(got["tsPWS"], want["tsPWS"]) < TOL32
+        np.testing.assert_array_equal(got["jk_mtr"], want["jk_mtr"])
+        assert max(abi.relerr(got["jk_ts"][c], want["jk_ts"][c]) for c in range(4)) < TOL32
+        assert max(abi.relerr(got["jk_ls"][c], want["jk_ls"][c]) for c in range(4)) < TOL32
+        # convergence curves need the whole ensemble on one device: the call takes the single-device path and still answers
+        kw = dict(convergence=1, Kmax=3)
+        got = abi.run_main(lib.tspws_main, abi.default_params(**kw), X[:12])
+        want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), X[:12])
+        assert got["rc"] == 0 and abi.relerr(got["conv_tsPWS_sim"], want["conv_tsPWS_sim"]) < 1e-6
+    finally:
+        lib.tspws_main_release()

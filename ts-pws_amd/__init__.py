@@ -118,6 +118,23 @@ SYMBOLS = {
     "tspws_hip_subsample": (_i, [_vp, _vp, _vp, _sz, _sz, _u, _vp, _vp, _vp]),
     "tspws_hip_convergence": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tspws_hip_synth": (_i, [_vp, _sz, _sz, _sz, C.c_uint64, _sz, _vp]),
+    # several devices of one process (csrc/comm.hip)
+    "tspws_hip_comm_create": (_i, [C.POINTER(_vp), _i, _vp]),
+    "tspws_hip_comm_destroy": (None, [_vp]),
+    "tspws_hip_comm_size": (_i, [_vp]),
+    "tspws_hip_comm_device": (_i, [_vp, _i]),
+    "tspws_hip_comm_stream": (_vp, [_vp, _i]),
+    "tspws_hip_comm_backend": (C.c_char_p, [_vp]),
+    "tspws_hip_allreduce_f64": (_i, [_vp, _vp, _sz, _vp]),
+    "tspws_shard_range": (None, [_sz, _u, _u, C.POINTER(_sz), C.POINTER(_sz)]),
+    "tspws_hip_multi_create": (_i, [C.POINTER(_vp), _i, _vp, _i, _u, _u, _u, _d, _d, _d, _i]),
+    "tspws_hip_multi_destroy": (None, [_vp]),
+    "tspws_hip_multi_comm": (_vp, [_vp]),
+    "tspws_hip_multi_plan": (_vp, [_vp, _i]),
+    "tspws_hip_multi_upload": (_i, [_vp, _vp, _sz, _sz, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "tspws_hip_multi_prologue": (_i, [_vp, _vp, _sz, _sz, _sz, _i, _i]),
+    "tspws_hip_multi_stack": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp]),
+    "tspws_hip_multi_stack_jackknife": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _u, _vp, _vp, _vp]),
 }
 
 
@@ -155,7 +172,7 @@ def resolve(params, nsamp, dt=1.0):
 
 
 def shard_range(mtr_global, rank, world):
-    """Contiguous trace shard [first, first+count) of `rank`."""
+    """Contiguous trace shard [first, first+count) of `rank` (the library's tspws_shard_range)."""
     first = rank * mtr_global // world
     last = (rank + 1) * mtr_global // world
     return first, last - first

@@ -12,6 +12,14 @@
  * weighting (:226-228), convergence curves (:247-314), random subsampling
  * (:324-333), two-stage jackknife (:335-345).
  *
+ * Several devices: TSPWS_DEVICES="0,1,2,3" (or "all") shards in->sigall by
+ * traces over those devices of this process -- every device pulls its shard
+ * over its own PCIe link, sums it (ts_pws1f_lib.c:866-881), ONE RCCL
+ * all-reduce over xGMI adds the shards, the finish stage is split by scales
+ * (include/tspws_hip.h, "several devices").  Convergence curves and random
+ * subsampling need the whole ensemble on one device and take the single-
+ * device path.
+ *
  * The frame (plan) and the device trace buffer of the last call are kept: a
  * caller that stacks many ensembles of the same length with the same wavelet
  * parameters (the CLI in a loop, the MATLAB gateway) pays for the frame once.
@@ -33,6 +41,7 @@ static int device_from_env(void)
 #define TRY(call) do { rc = (call); if (rc) goto done; } while (0)
 
 /* ---- frame / trace-buffer cache (one entry: the last call's) ------------------------------------------------------ */
+#define TSPWS_MAX_DEVICES 64
 static struct {
 	tspws_hip_plan *plan;
 	int type, uni, dev;
@@ -40,6 +49,11 @@ static struct {
 	double s0, b0, w0;
 	float *d_sig;          /* device trace buffer, grown on demand */
 	size_t sig_bytes;
+	/* several devices: plans + communicator + shard buffers, keyed on the same frame parameters and the device list */
+	tspws_hip_multi *multi;
+	int mtype, muni, mndev, mdevs[TSPWS_MAX_DEVICES];
+	unsigned mJ, mV, mN;
+	double ms0, mb0, mw0;
 } g_cache;
 
 static int cache_enabled(void)
@@ -52,7 +66,94 @@ void tspws_main_release(void)
 {
 	tspws_hip_plan_destroy(g_cache.plan);
 	tspws_hip_free(g_cache.d_sig);
+	tspws_hip_multi_destroy(g_cache.multi);
 	memset(&g_cache, 0, sizeof g_cache);
+}
+
+/* TSPWS_DEVICES: "all" or a comma-separated list of HIP device ids; returns the number of entries (0: not set) */
+static int devices_from_env(int *devs, int cap)
+{
+	const char *e = getenv("TSPWS_DEVICES");
+	int n = 0;
+	if (!e || !*e) return 0;
+	if (!strcmp(e, "all")) {
+		const int have = tspws_hip_device_count();
+		for (; n < have && n < cap; n++) devs[n] = n;
+		return n;
+	}
+	while (*e && n < cap) {
+		char *end;
+		const long v = strtol(e, &end, 10);
+		if (end == e) break;
+		devs[n++] = (int)v;
+		e = (*end == ',') ? end + 1 : end;
+	}
+	return n;
+}
+
+static int get_multi(tspws_hip_multi **m, const t_tsPWS *p, unsigned N, const int *devs, int ndev)
+{
+	if (g_cache.multi && g_cache.mtype == p->type && g_cache.mJ == p->J && g_cache.mV == p->V && g_cache.mN == N && g_cache.ms0 == p->s0 &&
+	    g_cache.mb0 == p->b0 && g_cache.mw0 == p->w0 && g_cache.muni == (int)p->uni && g_cache.mndev == ndev &&
+	    !memcmp(g_cache.mdevs, devs, (size_t)ndev * sizeof(int))) {
+		*m = g_cache.multi;
+		return 0;
+	}
+	tspws_hip_multi *fresh = NULL;
+	int rc = tspws_hip_multi_create(&fresh, ndev, devs, p->type, p->J, p->V, N, p->s0, p->b0, p->w0, (int)p->uni);
+	if (rc) return rc;
+	tspws_hip_multi_destroy(g_cache.multi);
+	g_cache.multi = fresh;
+	g_cache.mtype = p->type; g_cache.mJ = p->J; g_cache.mV = p->V; g_cache.mN = N; g_cache.ms0 = p->s0; g_cache.mb0 = p->b0; g_cache.mw0 = p->w0;
+	g_cache.muni = (int)p->uni; g_cache.mndev = ndev;
+	memcpy(g_cache.mdevs, devs, (size_t)ndev * sizeof(int));
+	*m = fresh;
+	return 0;
+}
+
+/* The call over trace shards on several devices (no convergence curves, no random subsampling: the caller checked). */
+static int main_multi(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in, size_t mtr, int do_fold, const int *devs, int ndev)
+{
+	const size_t ld = (size_t)in->hdr.max;
+	const unsigned nsamp = (unsigned)in->hdr.max;
+	tspws_hip_multi *m = NULL;
+	const float *const *d_shards = NULL;
+	float *d_ls = NULL, *d_ts = NULL, *jk = NULL;
+	char *sel = NULL;
+	int rc = get_multi(&m, tspws, nsamp, devs, ndev);
+	if (rc) {
+		printf("tspws_main: cannot set up the devices / the wavelet frame (%s)\n", tspws_hip_last_error());
+		return rc == TSPWS_E_NODEV ? rc : TSPWS_E_NOMEM;
+	}
+	TRY(tspws_hip_multi_upload(m, in->sigall, ld, mtr, &d_shards, &d_ls, &d_ts));
+	TRY(tspws_hip_multi_prologue(m, in->sigall, ld, ld, mtr, do_fold, tspws->lrm));
+	const int want_jk = tspws->jackknife_n > 0 && tspws->jackknife_d > 0 && tspws->Kmax && tspws->Kmax <= mtr && out->M && out->ls_subsmpl &&
+	                    out->tsPWS_subsmpl && out->mtr_subsmpl;
+	int jk_ready = 0;
+	if (want_jk) {
+		const unsigned C = out->M;
+		sel = (char *)malloc((size_t)C * mtr);
+		jk = (float *)malloc(2 * (size_t)C * ld * sizeof(float));
+		if (!sel || !jk) { rc = TSPWS_E_NOMEM; goto done; }
+		if (tspws_jackknife_plan(sel, in->time, mtr, tspws->jackknife_d, tspws->jackknife_n, C) == 0) {
+			jk_ready = 1;
+			TRY(tspws_hip_multi_stack_jackknife(m, tspws, d_shards, ld, mtr, d_ls, d_ts, sel, C, jk, jk + (size_t)C * ld, out->mtr_subsmpl));
+			for (unsigned c = 0; c < C; c++) {
+				memcpy(out->ls_subsmpl[c], jk + (size_t)c * ld, ld * sizeof(float));
+				memcpy(out->tsPWS_subsmpl[c], jk + ((size_t)C + c) * ld, ld * sizeof(float));
+			}
+		} else
+			printf("tspws_main: jackknife needs trace start times (binary input); replicas left untouched.\n");
+	}
+	if (!jk_ready) TRY(tspws_hip_multi_stack(m, tspws, d_shards, ld, mtr, d_ls, d_ts));
+	TRY(tspws_hip_download(out->ls, d_ls, ld * sizeof(float), NULL));
+	TRY(tspws_hip_download(out->tsPWS, d_ts, ld * sizeof(float), NULL));
+done:
+	if (rc) printf("tspws_main: HIP path failed (%d: %s)\n", rc, tspws_hip_last_error());
+	free(sel);
+	free(jk);
+	if (!cache_enabled()) tspws_main_release();
+	return rc;
 }
 
 /* the frame of (type, J, V, N, s0, b0, w0, uni) on `dev`: the cached one when every parameter matches bit for bit */
@@ -142,6 +243,15 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 	const size_t ld = (size_t)max;
 
 	if (!mtr) return 0; /* the reference builds the family and returns 0 without touching out (:194) */
+
+	{ /* several devices (or TSPWS_COMM set: the sharded path even on one device -- tests) */
+		int devs[TSPWS_MAX_DEVICES];
+		const int ndev = devices_from_env(devs, TSPWS_MAX_DEVICES);
+		const int needs_one = (tspws->convergence && out->ls_sim && out->tsPWS_sim && out->ls_misfit && out->tsPWS_misfit) ||
+		                      (tspws->subsmpl_N > 0 && tspws->subsmpl_p > 0 && out->ls_subsmpl && out->tsPWS_subsmpl);
+		if ((ndev > 1 || (ndev == 1 && getenv("TSPWS_COMM"))) && !needs_one && tspws->J && tspws->V)
+			return main_multi(tspws, out, in, mtr, do_fold, devs, ndev);
+	}
 
 	int frame_rc = get_plan(&plan, tspws, nsamp, dev);
 	if (frame_rc) {
