@@ -461,16 +461,30 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
 		const unsigned nb = (unsigned)std::min(batch, ntr - t0), nblk = (nb + 63) / 64, TP = nblk * 64;
 		const TIn *xb = d_x + t0 * ld;
-		hipLaunchKernelGGL((k_transpose_traces<TIn>), dim3((p->N + 63) / 64, nblk), dim3(256), 0, st, xb, ld, nb, p->N, TP, xT);
-		hipLaunchKernelGGL((k_fwd_tl<TIn>), dim3(p->tl_wgs, nblk), dim3(TL_NT), p->tl_lds, st, (const TIn *)xT, TP, nb, p->N, p->d_tl, p->tl_n, p->d_w,
-		                   planes, planes + p->ncoef, 2 * p->ncoef, part, p->tl_npart);
-		if (p->tl_waves) { // scales with too few outputs for the trace-lane kernel: direct kernel, tl partial layout
+		// the direct kernel (scales with too few outputs for the trace-lane kernel: latency-bound, tl partial layout) on the side
+		// stream: it reads the traces themselves, so it starts with the transposition and runs beside the trace-lane kernel
+		hipStream_t sp = st;
+		if (p->tl_waves) {
+			const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+			if (!p->side) HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+			if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, evf));
+			if (!p->ev_join) HIP_TRY(hipEventCreateWithFlags(&p->ev_join, evf));
+			HIP_TRY(hipEventRecord(p->ev_fork, st)); // (after the previous batch's accumulation: `part` is free again)
+			HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+			sp = p->side;
 			const unsigned nbw = (p->tl_waves + 3) / 4;
 			for (size_t u0 = 0; u0 < nb; u0 += 2 * 32768) {
 				const unsigned nt = (unsigned)std::min<size_t>(nb - u0, 2 * 32768);
-				hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nbw, (nt + 1) / 2), dim3(256), 0, st, xb + u0 * ld, ld, nt, p->N, p->d_sc_tl, p->S, p->d_w,
+				hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nbw, (nt + 1) / 2), dim3(256), 0, sp, xb + u0 * ld, ld, nt, p->N, p->d_sc_tl, p->S, p->d_w,
 				                   part + u0 * p->tl_npart, p->tl_npart, p->tl_waves);
 			}
+		}
+		hipLaunchKernelGGL((k_transpose_traces<TIn>), dim3((p->N + 63) / 64, nblk), dim3(256), 0, st, xb, ld, nb, p->N, TP, xT);
+		hipLaunchKernelGGL((k_fwd_tl<TIn>), dim3(p->tl_wgs, nblk), dim3(TL_NT), p->tl_lds, st, (const TIn *)xT, TP, nb, p->N, p->d_tl, p->tl_n, p->d_w,
+		                   planes, planes + p->ncoef, 2 * p->ncoef, part, p->tl_npart);
+		if (sp != st) {
+			HIP_TRY(hipEventRecord(p->ev_join, sp));
+			HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
 		}
 		FuseOut fz;
 		fz.accST = planes; fz.accPS = planes + p->ncoef; fz.stride = 2 * p->ncoef; fz.tps = 64; fz.applied = true;
