@@ -12,6 +12,9 @@ cd $R
 python3 profiles/summarize_rocpd.py gpurun_out/prof_$TAG/b_results.db > gpurun_out/${TAG}_stats.txt 2>&1
 python3 profiles/timeline_rocpd.py gpurun_out/prof_$TAG/b_results.db 14 > gpurun_out/${TAG}_timeline.txt 2>&1
 bash profiles/collect_pmc.sh $TAG > /dev/null 2>&1
-python3 tools/bench_configs.py > gpurun_out/${TAG}_configs.json 2>/dev/null
 python3 tools/cfg1_run.py 2>/dev/null | grep cfg1 > gpurun_out/${TAG}_cfg1.txt
-tail -c 2500 gpurun_out/${TAG}_bench_line.json; cat gpurun_out/${TAG}_stats.txt gpurun_out/${TAG}_timeline.txt gpurun_out/${TAG}_configs.json gpurun_out/${TAG}_cfg1.txt; grep -A30 "k_partial" gpurun_out/pmc_$TAG.txt | head -40
+# kernel stats of the other configs (bench.py's other_configs leg times them; these are the per-kernel breakdowns)
+bash tools/gpu_prof_cfg.sh ${TAG}cfg2 tools/cfg2_run.py > /dev/null 2>&1; cp gpurun_out/stats_${TAG}cfg2.txt gpurun_out/${TAG}_stats_cfg2.txt
+bash tools/gpu_prof_cfg.sh ${TAG}cfg4 tools/cfg4_run.py > /dev/null 2>&1; cp gpurun_out/stats_${TAG}cfg4.txt gpurun_out/${TAG}_stats_cfg4.txt
+rm -rf gpurun_out/prof_${TAG}* gpurun_out/pmc_$TAG
+tail -c 3500 gpurun_out/${TAG}_bench_line.json; cat gpurun_out/${TAG}_stats.txt gpurun_out/${TAG}_timeline.txt gpurun_out/${TAG}_cfg1.txt gpurun_out/${TAG}_stats_cfg2.txt gpurun_out/${TAG}_stats_cfg4.txt; grep -A30 "k_partial" gpurun_out/pmc_$TAG.txt | head -40
