@@ -28,8 +28,12 @@ def sac_list(tmp_path_factory, golden):
     return d
 
 
-def run_cli(cwd, *args):
-    r = subprocess.run([EXE, *args], cwd=cwd, capture_output=True, text=True, timeout=600)
+def run_cli(cwd, *args, env=None):
+    e = None
+    if env:
+        e = dict(os.environ)
+        e.update(env)
+    r = subprocess.run([EXE, *args], cwd=cwd, capture_output=True, text=True, timeout=600, env=e)
     assert r.returncode == 0, r.stdout + r.stderr
     return r.stdout
 
@@ -84,6 +88,22 @@ def test_example3_bin_twostage_and_jackknife(sac_list, golden):
     run_cli(sac_list, "list.txt", "osac=jk2", "TwoStage=4", "jackknife_n=4", "jackknife_d=1")
     r0 = abi.read_sac(sac_list / "ts_pws_jk2_subsmpl_0.sac")
     assert abi.relerr(r0["data"], want["jk_ts"][0]) < 2e-6 and r0["f"][40] == float(want["jk_mtr"][0])
+
+
+def test_cli_over_a_device_list_needs_no_python(sac_list, golden):
+    """The C front-end alone (no Python, no torch in the process) under TSPWS_DEVICES: (a) one device through RCCL -- the
+    library binds librccl.so.1 by itself and the stacks go through ncclAllReduce on a one-device communicator; (b) three
+    virtual shards of the one GPU (the library's own reduction kernel).  Same files as the single-device run."""
+    g = golden["example32"]
+    for tag, env in (("rccl", dict(TSPWS_DEVICES="0", TSPWS_COMM="rccl")), ("loc3", dict(TSPWS_DEVICES="0,0,0"))):
+        run_cli(sac_list, "list.txt", f"osac=md_{tag}", "wu=2", "rm", "fold", "TwoStage=10", "unbiased", "fmin=0.004", "J=3", env=env)
+        ts = abi.read_sac(sac_list / f"ts_pws_md_{tag}.sac")
+        ls = abi.read_sac(sac_list / f"tl_md_{tag}.sac")
+        assert abi.relerr(ts["data"], g["ex3/tsPWS"][8250:]) < 2e-6 and ts["f"][40] == 32.0
+        assert np.isfinite(ls["data"]).all() and ls["i"][9] == 8251
+        run_cli(sac_list, "list.txt", f"osac=sd_{tag}", env=env)            # single-stage: ST || PS are what the devices add
+        ts1 = abi.read_sac(sac_list / f"ts_pws_sd_{tag}.sac")
+        assert abi.relerr(ts1["data"], g["ex1/tsPWS"]) < 2e-6
 
 
 def test_convergence_and_subsampling_outputs(sac_list, golden):
