@@ -100,7 +100,7 @@ static size_t tl_min_traces()
 	return (size_t)v;
 }
 
-static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS);
+static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, TlTable &T);
 
 // Work decomposition of the forward kernels.  Scales with >= 8 output groups and (D >= 64 or D a power of two) run on the
 // LDS-staged kernel; the rest (very coarse scales, odd small decimations) on the direct kernel, which aims at ~FWD_STEPS
@@ -140,16 +140,22 @@ int tspws_build_forward(tspws_hip_plan *p)
 		p->n_fusable += d.fuse_ok;
 	}
 	p->fwd_waves = woff; p->lds_blocks = boff; p->npart = poff;
-	return build_tl_forward(p, FWD_STEPS);
+	// two many-trace decompositions (see stacks_tl for the choice): sweeps on 128 .. 2048 traces x 8192 .. 32768 samples, Morlet
+	// and Mexican hat (round 3): batches of >= 12 trace blocks are fastest with the octaves of >= 33 outputs on the trace-lane
+	// kernel, smaller batches (and frames with two voices per octave) with >= 257 -- the trace-lane kernel has tl.wgs x blocks
+	// workgroups, the direct kernel splits the taps
+	if (int rc = build_tl_forward(p, FWD_STEPS, 33, p->tl[0])) return rc;
+	return build_tl_forward(p, FWD_STEPS, 257, p->tl[1]);
 }
 
-// Decomposition for many-trace batches (fwd_tl.h): octaves (runs of scales with the same D and Ns) with at least TL_MINNS
-// outputs become trace-lane work items (voice subsets of <= TL_VMAX voices), the rest stays on the direct kernel; sc_tl is
+// Decomposition for many-trace batches (fwd_tl.h): octaves (runs of scales with the same D and Ns) with at least MINNS
+// outputs become trace-lane work items (voice subsets of <= TL_VMAX voices), the rest stays on the direct kernel; T.sc is
 // the scale table of that decomposition (partial layout, fused flags, accumulate geometry).
-static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS)
+static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, TlTable &T)
 {
-	const unsigned MINNS = 17, TLSTEPS = 96; // >= 3 of the 4 waves of an output block busy; ~96 residue steps per workgroup (sweeps on 1024 x 32768 and 499 x 16501)
-	p->sc_tl = p->sc;
+	const unsigned TLSTEPS = 96; // ~96 residue steps per workgroup (sweeps on 1024 x 32768 and 499 x 16501)
+	T.minns = MINNS;
+	T.sc = p->sc;
 	std::vector<TLItem> items;
 	std::vector<char> is_tl(p->S, 0);
 	unsigned wg = 0;
@@ -193,7 +199,7 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS)
 					// a workgroup should walk >= ~64 residue steps: with few residues per output block it takes several blocks
 					o.kbw = std::max(1u, std::min(o.nkb, TLSTEPS / std::max(1u, o.pps)));
 					o.wg_off = wg; wg += ((o.nkb + o.kbw - 1) / o.kbw) * o.nsplit;
-					p->tl_lds = std::max(p->tl_lds, 2 * ((size_t)o.XR * 64 * sizeof(double) + (size_t)o.trows * sizeof(double2)));
+					T.lds = std::max(T.lds, 2 * ((size_t)o.XR * 64 * sizeof(double) + (size_t)o.trows * sizeof(double2)));
 					items.push_back(o);
 				}
 				for (unsigned v = s; v < e; v++) is_tl[v] = 1;
@@ -205,7 +211,7 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS)
 	unsigned woff = 0, ablk = 0;
 	unsigned long long poff = 0;
 	for (unsigned s = 0; s < p->S; s++) {
-		ScaleDesc &d = p->sc_tl[s];
+		ScaleDesc &d = T.sc[s];
 		d.use_lds = 0; d.lds_off = 0;
 		if (is_tl[s]) {
 			d.nsplit = (d.D + TL_PMAX - 1) / TL_PMAX; d.cps = 1;
@@ -223,13 +229,13 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS)
 		d.acc2_off = ablk;
 		ablk += d.nsplit > 1 ? (d.Ns + 3) / 4 : (d.Ns + 255) / 256; // split scales: 4 coefficients per block (k_accumulate_parts, many)
 	}
-	for (TLItem &o : items) for (unsigned i = 0; i < o.nv; i++) o.part_off[i] = p->sc_tl[o.sc[i]].part_off;
-	p->tl_n = (unsigned)items.size(); p->tl_wgs = wg; p->tl_waves = woff; p->tl_acc2_blocks = ablk; p->tl_npart = poff;
-	if (!p->tl_n) return 0;
-	HIP_TRY(hipMalloc(&p->d_sc_tl, p->S * sizeof(ScaleDesc)));
-	HIP_TRY(hipMemcpy(p->d_sc_tl, p->sc_tl.data(), p->S * sizeof(ScaleDesc), hipMemcpyHostToDevice));
-	HIP_TRY(hipMalloc(&p->d_tl, items.size() * sizeof(TLItem)));
-	HIP_TRY(hipMemcpy(p->d_tl, items.data(), items.size() * sizeof(TLItem), hipMemcpyHostToDevice));
+	for (TLItem &o : items) for (unsigned i = 0; i < o.nv; i++) o.part_off[i] = T.sc[o.sc[i]].part_off;
+	T.n = (unsigned)items.size(); T.wgs = wg; T.waves = woff; T.acc2_blocks = ablk; T.npart = poff;
+	if (!T.n) return 0;
+	HIP_TRY(hipMalloc(&T.d_sc, p->S * sizeof(ScaleDesc)));
+	HIP_TRY(hipMemcpy(T.d_sc, T.sc.data(), p->S * sizeof(ScaleDesc), hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc(&T.d_items, items.size() * sizeof(TLItem)));
+	HIP_TRY(hipMemcpy(T.d_items, items.data(), items.size() * sizeof(TLItem), hipMemcpyHostToDevice));
 	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_tl<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_tl<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	return 0;
@@ -355,7 +361,7 @@ bool tspws_generic_forward()
 
 bool tspws_fused_forward(const tspws_hip_plan *p) { return p->n_fusable != 0; }
 
-bool tspws_many_trace_path(const tspws_hip_plan *p, size_t ntr) { return ntr >= tl_min_traces() && p->tl_n && !tspws_generic_forward(); }
+bool tspws_many_trace_path(const tspws_hip_plan *p, size_t ntr) { return ntr >= tl_min_traces() && (p->tl[0].n || p->tl[1].n) && !tspws_generic_forward(); }
 
 template <typename TIn>
 static int forward_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_Y, hipStream_t st)
@@ -418,7 +424,7 @@ extern "C" int tspws_hip_accumulate(tspws_hip_plan *p, const double *d_Y, size_t
 
 // launches k_accumulate_parts for `nb` transformed traces; fz = what the forward launch left behind (may be NULL / not applied)
 void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb, double2 *ST, double2 *PS, int zero_first, const FuseOut *fz,
-                             unsigned nslices, hipStream_t st, unsigned nbatch, size_t y_part, size_t y_stack, bool tl, const WeightArgs *wa,
+                             unsigned nslices, hipStream_t st, unsigned nbatch, size_t y_part, size_t y_stack, const TlTable *tl, const WeightArgs *wa,
                              ScaleRange rg)
 {
 	WeightArgs w0; w0.OUT = nullptr; w0.mode = 0; w0.K = w0.M = w0.wu = 0;
@@ -426,10 +432,10 @@ void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb
 	const bool direct = on && fz->accST == ST; // the single slice went straight into ST / PS
 	// tl: the many-trace decomposition's scale table (partial layout, fused flags, block geometry)
 	const LaunchRange lr = launch_range(p, rg);
-	const unsigned a0 = tl ? 0u : lr.acc0, a1 = tl ? p->tl_acc2_blocks : lr.acc1;
+	const unsigned a0 = tl ? 0u : lr.acc0, a1 = tl ? tl->acc2_blocks : lr.acc1;
 	if (a1 <= a0) return;
-	hipLaunchKernelGGL(k_accumulate_parts, dim3(a1 - a0, nbatch), dim3(256), 0, st, part, tl ? p->tl_npart : p->npart,
-	                   tl ? p->d_sc_tl : p->d_sc, p->S, nb, ST, PS, zero_first,
+	hipLaunchKernelGGL(k_accumulate_parts, dim3(a1 - a0, nbatch), dim3(256), 0, st, part, tl ? tl->npart : p->npart,
+	                   tl ? tl->d_sc : p->d_sc, p->S, nb, ST, PS, zero_first,
 	                   on ? (direct ? 1 : 2) : 0, on ? (const double2 *)fz->accST : nullptr, on ? (const double2 *)fz->accPS : nullptr,
 	                   on ? fz->stride : (size_t)0, nslices, y_part, y_stack, tl ? 1 : 0, wa ? *wa : w0, a0);
 }
@@ -446,9 +452,12 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 {
 	int rc;
 	void *v;
+	// decomposition: many trace blocks and more than two voices per octave -> tl[0], else tl[1] (tspws_build_forward)
+	const unsigned pick = ((ntr + 63) / 64 >= 12 && p->V > 2) ? 0u : 1u;
+	const TlTable &T = p->tl[p->tl[pick].n ? pick : 1u - pick]; // (a short frame may leave one of them without trace-lane items)
 	// traces per batch: transposed copy <= 1 GiB, at most 4096 (64 plane pairs), a multiple of 64
 	size_t batch = std::min<size_t>(4096, std::max<size_t>(64, (((size_t)1 << 30) / ((size_t)p->N * sizeof(TIn))) & ~(size_t)63));
-	if (p->tl_npart) batch = std::min(batch, std::max<size_t>(64, (tspws_part_budget_bytes() / (p->tl_npart * sizeof(double2))) & ~(size_t)63));
+	if (T.npart) batch = std::min(batch, std::max<size_t>(64, (tspws_part_budget_bytes() / (T.npart * sizeof(double2))) & ~(size_t)63));
 	if (const char *e = getenv("TSPWS_TL_BATCH")) batch = std::max<size_t>(64, (size_t)atoi(e) & ~(size_t)63); // tests: force several batches
 	batch = std::min(batch, (ntr + 63) & ~(size_t)63);
 	const size_t nblk_max = batch / 64;
@@ -457,14 +466,14 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 	if ((rc = scratch(p, SCR_FZ, nblk_max * 2 * p->ncoef * sizeof(double2), &v))) return rc;
 	double2 *planes = (double2 *)v;
 	double2 *part = nullptr;
-	if (p->tl_npart) { if ((rc = scratch(p, SCR_PART, batch * p->tl_npart * sizeof(double2), &v))) return rc; part = (double2 *)v; }
+	if (T.npart) { if ((rc = scratch(p, SCR_PART, batch * T.npart * sizeof(double2), &v))) return rc; part = (double2 *)v; }
 	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
 		const unsigned nb = (unsigned)std::min(batch, ntr - t0), nblk = (nb + 63) / 64, TP = nblk * 64;
 		const TIn *xb = d_x + t0 * ld;
 		// the direct kernel (scales with too few outputs for the trace-lane kernel: latency-bound, tl partial layout) on the side
 		// stream: it reads the traces themselves, so it starts with the transposition and runs beside the trace-lane kernel
 		hipStream_t sp = st;
-		if (p->tl_waves) {
+		if (T.waves) {
 			const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
 			if (!p->side) HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
 			if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, evf));
@@ -472,16 +481,16 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 			HIP_TRY(hipEventRecord(p->ev_fork, st)); // (after the previous batch's accumulation: `part` is free again)
 			HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
 			sp = p->side;
-			const unsigned nbw = (p->tl_waves + 3) / 4;
+			const unsigned nbw = (T.waves + 3) / 4;
 			for (size_t u0 = 0; u0 < nb; u0 += 2 * 32768) {
 				const unsigned nt = (unsigned)std::min<size_t>(nb - u0, 2 * 32768);
-				hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nbw, (nt + 1) / 2), dim3(256), 0, sp, xb + u0 * ld, ld, nt, p->N, p->d_sc_tl, p->S, p->d_w,
-				                   part + u0 * p->tl_npart, p->tl_npart, p->tl_waves);
+				hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nbw, (nt + 1) / 2), dim3(256), 0, sp, xb + u0 * ld, ld, nt, p->N, T.d_sc, p->S, p->d_w,
+				                   part + u0 * T.npart, T.npart, T.waves);
 			}
 		}
 		hipLaunchKernelGGL((k_transpose_traces<TIn>), dim3((p->N + 63) / 64, nblk), dim3(256), 0, st, xb, ld, nb, p->N, TP, xT);
-		hipLaunchKernelGGL((k_fwd_tl<TIn>), dim3(p->tl_wgs, nblk), dim3(TL_NT), p->tl_lds, st, (const TIn *)xT, TP, nb, p->N, p->d_tl, p->tl_n, p->d_w,
-		                   planes, planes + p->ncoef, 2 * p->ncoef, part, p->tl_npart);
+		hipLaunchKernelGGL((k_fwd_tl<TIn>), dim3(T.wgs, nblk), dim3(TL_NT), T.lds, st, (const TIn *)xT, TP, nb, p->N, T.d_items, T.n, p->d_w,
+		                   planes, planes + p->ncoef, 2 * p->ncoef, part, T.npart);
 		if (sp != st) {
 			HIP_TRY(hipEventRecord(p->ev_join, sp));
 			HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
@@ -489,7 +498,7 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 		FuseOut fz;
 		fz.accST = planes; fz.accPS = planes + p->ncoef; fz.stride = 2 * p->ncoef; fz.tps = 64; fz.applied = true;
 		const bool last = t0 + batch >= ntr; // the launch that completes the stacks also weights them (wa)
-		tspws_launch_accumulate(p, part, nb, (double2 *)d_ST, (double2 *)d_PS, (t0 == 0 && !keep) ? 1 : 0, &fz, nblk, st, 1, 0, 0, true, last && !keep ? wa : nullptr, ScaleRange());
+		tspws_launch_accumulate(p, part, nb, (double2 *)d_ST, (double2 *)d_PS, (t0 == 0 && !keep) ? 1 : 0, &fz, nblk, st, 1, 0, 0, &T, last && !keep ? wa : nullptr, ScaleRange());
 		if (last && !keep && wa && wa->OUT && weighted) *weighted = true;
 	}
 	HIP_TRY(hipGetLastError());
@@ -543,7 +552,7 @@ static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld,
 		}
 		if ((rc = forward_parts<TIn>(p, d_x + t0 * ld, nb, ld, (double2 *)v, st, fuse ? &fz : nullptr, rg))) return rc;
 		const bool all = nb == ntr && !keep; // one batch holds every trace: the accumulation completes the stacks
-		tspws_launch_accumulate(p, (const double2 *)v, (unsigned)nb, (double2 *)d_ST, (double2 *)d_PS, zero_first, &fz, nsl, st, 1, 0, 0, false, all ? wa : nullptr, rg);
+		tspws_launch_accumulate(p, (const double2 *)v, (unsigned)nb, (double2 *)d_ST, (double2 *)d_PS, zero_first, &fz, nsl, st, 1, 0, 0, nullptr, all ? wa : nullptr, rg);
 		if (all && wa && wa->OUT && weighted) *weighted = true;
 	}
 	HIP_TRY(hipGetLastError());

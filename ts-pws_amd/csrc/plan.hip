@@ -225,8 +225,7 @@ extern "C" void tspws_hip_plan_destroy(tspws_hip_plan *p)
 	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
 	if (p->side) (void)hipStreamDestroy(p->side);
 	if (p->d_oc) (void)hipFree(p->d_oc);
-	if (p->d_sc_tl) (void)hipFree(p->d_sc_tl);
-	if (p->d_tl) (void)hipFree(p->d_tl);
+	for (TlTable &T : p->tl) { if (T.d_sc) (void)hipFree(T.d_sc); if (T.d_items) (void)hipFree(T.d_items); }
 	if (p->d_sc) (void)hipFree(p->d_sc);
 	if (p->d_w) (void)hipFree(p->d_w);
 	if (p->d_wd) (void)hipFree(p->d_wd);

@@ -213,7 +213,7 @@ static int finish_replicas(tspws_hip_plan *pl, const t_tsPWS *p, double *d_P, co
 		// the replicas of the batch side by side in every launch (grid.y): stacks of the scales the fused kernel left out,
 		// weights with each replica's trace count, time-domain linear stacks, inverses two replicas per tap read, outputs
 		FuseOut fj = fz; // replica j's slice went straight into its ST / PS planes
-		tspws_launch_accumulate(pl, (const double2 *)part, KM, (double2 *)STr, (double2 *)STr + nc, 1, &fj, 1, st, nr, (size_t)KM * pl->npart, 2 * nc, false, nullptr,
+		tspws_launch_accumulate(pl, (const double2 *)part, KM, (double2 *)STr, (double2 *)STr + nc, 1, &fj, 1, st, nr, (size_t)KM * pl->npart, 2 * nc, nullptr, nullptr,
 		                        ScaleRange());
 		tspws_weight_batched(pl, (double2 *)OUT, (const double2 *)STr, (const double2 *)STr + nc, tspws_weight_mode(p->wu, p->unbiased, KM), (double)KM, p->wu,
 		                     (const double *)(d_Mv + c0), nr, nc, 2 * nc, st);
@@ -522,7 +522,7 @@ extern "C" int tspws_hip_convergence(tspws_hip_plan *pl, const t_tsPWS *p, const
 		if (!p->Kmax || p->Kmax >= Tr) { // incremental single-stage step (tspws_stacks_float_1step, :835-863)
 			K = (unsigned)Tr;
 			if ((rc = tspws_forward_parts_f32(pl, d_x + i * ld, 1, ld, part, st, nullptr, ScaleRange()))) return rc;
-			tspws_launch_accumulate(pl, (const double2 *)part, 1u, (double2 *)ST, (double2 *)PS, i == 0 ? 1 : 0, nullptr, 0, st, 1, 0, 0, false, nullptr, ScaleRange());
+			tspws_launch_accumulate(pl, (const double2 *)part, 1u, (double2 *)ST, (double2 *)PS, i == 0 ? 1 : 0, nullptr, 0, st, 1, 0, 0, nullptr, nullptr, ScaleRange());
 		} else { // two-stage over the first Tr traces, recomputed from scratch like the reference (:266-268)
 			K = p->Kmax;
 			if ((rc = tspws_hip_partial_stacks(pl, d_x, ld, Tr, 0, Tr, K, P, N, s))) return rc;

@@ -107,6 +107,17 @@ enum { SCR_Y = 0, SCR_PART, SCR_XT, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_
 struct OctDesc; // inverse work items (inv_poly.h)
 struct TLItem;  // many-trace forward work items (fwd_tl.h)
 
+// One work decomposition of the many-trace forward path: its own scale table (partial layout, fused flags, accumulate
+// geometry), the trace-lane work items of k_fwd_tl and the waves of the direct kernel for the scales it leaves out.
+struct TlTable {
+	unsigned minns = 0;              // octaves with fewer outputs than this stay on the direct kernel
+	std::vector<ScaleDesc> sc;
+	ScaleDesc *d_sc = nullptr;
+	TLItem *d_items = nullptr;
+	unsigned n = 0, wgs = 0, waves = 0, acc2_blocks = 0; // items, workgroups per trace block, direct-kernel waves, accumulate blocks
+	size_t npart = 0, lds = 0;
+};
+
 struct tspws_hip_plan {
 	int device = 0, type = -1;
 	unsigned S = 0, V = 0, J = 0, N = 0;
@@ -118,12 +129,9 @@ struct tspws_hip_plan {
 	unsigned acc2_blocks = 0;  // blocks of k_accumulate_parts
 	unsigned lds_blocks = 0;   // workgroups per trace slice of k_fwd_lds
 	unsigned n_fusable = 0;    // scales whose stacks the fused forward kernel keeps in registers
-	// many-trace decomposition (fwd_tl.h): second scale table, trace-lane work items
-	std::vector<ScaleDesc> sc_tl;
-	ScaleDesc *d_sc_tl = nullptr;
-	TLItem *d_tl = nullptr;
-	unsigned tl_n = 0, tl_wgs = 0, tl_waves = 0, tl_acc2_blocks = 0; // items, workgroups per trace block, direct-kernel waves, accumulate blocks
-	size_t tl_npart = 0, tl_lds = 0;
+	// many-trace decompositions (fwd_tl.h): tl[0] for batches of many 64-trace blocks, tl[1] for few (more scales on the
+	// direct kernel, whose parallelism is in the taps): see TlTable
+	TlTable tl[2];
 	std::vector<unsigned> oc_s0, oc_nv, oc_wave_off, oc_nwaves, oc_gen; // host copy of the inverse's octave items (launch order)
 	unsigned inv_waves = 0, inv_waves_fast = 0, inv_noct = 0, inv_ngeneric = 0; // polyphase inverse: waves (of the octaves whose D divides N first), octave items, scales left to the generic kernel
 	OctDesc *d_oc = nullptr;
@@ -237,7 +245,7 @@ int  tspws_stacks_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, size_t l
                       const WeightArgs *wa, bool *weighted, ScaleRange rg);
 // k_accumulate_parts for nb transformed traces (nbatch independent stacks side by side: y_part / y_stack apart)
 void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb, double2 *ST, double2 *PS, int zero_first, const FuseOut *fz,
-                             unsigned nslices, hipStream_t st, unsigned nbatch, size_t y_part, size_t y_stack, bool tl, const WeightArgs *wa,
+                             unsigned nslices, hipStream_t st, unsigned nbatch, size_t y_part, size_t y_stack, const TlTable *tl, const WeightArgs *wa,
                              ScaleRange rg);
 bool tspws_fused_forward(const tspws_hip_plan *p);        // the few-trace forward kernel stacks some scales in registers
 bool tspws_many_trace_path(const tspws_hip_plan *p, size_t ntr); // a batch this size goes to the trace-lane kernel
