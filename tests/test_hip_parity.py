@@ -497,8 +497,9 @@ def test_random_subsampling_vs_oracle(lib, kw):
 
 # ------------------------------------------------------------------------------- layout edge cases
 @pytest.mark.parametrize("pad", [4, 1])
-def test_padded_rows_and_many_traces(lib, torch, pad):
+def test_padded_rows_and_many_traces(lib, torch, pad, monkeypatch):
     """Row stride ld > N (vectorised when ld % 4 == 0, scalar otherwise) through the device-resident path."""
+    monkeypatch.setenv("TSPWS_TL_MIN", "64")   # (the single-stage part below goes through the many-trace kernel)
     mtr, N, K = 70, 4096, 7
     p = tspws.resolve(abi.default_params(Kmax=K, unbiased=1), N)
     pl = tspws.Plan(p, N)
@@ -769,10 +770,12 @@ def test_sharded_jackknife_rows_add_up(lib, torch, kw, bounds):
     (dict(b0=4.0), 8192, 80),
     (dict(Kmax=80, unbiased=1), 2048, 200),   # two-stage with many groups: the 80 FP64 partial stacks take the many-trace path too
 ])
-def test_many_trace_single_stage_vs_oracle(lib, torch, kw, N, mtr):
+def test_many_trace_single_stage_vs_oracle(lib, torch, kw, N, mtr, monkeypatch):
     """Single-stage stacks of >= 64 traces run on the trace-lane kernel (csrc/fwd_tl.h: transposed batch, lanes = traces, fused
     phase stack per 64-trace block, residue splits for large decimations, direct kernel for the coarsest scales): whole call
-    against the oracle, device-resident and through tspws_main, including partially filled trace blocks and an all-zero trace."""
+    against the oracle, device-resident and through tspws_main, including partially filled trace blocks and an all-zero trace.
+    (TSPWS_TL_MIN forces that path: by default ensembles this small stay on the few-trace kernels.)"""
+    monkeypatch.setenv("TSPWS_TL_MIN", "64")
     X = abi.synth_traces(mtr, N, seed=41)
     X[mtr // 3] = 0.0
     want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), X)
@@ -785,9 +788,29 @@ def test_many_trace_single_stage_vs_oracle(lib, torch, kw, N, mtr):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw,mtr,N", [(dict(), 100, 8192), (dict(), 1000, 8192), (dict(type=-3), 1000, 8192)])
+def test_single_stage_path_choice_is_invisible(lib, torch, kw, mtr, N, monkeypatch):
+    """The library picks the forward path of a single-stage batch by its size and frame (few-trace kernels below ~7 M samples and
+    for two-voice frames, the trace-lane kernel above): forced either way and left alone, the call gives the oracle's outputs."""
+    X = abi.synth_traces(mtr, N, seed=48)
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), X)
+    Xd = torch.as_tensor(X, device="cuda")
+    for force in (None, "64", "1000000"):
+        if force is None:
+            monkeypatch.delenv("TSPWS_TL_MIN", raising=False)
+        else:
+            monkeypatch.setenv("TSPWS_TL_MIN", force)
+        pl = tspws.Plan(tspws.resolve(abi.default_params(**kw), N), N)
+        ls, ts = pl.stack(Xd)
+        torch.cuda.synchronize()
+        assert abi.relerr(ls.cpu().numpy(), want["ls"]) < TOL32 and abi.relerr(ts.cpu().numpy(), want["tsPWS"]) < TOL32, force
+
+
+@pytest.mark.gpu
 def test_many_trace_batches(lib, torch, monkeypatch):
     """The trace-lane path walks large ensembles in batches (transposed copy <= 1 GiB): forced here to 64 / 128 traces per batch,
     the later batches add to the stacks of the first, the last one is partial."""
+    monkeypatch.setenv("TSPWS_TL_MIN", "64")
     mtr, N = 200, 2048
     X = abi.synth_traces(mtr, N, seed=47)
     want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(), X)
@@ -800,10 +823,11 @@ def test_many_trace_batches(lib, torch, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_many_trace_path_matches_the_few_trace_kernels(lib, torch):
+def test_many_trace_path_matches_the_few_trace_kernels(lib, torch, monkeypatch):
     """Same ensemble through the trace-lane decomposition (stack_local on 192 traces: the single-stage all-reduce payload
     ST || PS) and through the per-trace forward API (k_fwd_lds / k_fwd_poly, coefficients of every trace) with the stacks
     formed on the host: the FP64 stacks agree to rounding."""
+    monkeypatch.setenv("TSPWS_TL_MIN", "64")
     mtr, N = 192, 8192
     p = tspws.resolve(abi.default_params(), N)
     Xd = tspws.synth(mtr, N, seed=43)

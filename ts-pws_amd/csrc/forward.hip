@@ -93,11 +93,11 @@ static int forward_generic(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t
 #include "fwd_lds.h"
 #include "fwd_tl.h"
 
-static size_t tl_min_traces()
+// TSPWS_TL_MIN=n forces the many-trace path for batches of >= n traces (tests; read at every call), unset: the rule below
+static long tl_min_env()
 {
-	static long v = -1;
-	if (v < 0) { const char *e = getenv("TSPWS_TL_MIN"); v = e ? std::max(1, atoi(e)) : 64; }
-	return (size_t)v;
+	const char *e = getenv("TSPWS_TL_MIN");
+	return e ? std::max(1, atoi(e)) : -1;
 }
 
 static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, TlTable &T);
@@ -361,7 +361,19 @@ bool tspws_generic_forward()
 
 bool tspws_fused_forward(const tspws_hip_plan *p) { return p->n_fusable != 0; }
 
-bool tspws_many_trace_path(const tspws_hip_plan *p, size_t ntr) { return ntr >= tl_min_traces() && (p->tl[0].n || p->tl[1].n) && !tspws_generic_forward(); }
+// Does a batch of ntr traces go to the trace-lane kernel?  Round-3 sweeps (tools/cfg_bench.py, 64 .. 4096 traces x 8192 .. 131072
+// samples, both paths forced): below ~7 M samples per batch, or with fewer than three trace blocks, the few-trace kernels win
+// (64 x 32768: 0.37 vs 0.85 ms; 192 x 32768: 0.88 vs 1.01; 256 x 16501: 0.86 vs 1.01), above it the trace-lane kernel
+// (320 x 32768: 1.24 vs 1.40; 1024 x 32768: 3.03 vs 4.19; 256 x 131072: 3.60 vs 4.10); frames with two voices per octave
+// (Mexican hat) stay on the few-trace kernels at every size measured (1024 x 32768: 3.66 vs 4.63; 4096 x 16384: 8.5 vs 9.9) --
+// a trace-lane work item shares its staged rows among the voices of an octave.
+bool tspws_many_trace_path(const tspws_hip_plan *p, size_t ntr)
+{
+	if (!(p->tl[0].n || p->tl[1].n) || tspws_generic_forward()) return false;
+	const long forced = tl_min_env();
+	if (forced > 0) return ntr >= (size_t)forced;
+	return p->V > 2 && ntr >= 160 && (double)ntr * (double)p->N >= 7.0 * 1048576.0;
+}
 
 template <typename TIn>
 static int forward_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_Y, hipStream_t st)
