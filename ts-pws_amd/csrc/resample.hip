@@ -412,13 +412,19 @@ extern "C" int tspws_hip_subsample(tspws_hip_plan *pl, const t_tsPWS *p, const f
 	if ((rc = scratch(pl, SCR_SUBST, (size_t)M * nc * 2 * sizeof(double2), &v))) return rc;
 	double2 *STm = (double2 *)v, *PSm = STm + (size_t)M * nc;
 	HIP_TRY(hipMemsetAsync(STm, 0, (size_t)M * nc * 2 * sizeof(double2), st));
-	if ((rc = scratch(pl, SCR_PART, 8 * pl->npart * sizeof(double2), &v))) return rc;
+	// the traces are transformed 64 at a time (the forward kernels fill the GPU far better than with 8) and handed to the masked
+	// accumulation in its batches of 8, in trace order
+	const size_t FB = std::min<size_t>(64, std::max<size_t>(8, (tspws_part_budget_bytes() / (pl->npart * sizeof(double2))) & ~(size_t)7));
+	if ((rc = scratch(pl, SCR_PART, FB * pl->npart * sizeof(double2), &v))) return rc;
 	double2 *part = (double2 *)v;
-	for (size_t t0 = 0; t0 < mtr; t0 += 8) {
-		const unsigned nb = (unsigned)std::min<size_t>(8, mtr - t0);
-		if ((rc = tspws_forward_parts_f32(pl, d_x + t0 * ld, nb, ld, part, st, nullptr, ScaleRange()))) return rc;
-		hipLaunchKernelGGL(k_accumulate_masked, dim3(pl->acc_blocks), dim3(256), 0, st, (const double2 *)part, pl->npart, pl->d_sc, pl->S, nc,
-		                   nb, d_sel, mtr, t0, M, STm, PSm);
+	for (size_t t0 = 0; t0 < mtr; t0 += FB) {
+		const size_t nf = std::min(FB, mtr - t0);
+		if ((rc = tspws_forward_parts_f32(pl, d_x + t0 * ld, nf, ld, part, st, nullptr, ScaleRange()))) return rc;
+		for (size_t u0 = 0; u0 < nf; u0 += 8) {
+			const unsigned nb = (unsigned)std::min<size_t>(8, nf - u0);
+			hipLaunchKernelGGL(k_accumulate_masked, dim3(pl->acc_blocks), dim3(256), 0, st, (const double2 *)(part + u0 * pl->npart), pl->npart, pl->d_sc, pl->S,
+			                   nc, nb, d_sel, mtr, t0 + u0, M, STm, PSm);
+		}
 	}
 	const float scale = (float)(1. / (double)K); // fa1 = W[m]/K with W = 1 (:580)
 	hipLaunchKernelGGL(k_sub_linear, dim3((unsigned)((N + 255) / 256), M), dim3(256), 0, st, d_x, ld, N, mtr, d_sel, scale, d_ls_out);
