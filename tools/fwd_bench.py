@@ -32,6 +32,10 @@ ST = torch.empty(2 * pl.ncoef, dtype=torch.float64, device="cuda")
 PS = torch.empty(2 * pl.ncoef, dtype=torch.float64, device="cuda")
 
 
+if os.environ.get("TSPWS_FWD_CLASSES"):  # -DFL_ABLATE=1 builds: switch classes of k_fwd_lds off (results wrong, only the clock counts)
+    lib.tspws_hip_fwd_ablate()
+
+
 def timeit(fn):
     for _ in range(5):
         fn()

@@ -267,7 +267,12 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 	const LaunchRange lr = launch_range(p, rg);
 	const bool has_lds = lr.lds1 > lr.lds0, has_poly = lr.wav1 > lr.wav0;
 	hipStream_t sp = st; // stream of the direct kernel
-	if (has_lds && has_poly) {
+#if FL_TIMING || FL_ABLATE
+	static const bool serial = getenv("TSPWS_FWD_SERIAL") != nullptr; // debug builds: the two kernels one after the other
+#else
+	constexpr bool serial = false;
+#endif
+	if (has_lds && has_poly && !serial) {
 		const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence; // device-local ordering only
 		if (!p->side) HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
 		if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, evf));
@@ -326,6 +331,18 @@ int tspws_forward_parts_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, si
 {
 	return forward_parts<double>(p, d_x, ntr, ld, d_part, st, fz, rg);
 }
+
+#if FL_ABLATE
+// debug build only: only the log2(D) classes of k_fwd_lds named by the hex mask TSPWS_FWD_CLASSES run (results wrong: timing ablation)
+extern "C" int tspws_hip_fwd_ablate(void)
+{
+	if (const char *e = getenv("TSPWS_FWD_CLASSES")) {
+		const unsigned m = (unsigned)strtoul(e, nullptr, 16);
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(fl_class_mask), &m, sizeof m));
+	}
+	return 0;
+}
+#endif
 
 #if FL_TIMING
 // debug build only: device buffer of the per-phase wave timers of k_fwd_lds

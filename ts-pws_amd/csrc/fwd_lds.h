@@ -98,6 +98,14 @@ __device__ __forceinline__ void fl_lds_barrier()
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+#ifndef FL_ABLATE
+#define FL_ABLATE 0                             /* 1: debug builds can switch parts of the kernel off (TSPWS_FWD_CLASSES, tools/fwd_bench.py): results wrong, only the clock counts */
+#endif
+#if FL_ABLATE
+// bits 0-6: the workgroups of log2(D) class c run (6: D >= 64); for the D >= 64 workgroups: 0x100 lane reduction and partial
+// stores only after the last trace, 0x200 no FMA passes, 0x400 no LDS image store, 0x800 no window prefetch
+__device__ unsigned fl_class_mask = 0x7fu;
+#endif
 #if FL_TIMING
 __device__ unsigned long long *fl_timing_out; // [7 classes][8]: set-up, barrier 1, stage, barrier 2, FMA, reduce, traces, waves
 #endif
@@ -269,12 +277,21 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 			fl_lds_barrier(); // everyone is done reading the previous image (x rows, taps)
 			FL_STAMP(1); // barrier 1 (+ accumulator reset)
 			if (!resident) { stage_taps(qa, qn); load_x(NWT, xv, xt, qa); }
+#if FL_ABLATE
+			if (!(!SMALL && (fl_class_mask & 0x400u)))
+#endif
 			store_x(xv);
 			FL_STAMP(2); // wait for the prefetched x (vmcnt) + LDS stores
 			fl_lds_barrier();
+#if FL_ABLATE
+			if (!(!SMALL && (fl_class_mask & 0x800u)))
+#endif
 			if (resident && t + 1 < ntr) load_x(NWT, xv, xt + ld, 0); // next trace's window flies while this one is computed
 			FL_STAMP(3); // barrier 2 + issue of the next prefetch
 			// ------------------------------------------------------------------ compute: two passes (group slots) per wave
+#if FL_ABLATE
+			if (!SMALL && (fl_class_mask & 0x200u)) continue;
+#endif
 			if constexpr (WIDE) {
 				constexpr int R2 = 2 * R;
 				const double *xb = xL + wv * (R2 * 64) + lane; // slots 2 wv, 2 wv + 1: outputs (g0 + 2 wv) R .. + 15
@@ -420,6 +437,9 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 			FL_STAMP(5); // lane reduction + phase normalisation
 			continue;
 		}
+#if FL_ABLATE
+		if (!SMALL && (fl_class_mask & 0x100u) && t + 1 < ntr) continue;
+#endif
 		// ------------------------------------------------------------------ store the split partial
 		double *pout = pout0 + (size_t)t * npart * 2;
 		if (SMALL) {
@@ -526,6 +546,9 @@ __device__ __forceinline__ void fwd_lds_workgroup(const unsigned bid, const unsi
 	const double2 *ws = w + d.tap_off;
 	double *pout0 = (double *)(part + (size_t)t0 * npart + d.part_off + (size_t)chunk * d.Ns);
 	double2 *aS = FUSE ? accST + (size_t)slice * acc_stride : nullptr, *aP = FUSE ? accPS + (size_t)slice * acc_stride : nullptr;
+#if FL_ABLATE
+	if (!((fl_class_mask >> (d.D >= 64 ? 6u : d.logDL)) & 1u)) return;
+#endif
 	if (d.D >= 64) { fwd_lds_body<TIn, 6, FUSE, FL_PASSES>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); return; }
 	switch (d.logDL) {
 	case 0: fwd_lds_body<TIn, 0, FUSE, FL_PASSES_FINE>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break; // D = 1 (Mexican hat, uni): 8 coefficients per lane
