@@ -36,6 +36,10 @@ if os.environ.get("TSPWS_FWD_CLASSES"):  # -DFL_ABLATE=1 builds: switch classes 
     lib.tspws_hip_fwd_ablate()
 
 
+if os.environ.get("TSPWS_INV_CLASSES"):  # likewise for the octave classes of k_inv_poly
+    lib.tspws_hip_inv_ablate()
+
+
 def timeit(fn):
     for _ in range(5):
         fn()

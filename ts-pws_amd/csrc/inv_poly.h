@@ -28,6 +28,16 @@
 #pragma once
 
 #define INV_R 8
+#ifndef INV_UNIFORM
+#define INV_UNIFORM 1                           /* 1: D >= 64: the coefficient windows of a wave through the scalar unit */
+#endif
+
+#ifndef FL_ABLATE
+#define FL_ABLATE 0
+#endif
+#if FL_ABLATE
+__device__ unsigned inv_class_mask = 0x7fu;   // debug builds: bit c = the octaves of lanes-per-phase class log2(DL) = c run (6: D >= 64); TSPWS_INV_CLASSES
+#endif
 
 struct OctDesc {
 	unsigned s0, nv;        // first scale, voices
@@ -58,6 +68,9 @@ __global__ void __launch_bounds__(256) k_inv_poly(const double2 *__restrict__ Y,
 		if (oc[mid].wave_off <= wid) lo = mid; else hi = mid;
 	}
 	const OctDesc o = oc[lo];
+#if FL_ABLATE
+	if (!((inv_class_mask >> o.logDL) & 1u)) return;
+#endif
 	const unsigned wl = wid - o.wave_off;
 	const unsigned chunk = wl / o.ngw, gb = wl - chunk * o.ngw;
 	const unsigned n0 = chunk * 64 + (lane & (o.DL - 1));
@@ -127,6 +140,55 @@ __global__ void __launch_bounds__(256) k_inv_poly(const double2 *__restrict__ Y,
 				}
 			}
 		}
+	} else if (INV_UNIFORM && o.DL == 64) {
+	// D >= 64: the 64 lanes of a wave are consecutive output phases of ONE group block, so their coefficient windows are the
+	// same rows -- up to a shift by one row for the lanes behind the point where n - cd crosses a multiple of D.  The rows are
+	// fetched ONCE per wave through the scalar unit (wave-uniform window in SGPRs) and the shifted lanes run one tap step late
+	// (their tap index starts at mu - D; taps outside [0, L) do nothing): per step one vector load (the lane's tap) instead of
+	// three.  Every lane executes the same additions in the same order as in the per-lane form below.
+	const unsigned gu = gb; // 64 / DL = 1 group per wave
+	for (unsigned v = 0; v < o.nv; v++) {
+		const ScaleDesc d = sc[o.s0 + v];
+		const double2 *ws = wd + d.tap_off;
+		const double2 *ys = Y + d.coef_off;
+		const long long t = (long long)n0c - d.cd;
+		const long long a = t >= 0 ? t / D : -((-t + D - 1) / D);
+		const unsigned rho = (unsigned)(t - a * (long long)D);
+		const unsigned mu = rho ? D - rho : 0;
+		const int idx = (int)a + (rho ? 1 : 0);                    // lane 0 has the smallest n0, hence the smallest index
+		const int A = __builtin_amdgcn_readfirstlane(idx);
+		const unsigned shift = n0 < D ? (unsigned)(idx - A) : 0u;  // 0 or 1
+		long long am = ((long long)A + (long long)gu * R) % (long long)Ns;
+		if (am < 0) am += Ns;
+		unsigned row = (unsigned)am;                               // uniform: coefficient index of window slot 0
+		const double gD = d.gain * (double)D;
+		double2 yw[NREC][R];
+#pragma unroll
+		for (int j = 0; j < R - 1; j++) {
+#pragma unroll
+			for (int c = 0; c < NREC; c++) yw[c][j] = ys[(size_t)c * ncoef + row];
+			if (++row == Ns) row = 0;
+		}
+		unsigned l = mu - shift * D;                               // (wraps below zero for the first step of a shifted lane)
+		for (unsigned q = 0; q < d.Q + 1; q += R) {
+#pragma unroll
+			for (int u = 0; u < R; u++) {
+#pragma unroll
+				for (int c = 0; c < NREC; c++) yw[c][(u + R - 1) % R] = ys[(size_t)c * ncoef + row];
+				if (++row == Ns) row = 0;
+				double2 tp = ws[l < d.L ? l : d.L - 1];
+				if (l < d.L) {
+					tp.x *= gD; tp.y *= gD;
+#pragma unroll
+					for (int c = 0; c < NREC; c++)
+#pragma unroll
+						for (int r = 0; r < R; r++)
+							acc[c][r] = fma(tp.x, yw[c][(u + r) % R].x, fma(tp.y, yw[c][(u + r) % R].y, acc[c][r]));
+				}
+				l += D;
+			}
+		}
+	}
 	} else {
 	for (unsigned v = 0; v < o.nv; v++) {
 		const ScaleDesc d = sc[o.s0 + v];

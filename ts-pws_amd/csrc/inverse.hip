@@ -166,6 +166,18 @@ int tspws_build_inverse(tspws_hip_plan *p)
 	return 0;
 }
 
+#if FL_ABLATE
+// debug build only: only the octave classes of k_inv_poly named by the hex mask TSPWS_INV_CLASSES run (results wrong: timing ablation)
+extern "C" int tspws_hip_inv_ablate(void)
+{
+	if (const char *e = getenv("TSPWS_INV_CLASSES")) {
+		const unsigned m = (unsigned)strtoul(e, nullptr, 16);
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(inv_class_mask), &m, sizeof m));
+	}
+	return 0;
+}
+#endif
+
 bool tspws_generic_inverse()
 {
 	static int v = -1;
