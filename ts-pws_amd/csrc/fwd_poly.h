@@ -410,10 +410,9 @@ __global__ void __launch_bounds__(256) k_gather_parts(const double2 *__restrict_
 // One block works on ONE scale (acc2_off[s] = its first block), so the scale lookup and descriptor reads are
 // wave-uniform scalar work.  wa.OUT != nullptr (the call finishes the stacks: every trace of a single batch): the thread
 // that completes a coefficient also writes its weighted value -- no separate pass over the coefficients.
-// Scales without splits: 256 coefficients per block, one thread each.  Split scales (coarse
-// scales: few coefficients, up to 32 partials each): 32 coefficients per block, 8 lanes per coefficient share the
-// partial loads and combine with three shuffles -- otherwise a handful of threads would walk hundreds of dependent-
-// latency loads and set the kernel's duration.
+// Scales without splits: 256 coefficients per block, one thread each.  Split scales (coarse scales: few coefficients,
+// up to 32 partials each): 4 coefficients per block, a wave each -- otherwise a handful of threads would walk hundreds of
+// dependent-latency loads and set the kernel's duration.
 __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restrict__ part, size_t npart, const ScaleDesc *__restrict__ sc,
                                                           unsigned S, unsigned ntr, double2 *__restrict__ ST, double2 *__restrict__ PS,
                                                           int zero_first, int fused, const double2 *__restrict__ fzST,
@@ -473,36 +472,60 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 		}
 		return;
 	}
-	const unsigned sub = wide ? (threadIdx.x & 7) : 0, stride = wide ? 8u : 1u;
-	const unsigned k = (bx - sc[lo].acc2_off) * (wide ? 32u : 256u) + (wide ? threadIdx.x >> 3 : threadIdx.x);
-	const bool live = k < Ns;
-	if (!wide && !live) return;
-	const unsigned kc = live ? k : Ns - 1; // lanes past the end still take part in the shuffles
-	const size_t i = sc[lo].coef_off + kc;
-	const double2 *p0 = part + sc[lo].part_off + kc;
-	double2 st = make_double2(0, 0), ps = make_double2(0, 0);
-	if (!zero_first && sub == 0) { st = ST[i]; ps = PS[i]; }
-	for (unsigned b = 0; b < ntr; b++) {
-		const double2 *p = p0 + (size_t)b * npart;
-		double2 v = make_double2(0.0, 0.0);
-		for (unsigned sp = sub; sp < nsplit; sp += 4 * stride) { // up to four independent loads per lane and round
-			double2 t[4];
+	if (wide) {
+		// few traces, few coefficients, up to 32 partials each (table geometry: 4 coefficients per block): a wave per
+		// coefficient, its lanes are (8 traces) x (8 lanes that share the partials of a trace: up to four independent loads per
+		// lane and round, combined with three shuffles).  The traces of a round are then added in trace order from their
+		// groups' lanes (v_readlane: the sums are wave-uniform) -- ntr / 8 dependent memory round trips instead of ntr, the
+		// additions and their order are those of the one-trace-at-a-time form.
+		const unsigned k = (bx - sc[lo].acc2_off) * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+		if (k >= Ns) return;
+		const unsigned sub = lane & 7, bt = lane >> 3;
+		const size_t i = sc[lo].coef_off + k;
+		const double2 *p0 = part + sc[lo].part_off + k;
+		double2 st = make_double2(0, 0), ps = make_double2(0, 0);
+		if (!zero_first) { st = ST[i]; ps = PS[i]; }
+		for (unsigned b0 = 0; b0 < ntr; b0 += 8) {
+			const bool on = b0 + bt < ntr;
+			const double2 *p = p0 + (size_t)(on ? b0 + bt : 0u) * npart;
+			double2 v = make_double2(0.0, 0.0);
+			for (unsigned sp = sub; sp < nsplit; sp += 32) {
+				double2 t[4];
 #pragma unroll
-			for (int j = 0; j < 4; j++) t[j] = (sp + (unsigned)j * stride < nsplit) ? p[(size_t)(sp + (unsigned)j * stride) * Ns] : make_double2(0.0, 0.0);
+				for (int j = 0; j < 4; j++) t[j] = (on && sp + (unsigned)j * 8u < nsplit) ? p[(size_t)(sp + (unsigned)j * 8u) * Ns] : make_double2(0.0, 0.0);
 #pragma unroll
-			for (int j = 0; j < 4; j++) { v.x += t[j].x; v.y += t[j].y; }
-		}
-		if (wide) {
+				for (int j = 0; j < 4; j++) { v.x += t[j].x; v.y += t[j].y; }
+			}
 #pragma unroll
 			for (int o = 1; o < 8; o <<= 1) { v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); }
+			const unsigned nb = ntr - b0 < 8u ? ntr - b0 : 8u;
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				if ((unsigned)j < nb) {
+					const double2 vj = make_double2(readlane_f64(v.x, 8 * j), readlane_f64(v.y, 8 * j));
+					st.x += vj.x; st.y += vj.y;
+					add_unit_phasor(ps, vj);
+				}
+			}
 		}
-		if (sub == 0) {
-			st.x += v.x; st.y += v.y;
-			add_unit_phasor(ps, v);
+		if (lane == 0) {
+			ST[i] = st; PS[i] = ps;
+			if (wa.OUT) wa.OUT[i] = weight_value(st, ps, wa.mode, wa.K, wa.M, wa.wu);
 		}
+		return;
 	}
-	if (sub == 0 && live) {
-		ST[i] = st; PS[i] = ps;
-		if (wa.OUT) wa.OUT[i] = weight_value(st, ps, wa.mode, wa.K, wa.M, wa.wu);
+	// scales without splits that the forward kernel did not stack itself: one thread per coefficient
+	const unsigned k = (bx - sc[lo].acc2_off) * 256u + threadIdx.x;
+	if (k >= Ns) return;
+	const size_t i = sc[lo].coef_off + k;
+	const double2 *p0 = part + sc[lo].part_off + k;
+	double2 st = make_double2(0, 0), ps = make_double2(0, 0);
+	if (!zero_first) { st = ST[i]; ps = PS[i]; }
+	for (unsigned b = 0; b < ntr; b++) {
+		const double2 v = p0[(size_t)b * npart];
+		st.x += v.x; st.y += v.y;
+		add_unit_phasor(ps, v);
 	}
+	ST[i] = st; PS[i] = ps;
+	if (wa.OUT) wa.OUT[i] = weight_value(st, ps, wa.mode, wa.K, wa.M, wa.wu);
 }

@@ -191,7 +191,7 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 		p->sc[s].acc_off = p->acc_blocks;
 		p->acc_blocks += (p->sc[s].Ns + 255) / 256;
 		p->sc[s].acc2_off = p->acc2_blocks;
-		p->acc2_blocks += p->sc[s].nsplit > 1 ? (p->sc[s].Ns + 31) / 32 : (p->sc[s].Ns + 255) / 256;
+		p->acc2_blocks += p->sc[s].nsplit > 1 ? (p->sc[s].Ns + 3) / 4 : (p->sc[s].Ns + 255) / 256;
 	}
 
 	hipError_t e;

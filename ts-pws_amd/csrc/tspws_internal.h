@@ -67,7 +67,7 @@ struct ScaleDesc {
 	unsigned acc_off;           // first 256-coefficient block of this scale in k_accumulate_masked
 	unsigned use_lds;           // 1: forward transform by k_fwd_lds (fwd_lds.h), 0: k_fwd_poly
 	unsigned lds_off, lds_bps;  // first workgroup of this scale in k_fwd_lds, workgroups per split
-	unsigned acc2_off;          // first block of this scale in k_accumulate_parts (32 coefficients per block when split)
+	unsigned acc2_off;          // first block of this scale in k_accumulate_parts (4 coefficients per block when split)
 	unsigned fuse_ok;           // 1: k_fwd_lds<FUSE> keeps this scale's linear / phase stacks in registers (no partials)
 	unsigned r16;               // 1: the direct kernel gives a thread 16 outputs of this scale (ngw counts 16-output groups)
 	unsigned long long part_off; // offset of this scale's [nsplit][Ns] partial block
@@ -187,6 +187,13 @@ __device__ __forceinline__ double wave_sum(double v) // wave = 64 lanes
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
 	return v;
+}
+
+// a double of lane `src` (compile-time or wave-uniform) as a wave-uniform value
+__device__ __forceinline__ double readlane_f64(const double x, const int src)
+{
+	const int lo = __builtin_amdgcn_readlane(__double2loint(x), src), hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+	return __hiloint2double(hi, lo);
 }
 
 // PS += Y/|Y| unless the quotient is not a unit phasor (Y == 0 gives NaN and is skipped), ts_pws1f_lib.c:491-492.
