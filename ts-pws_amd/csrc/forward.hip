@@ -100,6 +100,12 @@ static long tl_min_env()
 	return e ? std::max(1, atoi(e)) : -1;
 }
 
+#ifndef FWD_LDS_MIN_NG
+#define FWD_LDS_MIN_NG 8 /* output groups (of 8) a scale needs for the LDS-staged kernel */
+#endif
+#ifndef FWD_STEPS_DEF
+#define FWD_STEPS_DEF 96 /* tap steps per wave of the direct kernel */
+#endif
 static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, TlTable &T);
 
 // Work decomposition of the forward kernels.  Scales with >= 8 output groups and (D >= 64 or D a power of two) run on the
@@ -108,7 +114,7 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINN
 int tspws_build_forward(tspws_hip_plan *p)
 {
 	const unsigned S = p->S;
-	const unsigned FWD_STEPS = 96;
+	const unsigned FWD_STEPS = FWD_STEPS_DEF;
 	const unsigned R = 8, FL_SLOTS_HOST = FL_WAVES * FL_PASSES;
 	unsigned woff = 0, boff = 0;
 	unsigned long long poff = 0;
@@ -121,7 +127,7 @@ int tspws_build_forward(tspws_hip_plan *p)
 		d.MC = d.D > 64 ? (d.D + 63) / 64 : 1;
 		const unsigned NG = (d.Ns + R - 1) / R, GW = 64 / d.DL;
 		const bool pow2 = (d.D & (d.D - 1)) == 0;
-		d.use_lds = (NG >= 8 && (d.D >= 64 || pow2)) ? 1u : 0u;
+		d.use_lds = (NG >= FWD_LDS_MIN_NG && (d.D >= 64 || pow2)) ? 1u : 0u;
 		d.ngw = (NG + GW - 1) / GW;
 		// direct kernel, 64 phase lanes, at least 16 outputs: 16 outputs per thread (half the operand bytes per FMA)
 		d.r16 = (!d.use_lds && d.DL == 64 && d.Ns >= 16) ? 1u : 0u;

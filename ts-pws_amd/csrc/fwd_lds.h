@@ -562,8 +562,13 @@ __device__ __forceinline__ void fwd_lds_workgroup(const unsigned bid, const unsi
 
 // grid = (workgroups of all LDS scales, trace slices); a workgroup handles traces [slice*tps, min(ntr, (slice+1)*tps))
 // FUSE: accST / accPS + slice * acc_stride are the [ncoef] planes that receive the slice's stacks of the unsplit scales.
+#ifdef FL_MAXVGPR
+#define FL_VGPR_ATTR __attribute__((amdgpu_num_vgpr(FL_MAXVGPR)))
+#else
+#define FL_VGPR_ATTR
+#endif
 template <typename TIn, bool FUSE>
-__global__ void __launch_bounds__(FL_NT, 2) k_fwd_lds(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
+__global__ void __launch_bounds__(FL_NT, 2) FL_VGPR_ATTR k_fwd_lds(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
                                                  const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
                                                  double2 *__restrict__ part, size_t npart, double2 *__restrict__ accST,
                                                  double2 *__restrict__ accPS, size_t acc_stride, unsigned bid0)
