@@ -103,6 +103,9 @@ static long tl_min_env()
 #ifndef FWD_LDS_MIN_NG
 #define FWD_LDS_MIN_NG 8 /* output groups (of 8) a scale needs for the LDS-staged kernel */
 #endif
+#ifndef TL_MINNS0
+#define TL_MINNS0 33 /* many-trace batches: octaves with at least this many outputs on the trace-lane kernel */
+#endif
 #ifndef FWD_STEPS_DEF
 #define FWD_STEPS_DEF 96 /* tap steps per wave of the direct kernel */
 #endif
@@ -150,7 +153,7 @@ int tspws_build_forward(tspws_hip_plan *p)
 	// and Mexican hat (round 3): batches of >= 12 trace blocks are fastest with the octaves of >= 33 outputs on the trace-lane
 	// kernel, smaller batches (and frames with two voices per octave) with >= 257 -- the trace-lane kernel has tl.wgs x blocks
 	// workgroups, the direct kernel splits the taps
-	if (int rc = build_tl_forward(p, FWD_STEPS, 33, p->tl[0])) return rc;
+	if (int rc = build_tl_forward(p, FWD_STEPS, TL_MINNS0, p->tl[0])) return rc;
 	return build_tl_forward(p, FWD_STEPS, 257, p->tl[1]);
 }
 
@@ -176,7 +179,7 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINN
 			a[v] = (unsigned)d.c / D; b[v] = (unsigned)d.c % D;
 			const long long num = (long long)d.L - 1 - (long long)b[v];
 			const long long fl = num >= 0 ? num / (long long)D : -1;
-			qr[v] = ((unsigned)(fl + 2) + 3) & ~3u;
+			qr[v] = ((unsigned)(fl + 2) + 1) & ~1u; // tap rows of a residue image, even (k_fwd_tl walks them in blocks of 4 and a last block of 2)
 			if (qr[v] > TL_QMAX) ok = false;
 		}
 		if (ok) {
