@@ -179,7 +179,7 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINN
 			a[v] = (unsigned)d.c / D; b[v] = (unsigned)d.c % D;
 			const long long num = (long long)d.L - 1 - (long long)b[v];
 			const long long fl = num >= 0 ? num / (long long)D : -1;
-			qr[v] = ((unsigned)(fl + 2) + 1) & ~1u; // tap rows of a residue image, even (k_fwd_tl walks them in blocks of 4 and a last block of 2)
+			qr[v] = ((unsigned)(fl + 2) + 3) & ~3u; // tap rows of a residue image: k_fwd_tl walks them in blocks of 4
 			if (qr[v] > TL_QMAX) ok = false;
 		}
 		if (ok) {
