@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Extended seeded sweep over the parameter grammar (tests/test_hip_parity.py::_random_case, 360 cases): tspws_main of this
-engine against the oracle -- return codes, resolved parameters, mutated traces, both outputs.  usage: random_sweep.py [first_seed [n_seeds]]"""
+engine against the oracle -- return codes, resolved parameters, mutated traces, both outputs; every third case with the many-trace
+forward path forced (TSPWS_TL_MIN).  usage: random_sweep.py [first_seed [n_seeds]]"""
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, importlib, abi
@@ -15,6 +16,11 @@ for seed in range(_a, _a + _n):
         kw, N, mtr, beg = T._random_case(rng)
         X = abi.synth_traces(mtr, N, seed=100 * seed + it)
         p = abi.default_params(**kw)
+        # every third case through the many-trace forward path whatever its size (the path choice is read at every call)
+        if it % 3 == 2:
+            os.environ["TSPWS_TL_MIN"] = "2"
+        else:
+            os.environ.pop("TSPWS_TL_MIN", None)
         a = abi.run_main(lib.tspws_main, p, X, beg=beg)
         b = abi.run_main(abi.oracle().orc_tspws_main, p, X, beg=beg)
         n += 1
