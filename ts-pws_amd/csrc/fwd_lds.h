@@ -266,11 +266,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 	FL_STAMP(0); // set-up: descriptor, tap staging, first x loads
 	for (unsigned t = 0; t < ntr; t++) {
 		const TIn *xt = x0 + (size_t)t * ld;
-		double ar[PASSES][R], ai[PASSES][R];
-#pragma unroll
-		for (int p = 0; p < PASSES; p++)
-#pragma unroll
-			for (int r = 0; r < R; r++) { ar[p][r] = 0; ai[p][r] = 0; }
+		double ar[PASSES][R], ai[PASSES][R]; // set by the first tap step of the first tile (a product instead of 0 + product)
 
 		for (unsigned qa = 0; qa < d.Q; qa += qt) {
 			const unsigned qn = (d.Q - qa) < qt ? (d.Q - qa) : qt;
@@ -293,23 +289,25 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 			if (!SMALL && (fl_class_mask & 0x200u)) continue;
 #endif
 			if constexpr (WIDE) {
-				constexpr int R2 = 2 * R;
+				constexpr int R2 = 2 * R, RING = R2 + 2 * FL_BATCH;
 				const double *xb = xL + wv * (R2 * 64) + lane; // slots 2 wv, 2 wv + 1: outputs (g0 + 2 wv) R .. + 15
 				const double2 *tb = tL + lane;
-				double xw[R2];
+				// the sliding window is a ring of registers: the operands of the next burst land in the slots they are used from
+				// (no copies); every index below is a compile-time constant after unrolling
+				double xw[RING];
 #pragma unroll
 				for (int j = 0; j < R2 - 1; j++) xw[j] = xb[j * 64];
-				double xn[2][FL_BATCH];
 				double2 tn[2][FL_BATCH];
 #pragma unroll
-				for (int u = 0; u < FL_BATCH; u++) { xn[0][u] = xb[(u + R2 - 1) * 64]; tn[0][u] = tb[u * 64]; }
+				for (int u = 0; u < FL_BATCH; u++) { xw[(u + R2 - 1) % RING] = xb[(u + R2 - 1) * 64]; tn[0][u] = tb[u * 64]; }
+				const bool first_tile = qa == 0;
 #pragma unroll
 				for (int h = 0; h < FL_QT / FL_BATCH; h++) {
 					if ((unsigned)(h * FL_BATCH) < qn) {
 						if (h + 1 < FL_QT / FL_BATCH) {
 #pragma unroll
 							for (int u = 0; u < FL_BATCH; u++) {
-								xn[(h + 1) & 1][u] = xb[((h + 1) * FL_BATCH + u + R2 - 1) * 64]; // (last row read: 16 wv + FL_QT + 14 < XROWS)
+								xw[((h + 1) * FL_BATCH + u + R2 - 1) % RING] = xb[((h + 1) * FL_BATCH + u + R2 - 1) * 64]; // (last row read: 16 wv + FL_QT + 14 < XROWS)
 								tn[(h + 1) & 1][u] = tb[((h + 1) * FL_BATCH + u) * 64];
 							}
 							asm volatile("" ::: "memory"); // the scheduler otherwise sinks these reads to just in front of their FMAs
@@ -317,11 +315,18 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 #pragma unroll
 						for (int u = 0; u < FL_BATCH; u++) {
 							const int sidx = h * FL_BATCH + u; // compile-time after unrolling
-							xw[(sidx + R2 - 1) % R2] = xn[h & 1][u];
+							if (sidx == 0 && first_tile) {
 #pragma unroll
-							for (int r = 0; r < R2; r++) {
-								ar[r / R][r % R] = fma(xw[(sidx + r) % R2], tn[h & 1][u].x, ar[r / R][r % R]);
-								ai[r / R][r % R] = fma(xw[(sidx + r) % R2], tn[h & 1][u].y, ai[r / R][r % R]);
+								for (int r = 0; r < R2; r++) {
+									ar[r / R][r % R] = xw[r % RING] * tn[0][0].x;
+									ai[r / R][r % R] = xw[r % RING] * tn[0][0].y;
+								}
+							} else {
+#pragma unroll
+								for (int r = 0; r < R2; r++) {
+									ar[r / R][r % R] = fma(xw[(sidx + r) % RING], tn[h & 1][u].x, ar[r / R][r % R]);
+									ai[r / R][r % R] = fma(xw[(sidx + r) % RING], tn[h & 1][u].y, ai[r / R][r % R]);
+								}
 							}
 						}
 					}
@@ -342,24 +347,26 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 				}
 				constexpr unsigned XS = SMALL ? DC : 64u;              // row stride in doubles (before padding)
 #define FL_XOFF(j) (SMALL ? (unsigned)(j) * DC + ((unsigned)(j) >> 3) * DC : (unsigned)(j) * 64u)
-				double xw[R];
-#pragma unroll
-				for (int j = 0; j < R - 1; j++) xw[j] = xb[FL_XOFF(j)];
 #if FL_PREFETCH
 				// software pipeline: the operands of burst h+1 are requested before the FMAs of burst h, so a wave's own FMA
 				// stream covers its LDS latency (one wave per SIMD sustains ~85 % of the FP64 rate when its stream is dense:
 				// tools/fma64_issue.hip).  Prefetching past qn reads rows / taps that exist in LDS but are never used.
-				double xn[2][FL_BATCH];
+				// The sliding window is a ring of registers (see the wide form above).
+				constexpr int RING = R + 2 * FL_BATCH;
+				double xw[RING];
+#pragma unroll
+				for (int j = 0; j < R - 1; j++) xw[j] = xb[FL_XOFF(j)];
 				double2 tn[2][FL_BATCH];
 #pragma unroll
-				for (int u = 0; u < FL_BATCH; u++) { xn[0][u] = xb[FL_XOFF(u + R - 1)]; tn[0][u] = tb[u * XS]; }
+				for (int u = 0; u < FL_BATCH; u++) { xw[(u + R - 1) % RING] = xb[FL_XOFF(u + R - 1)]; tn[0][u] = tb[u * XS]; }
+				const bool first_tile = qa == 0;
 #pragma unroll
 				for (int h = 0; h < FL_QT / FL_BATCH; h++) {
 					if ((unsigned)(h * FL_BATCH) < qn) {
 						if (h + 1 < FL_QT / FL_BATCH) {
 #pragma unroll
 							for (int u = 0; u < FL_BATCH; u++) {
-								xn[(h + 1) & 1][u] = xb[FL_XOFF((h + 1) * FL_BATCH + u + R - 1)];
+								xw[((h + 1) * FL_BATCH + u + R - 1) % RING] = xb[FL_XOFF((h + 1) * FL_BATCH + u + R - 1)];
 								tn[(h + 1) & 1][u] = tb[((h + 1) * FL_BATCH + u) * XS];
 							}
 							asm volatile("" ::: "memory"); // the scheduler otherwise sinks these reads to just in front of their FMAs
@@ -367,16 +374,30 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 #pragma unroll
 						for (int u = 0; u < FL_BATCH; u++) {
 							const int sidx = h * FL_BATCH + u; // compile-time after unrolling
-							xw[(sidx + R - 1) % R] = xn[h & 1][u];
+							if (sidx == 0 && first_tile) {
 #pragma unroll
-							for (int r = 0; r < R; r++) {
-								ar[p][r] = fma(xw[(sidx + r) % R], tn[h & 1][u].x, ar[p][r]);
-								ai[p][r] = fma(xw[(sidx + r) % R], tn[h & 1][u].y, ai[p][r]);
+								for (int r = 0; r < R; r++) {
+									ar[p][r] = xw[r % RING] * tn[0][0].x;
+									ai[p][r] = xw[r % RING] * tn[0][0].y;
+								}
+							} else {
+#pragma unroll
+								for (int r = 0; r < R; r++) {
+									ar[p][r] = fma(xw[(sidx + r) % RING], tn[h & 1][u].x, ar[p][r]);
+									ai[p][r] = fma(xw[(sidx + r) % RING], tn[h & 1][u].y, ai[p][r]);
+								}
 							}
 						}
 					}
 				}
 #else
+				double xw[R];
+#pragma unroll
+				for (int j = 0; j < R - 1; j++) xw[j] = xb[FL_XOFF(j)];
+				if (qa == 0) {
+#pragma unroll
+					for (int r = 0; r < R; r++) { ar[p][r] = 0; ai[p][r] = 0; }
+				}
 #pragma unroll
 				for (int h = 0; h < FL_QT / FL_BATCH; h++) { // LDS reads of FL_BATCH steps are issued together, then their FMAs
 					if ((unsigned)(h * FL_BATCH) < qn) {
