@@ -117,6 +117,8 @@ def test_forward_inverse_golden(lib, torch, golden):
     (dict(J=2), 64, 3), (dict(s0=7.890778, J=3), 16501, 1),
     (dict(b0=0.25), 32768, 2),   # 40-67 taps per phase: the LDS kernel's tiled (non-resident) path at D >= 64
     (dict(b0=0.25, type=-3, V=3), 8192, 3), (dict(b0=4.0), 65536, 2),
+    # decimations 3 * 2^j / 5 * 2^j that divide N: 64-phase chunks with idle lanes (D = 96, 80, 160 ...) on the polyphase kernels
+    (dict(b0=3.0), 49152, 2), (dict(b0=5.0, J=7), 81920, 1), (dict(b0=1.5, type=-3), 12288, 3),
 ])
 def test_forward_inverse_vs_oracle(lib, torch, kw, N, ntr):
     p = abi.resolve(abi.default_params(**kw), N)
