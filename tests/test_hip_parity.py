@@ -249,6 +249,7 @@ def test_tspws_main_example_data(lib, golden):
 @pytest.mark.parametrize("kw,mtr,N", [
     (dict(), 24, 4096), (dict(Kmax=10, unbiased=1), 100, 8192), (dict(type=-3, Kmax=3), 30, 4096),
     (dict(w0=2 * np.pi), 12, 32768), (dict(Kmax=10, unbiased=1), 40, 131072), (dict(lrm=1, wu=1.3), 10, 3000),
+    (dict(b0=3.0), 20, 49152), (dict(b0=5.0, J=7, Kmax=4, unbiased=1), 24, 20480),   # decimations 3 * 2^j, 5 * 2^j
 ])
 def test_tspws_main_vs_oracle(lib, kw, mtr, N):
     X = abi.synth_traces(mtr, N, seed=33)
@@ -769,7 +770,7 @@ def test_sharded_jackknife_rows_add_up(lib, torch, kw, bounds):
 @pytest.mark.parametrize("kw,N,mtr", [
     (dict(), 4096, 64), (dict(), 2048, 200), (dict(), 1501, 70), (dict(type=-3), 4096, 100), (dict(w0=2 * np.pi), 8192, 129),
     (dict(s0=3.7, J=6), 3001, 77), (dict(type=-2, wu=1.0), 2048, 90), (dict(unbiased=1), 16501, 96), (dict(uni=1, J=3), 1024, 65),
-    (dict(b0=4.0), 8192, 80),
+    (dict(b0=4.0), 8192, 80), (dict(b0=3.0), 12288, 70),
     (dict(Kmax=80, unbiased=1), 2048, 200),   # two-stage with many groups: the 80 FP64 partial stacks take the many-trace path too
 ])
 def test_many_trace_single_stage_vs_oracle(lib, torch, kw, N, mtr, monkeypatch):
