@@ -168,3 +168,42 @@ def test_tspws_main_over_a_device_list(lib, monkeypatch, devices, comm):
         assert got["rc"] == 0 and abi.relerr(got["conv_tsPWS_sim"], want["conv_tsPWS_sim"]) < 1e-6
     finally:
         lib.tspws_main_release()
+
+
+def test_torch_nccl_backend_reduces_the_plan_buffers(lib, torch):
+    """bench.py --gpus N and stack_sharded() hand views of the library's own device buffers (partial stacks, replica rows) to
+    torch.distributed with backend "nccl" (= RCCL).  One rank is all a 1-GPU box can start, but it still goes through RCCL's
+    registration of the buffer, the async work handle on the collective's stream and the stream hand-over back to the caller."""
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        N, mtr, K = 8192, 120, 6
+        p = tspws.resolve(abi.default_params(Kmax=K, unbiased=1), N)
+        pl = tspws.Plan(p, N)
+        X = tspws.synth(mtr, N, seed=4)
+        ls0, ts0 = pl.stack(X)
+        ls0, ts0 = ls0.clone(), ts0.clone()
+        buf = pl.reduce_buffer(mtr).view(K, N)
+        half = K // 2
+        pl.partial_stacks_range(X, 0, mtr, 0, half)
+        w1 = dist.all_reduce(buf[:half], op=dist.ReduceOp.SUM, async_op=True)
+        pl.partial_stacks_range(X, 0, mtr, half, K)
+        w2 = dist.all_reduce(buf[half:], op=dist.ReduceOp.SUM, async_op=True)
+        w1.wait(); w2.wait()
+        ls = torch.empty(N, dtype=torch.float32, device="cuda")
+        ts = torch.empty(N, dtype=torch.float32, device="cuda")
+        pl.stack_finish(mtr, ls, ts)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(ls.cpu().numpy(), ls0.cpu().numpy())
+        np.testing.assert_array_equal(ts.cpu().numpy(), ts0.cpu().numpy())
+        x2 = torch.zeros(2 * N, dtype=torch.float64, device="cuda")
+        dist.all_reduce(x2, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
