@@ -429,6 +429,10 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 		if (sc[mid].acc2_off <= bx) lo = mid; else hi = mid;
 	}
 	const unsigned Ns = sc[lo].Ns, nsplit = sc[lo].nsplit;
+#ifdef ACC_ABLATE
+	if (ACC_ABLATE == 1 && fused && sc[lo].fuse_ok) return; // timing ablation: no work for the scales the forward kernel stacked
+	if (ACC_ABLATE == 2 && !(fused && sc[lo].fuse_ok)) return; // ... only those
+#endif
 	if (fused && sc[lo].fuse_ok) {
 		// the forward kernel already stacked this scale: fused == 1, straight into ST / PS (nothing left to do);
 		// fused == 2, one plane pair per trace slice, added here in slice order
