@@ -286,10 +286,13 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 		if (!p->side) HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
 		if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, evf));
 		if (!p->ev_join) HIP_TRY(hipEventCreateWithFlags(&p->ev_join, evf));
-		HIP_TRY(hipEventRecord(p->ev_fork, st));
-		HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+		// fork: the side stream waits for the producer of d_x -- its launch carried the event (plan->le.ready) or a record here
+		hipEvent_t ready = p->le.ready;
+		if (!ready) { ready = p->ev_fork; HIP_TRY(hipEventRecord(ready, st)); }
+		HIP_TRY(hipStreamWaitEvent(p->side, ready, 0));
 		sp = p->side;
 	}
+	p->le.ready = nullptr; // (valid for the first transforms after the producer only)
 	// the direct kernel first: its few hundred long, latency-bound workgroups (no LDS, 116 VGPRs) get their slots and the
 	// LDS kernel's workgroups fill in beside them
 	if (has_poly) {

@@ -1,6 +1,7 @@
 // inverse.hip -- phase weighting, inverse frame CWT (real part), epilogue.
 // Reference citations are relative to /root/reference/src.
 #include "tspws_internal.h"
+#include <hip/hip_ext.h>
 
 // ------------------------------------------------------------------------------------------
 // phase weighting (tspws_biased :909-943, tspws_unbiased :965-984)
@@ -214,7 +215,11 @@ static int inverse_launch(tspws_hip_plan *p, const double2 *Y, double *x, hipStr
 		hipLaunchKernelGGL(k_inverse_generic<NREC>, dim3(nbx, nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->S, p->d_wd,
 		                   obuf + (size_t)p->inv_noct * slot, 1, (size_t)NREC * p->ncoef, (size_t)nslots * slot);
 	if (NREC == 2 && nb == 1 && (f_ts || f_ls))
-		hipLaunchKernelGGL(k_inv_combine_out, dim3(nbx), dim3(256), 0, st, obuf, slot, nslots, (size_t)p->N, f_ts, f_ls, f_mtr);
+		if (hipEvent_t e1 = p->le.call_end) { // the call's end event rides on its last launch (tspws_hip_stack)
+			p->le.call_end = nullptr;
+			hipExtLaunchKernelGGL(k_inv_combine_out, dim3(nbx), dim3(256), 0, st, nullptr, e1, 0, (const double *)obuf, slot, nslots, (size_t)p->N, f_ts, f_ls, f_mtr);
+		} else
+			hipLaunchKernelGGL(k_inv_combine_out, dim3(nbx), dim3(256), 0, st, obuf, slot, nslots, (size_t)p->N, f_ts, f_ls, f_mtr);
 	else
 		hipLaunchKernelGGL(k_inv_combine, dim3((unsigned)((slot + 255) / 256), nb), dim3(256), 0, st, obuf, slot, nslots, slot, x,
 		                   (size_t)nslots * slot, slot);

@@ -239,17 +239,36 @@ extern "C" int tspws_hip_profile_end(tspws_hip_plan *pl, double *mean_ms, size_t
 	return 0;
 }
 
+static int hip_rc(hipError_t e, const char *what) { return e == hipSuccess ? 0 : tspws_fail(e == hipErrorOutOfMemory ? TSPWS_E_NOMEM : TSPWS_E_HIP, what, e); }
+
 extern "C" int tspws_hip_stack(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, float *d_ls, float *d_ts,
                                void *s)
 {
 	if (!pl || !p || !d_x || !mtr) return fail(TSPWS_E_ARG, "stack: bad argument");
 	HIP_TRY(hipSetDevice(pl->device));
 	int rc;
+	// Events of the call ride on its launches where they can (plan->le): start of the first and end of the last streaming launch
+	// -- the latter is also what the side stream of the forward transforms waits for --, end of the launch that writes the outputs.
+	// Whatever a path does not consume (single-stage calls, chunked passes, generic kernels) is recorded the ordinary way.
 	const bool prof = pl->prof_used + 3 <= pl->prof_ev.size();
-	if (prof) HIP_TRY(hipEventRecord(pl->prof_ev[pl->prof_used], S_(s)));
-	if ((rc = tspws_hip_stack_local(pl, p, d_x, ld, mtr, 0, mtr, s))) return rc;
-	if (prof) HIP_TRY(hipEventRecord(pl->prof_ev[pl->prof_used + 1], S_(s)));
-	if ((rc = tspws_hip_stack_finish(pl, p, mtr, d_ls, d_ts, s))) return rc;
-	if (prof) { HIP_TRY(hipEventRecord(pl->prof_ev[pl->prof_used + 2], S_(s))); pl->prof_used += 3; }
-	return 0;
+	hipEvent_t *pe = prof ? &pl->prof_ev[pl->prof_used] : nullptr;
+	if (!pl->ev_fork) HIP_TRY(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
+	pl->le = tspws_hip_plan::LaunchEvents();
+	const bool ride = is_two_stage(p, mtr); // the streaming pass of a two-stage call takes both of its events (tspws_run_chunks)
+	if (ride) { pl->le.first_start = prof ? pe[0] : nullptr; pl->le.last_stop = prof ? pe[1] : pl->ev_fork; }
+	else if (prof) HIP_TRY(hipEventRecord(pe[0], S_(s)));
+	rc = tspws_hip_stack_local(pl, p, d_x, ld, mtr, 0, mtr, s);
+	if (!rc) {
+		if (prof && (!ride || pl->le.last_stop)) rc = hip_rc(hipEventRecord(pe[1], S_(s)), "stack: event");
+		if (!rc && prof && pl->le.first_start) rc = hip_rc(hipEventRecord(pe[0], S_(s)), "stack: event"); // (never: both are consumed together)
+		pl->le.first_start = pl->le.last_stop = nullptr;
+		pl->le.call_end = prof ? pe[2] : nullptr;
+	}
+	if (!rc) rc = tspws_hip_stack_finish(pl, p, mtr, d_ls, d_ts, s);
+	if (!rc && prof) {
+		if (pl->le.call_end) rc = hip_rc(hipEventRecord(pe[2], S_(s)), "stack: event");
+		pl->prof_used += 3;
+	}
+	pl->le = tspws_hip_plan::LaunchEvents();
+	return rc;
 }

@@ -1,6 +1,7 @@
 // stream.hip -- trace prologue (fold, mean removal) and stage 1 of the two-stage stack: the HBM-streaming partial-stack pass.
 // Reference citations are relative to /root/reference/src.
 #include "tspws_internal.h"
+#include <hip/hip_ext.h>
 
 // ------------------------------------------------------------------------------------------
 // prologue kernels
@@ -200,7 +201,14 @@ int tspws_run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, c
 			p->last_stream_launches++;
 			const unsigned ny = (unsigned)std::min<size_t>(ck1 - c0, rpl);
 			double *dst = d_P + (size_t)(row_begin + (c0 - ck0)) * ldP;
-			if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, dst, ldP);
+			// the call's events ride on the first / last launch (tspws_hip_stack armed them: plan->le)
+			hipEvent_t e0 = nullptr, e1 = nullptr;
+			if (c0 == ck0) { e0 = p->le.first_start; p->le.first_start = nullptr; }
+			if (c0 + rpl >= ck1) { e1 = p->le.last_stop; p->le.last_stop = nullptr; p->le.ready = e1; }
+			if (e0 || e1) {
+				if (vec) hipExtLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, e0, e1, 0, d_x, ld, N, (const Chunk *)(d_chunks + c0), dst, ldP);
+				else hipExtLaunchKernelGGL(k_partial<false>, dim3(bx, ny), dim3(256), 0, st, e0, e1, 0, d_x, ld, N, (const Chunk *)(d_chunks + c0), dst, ldP);
+			} else if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, dst, ldP);
 			else hipLaunchKernelGGL(k_partial<false>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, dst, ldP);
 		}
 		HIP_TRY(hipGetLastError());
@@ -210,13 +218,22 @@ int tspws_run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, c
 	for (size_t c0 = ck0; c0 < ck1; c0 += 65535) {
 		p->last_stream_launches++;
 		const unsigned ny = (unsigned)std::min<size_t>(ck1 - c0, 65535);
-		if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, (double *)d_pc + c0 * ldpc, ldpc);
+		hipEvent_t e0 = nullptr;
+		if (c0 == ck0) { e0 = p->le.first_start; p->le.first_start = nullptr; }
+		if (e0) {
+			if (vec) hipExtLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, e0, nullptr, 0, d_x, ld, N, (const Chunk *)(d_chunks + c0), (double *)d_pc + c0 * ldpc, ldpc);
+			else hipExtLaunchKernelGGL(k_partial<false>, dim3(bx, ny), dim3(256), 0, st, e0, nullptr, 0, d_x, ld, N, (const Chunk *)(d_chunks + c0), (double *)d_pc + c0 * ldpc, ldpc);
+		} else if (vec) hipLaunchKernelGGL(k_partial<true>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, (double *)d_pc + c0 * ldpc, ldpc);
 		else hipLaunchKernelGGL(k_partial<false>, dim3(bx, ny), dim3(256), 0, st, d_x, ld, N, d_chunks + c0, (double *)d_pc + c0 * ldpc, ldpc);
 	}
 	for (unsigned r0 = row_begin; r0 < row_end; r0 += 65535) {
 		const unsigned ny = std::min(row_end - r0, 65535u);
-		hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((N + 255) / 256), ny), dim3(256), 0, st, (const double *)d_pc, ldpc,
-		                   d_rf + r0, d_P + (size_t)r0 * ldP, ldP, N);
+		hipEvent_t e1 = nullptr;
+		if (r0 + 65535u >= row_end) { e1 = p->le.last_stop; p->le.last_stop = nullptr; p->le.ready = e1; }
+		if (e1) hipExtLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((N + 255) / 256), ny), dim3(256), 0, st, nullptr, e1, 0, (const double *)d_pc, ldpc,
+		                              (const unsigned *)(d_rf + r0), d_P + (size_t)r0 * ldP, ldP, N);
+		else hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((N + 255) / 256), ny), dim3(256), 0, st, (const double *)d_pc, ldpc,
+		                        d_rf + r0, d_P + (size_t)r0 * ldP, ldP, N);
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;

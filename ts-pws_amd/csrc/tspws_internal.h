@@ -146,6 +146,14 @@ struct tspws_hip_plan {
 	hipStream_t side = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	// optional timing inside tspws_hip_stack (bench.py): three events per call -- start, end of the streaming stage, end
+	// Events that ride on kernel launches instead of being recorded as packets of their own (hipExtLaunchKernelGGL: the launch's
+	// start / completion signal IS the event; tools/probes/xstream_probe.hip: the next kernel of the stream follows 2.5 us after
+	// the kernel instead of 4.0).  Armed by tspws_hip_stack for the duration of that ONE call and consumed by the launches they
+	// name (arguments of the call in all but form; every field is NULL between API calls):
+	//   first_start / last_stop: first / last launch of the streaming pass (tspws_run_chunks); last_stop then becomes `ready`,
+	//   ready: the producer of the forward transforms' input has signalled it -- the side stream waits for it instead of a fork record,
+	//   call_end: the launch that writes the float outputs (tspws_inverse_pair_out).
+	struct LaunchEvents { hipEvent_t first_start = nullptr, last_stop = nullptr, ready = nullptr, call_end = nullptr; } le;
 	std::vector<hipEvent_t> prof_ev;
 	size_t prof_used = 0;
 	// cached chunk table: the host copy is keyed on (mtr_local, first, mtr_global, K); the device copy becomes valid only
