@@ -468,7 +468,7 @@ void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb
                              unsigned nslices, hipStream_t st, unsigned nbatch, size_t y_part, size_t y_stack, const TlTable *tl, const WeightArgs *wa,
                              ScaleRange rg)
 {
-	WeightArgs w0; w0.OUT = nullptr; w0.mode = 0; w0.K = w0.M = w0.wu = 0;
+	const WeightArgs w0;
 	const bool on = fz && fz->applied;
 	const bool direct = on && fz->accST == ST; // the single slice went straight into ST / PS
 	// tl: the many-trace decomposition's scale table (partial layout, fused flags, block geometry)

@@ -509,6 +509,10 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 					const double2 vj = make_double2(readlane_f64(v.x, 8 * j), readlane_f64(v.y, 8 * j));
 					st.x += vj.x; st.y += vj.y;
 					add_unit_phasor(ps, vj);
+					if (wa.OUTP && lane == 0) {
+						const unsigned cnt = wa.k0 + b0 + (unsigned)j + 1u;
+						wa.OUTP[(size_t)(b0 + (unsigned)j) * wa.outp_stride + i] = weight_value(st, ps, cnt == 1 ? wa.mode1 : wa.mode, (double)cnt, (double)cnt, wa.wu);
+					}
 				}
 			}
 		}
@@ -529,6 +533,10 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 		const double2 v = p0[(size_t)b * npart];
 		st.x += v.x; st.y += v.y;
 		add_unit_phasor(ps, v);
+		if (wa.OUTP) {
+			const unsigned cnt = wa.k0 + b + 1u;
+			wa.OUTP[(size_t)b * wa.outp_stride + i] = weight_value(st, ps, cnt == 1 ? wa.mode1 : wa.mode, (double)cnt, (double)cnt, wa.wu);
+		}
 	}
 	ST[i] = st; PS[i] = ps;
 	if (wa.OUT) wa.OUT[i] = weight_value(st, ps, wa.mode, wa.K, wa.M, wa.wu);

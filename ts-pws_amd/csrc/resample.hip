@@ -445,8 +445,10 @@ extern "C" int tspws_hip_subsample(tspws_hip_plan *pl, const t_tsPWS *p, const f
 // convergence curves (ts_pws1f_lib.c:247-314, similarity :433-449, misfit :452-462)
 // ------------------------------------------------------------------------------------------
 // out[0] = sum d*r, out[1] = sum d*d, out[2] = sum (d-r)^2, out[3] = sum r*r ; one workgroup, fixed order
+// blockIdx.x = row of d (N apart), its four sums 4 apart in out
 __global__ void __launch_bounds__(1024) k_dot4(const double *__restrict__ d, const float *__restrict__ r, size_t N, double *__restrict__ out)
 {
+	d += (size_t)blockIdx.x * N; out += (size_t)blockIdx.x * 4;
 	__shared__ double red[16][4];
 	double a = 0, b = 0, c = 0, e = 0;
 	for (size_t n = threadIdx.x; n < N; n += 1024) {
@@ -518,22 +520,36 @@ extern "C" int tspws_hip_convergence(tspws_hip_plan *pl, const t_tsPWS *p, const
 	const unsigned nblk = (unsigned)((N + 255) / 256);
 	if ((rc = scratch(pl, SCR_CONV, ((size_t)mtr * 4 + (size_t)nblk * mtr * 3 + mtr * 3) * sizeof(double), &v))) return rc;
 	double *d_ts = (double *)v, *d_lpart = d_ts + mtr * 4, *d_lin = d_lpart + (size_t)nblk * mtr * 3;
-	if ((rc = scratch(pl, SCR_PART, 2 * pl->npart * sizeof(double2), &v))) return rc;
+	// The single-stage steps (tspws_stacks_float_1step, :835-863: Tr <= Kmax or no two-stage at all) add ONE trace to the running
+	// stacks each.  They are taken in batches: the traces of a batch are transformed together (the kernels fill the GPU far better
+	// with 64 traces than with one), k_accumulate_parts adds them one by one in trace order and writes the weighted coefficients
+	// after every trace (prefix outputs), and the batch's inverses, similarity sums and float casts run side by side.
+	const size_t n_single = p->Kmax ? std::min<size_t>(mtr, p->Kmax) : mtr;
+	const size_t budget = tspws_part_budget_bytes();
+	const size_t per_step = (pl->npart + nc) * sizeof(double2) + N * sizeof(double);
+	const size_t FB = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(64, n_single), budget / std::max<size_t>(1, per_step)));
+	if ((rc = scratch(pl, SCR_PART, std::max<size_t>(2, FB) * pl->npart * sizeof(double2), &v))) return rc;
 	double2 *part = (double2 *)v;
+	if ((rc = scratch(pl, SCR_JKOUT, FB * (2 * nc + N) * sizeof(double), &v))) return rc;
+	double *OUTb = (double *)v, *xrb = OUTb + FB * 2 * nc;
 	double *P = nullptr;
 	if (p->Kmax) { if ((rc = scratch(pl, SCR_P, (size_t)p->Kmax * N * sizeof(double), &v))) return rc; P = (double *)v; }
-	for (size_t i = 0; i < mtr; i++) {
+	for (size_t i0 = 0; i0 < n_single; i0 += FB) {
+		const unsigned nb = (unsigned)std::min(FB, n_single - i0);
+		if ((rc = tspws_forward_parts_f32(pl, d_x + i0 * ld, nb, ld, part, st, nullptr, ScaleRange()))) return rc;
+		WeightArgs wa;
+		wa.OUTP = (double2 *)OUTb; wa.outp_stride = nc; wa.k0 = (unsigned)i0; wa.wu = p->wu;
+		wa.mode = tspws_weight_mode(p->wu, p->unbiased, 2); wa.mode1 = tspws_weight_mode(p->wu, p->unbiased, 1);
+		tspws_launch_accumulate(pl, (const double2 *)part, nb, (double2 *)ST, (double2 *)PS, i0 == 0 ? 1 : 0, nullptr, 0, st, 1, 0, 0, nullptr, &wa, ScaleRange());
+		if ((rc = tspws_hip_inverse(pl, OUTb, nb, xrb, s))) return rc;
+		hipLaunchKernelGGL(k_dot4, dim3(nb), dim3(1024), 0, st, (const double *)xrb, d_ref_ts, N, d_ts + i0 * 4);
+		if (d_ts_steps) tspws_epilogue_rows(d_ts_steps + i0 * N, xrb, N, nb, st);
+	}
+	for (size_t i = n_single; i < mtr; i++) { // two-stage over the first Tr traces, recomputed from scratch like the reference (:266-268)
 		const size_t Tr = i + 1;
-		unsigned K;
-		if (!p->Kmax || p->Kmax >= Tr) { // incremental single-stage step (tspws_stacks_float_1step, :835-863)
-			K = (unsigned)Tr;
-			if ((rc = tspws_forward_parts_f32(pl, d_x + i * ld, 1, ld, part, st, nullptr, ScaleRange()))) return rc;
-			tspws_launch_accumulate(pl, (const double2 *)part, 1u, (double2 *)ST, (double2 *)PS, i == 0 ? 1 : 0, nullptr, 0, st, 1, 0, 0, nullptr, nullptr, ScaleRange());
-		} else { // two-stage over the first Tr traces, recomputed from scratch like the reference (:266-268)
-			K = p->Kmax;
-			if ((rc = tspws_hip_partial_stacks(pl, d_x, ld, Tr, 0, Tr, K, P, N, s))) return rc;
-			if ((rc = tspws_hip_stacks_double(pl, P, K, N, ST, PS, s))) return rc;
-		}
+		const unsigned K = p->Kmax;
+		if ((rc = tspws_hip_partial_stacks(pl, d_x, ld, Tr, 0, Tr, K, P, N, s))) return rc;
+		if ((rc = tspws_hip_stacks_double(pl, P, K, N, ST, PS, s))) return rc;
 		if ((rc = tspws_hip_weight(pl, OUT, ST, PS, K, (unsigned)Tr, p->wu, p->unbiased, s))) return rc;
 		if ((rc = tspws_hip_inverse(pl, OUT, 1, xr, s))) return rc;
 		hipLaunchKernelGGL(k_dot4, dim3(1), dim3(1024), 0, st, (const double *)xr, d_ref_ts, N, d_ts + i * 4);

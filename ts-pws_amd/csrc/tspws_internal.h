@@ -97,9 +97,15 @@ struct FuseOut {
 // Phase weighting of one coefficient (tspws_biased :909-943, tspws_unbiased :965-984).
 // mode 0: wu == 2 biased, 1: wu == 1, 2: general power, 3: unbiased (K > 1); K = stacked units, M = traces.
 struct WeightArgs {
-	double2 *OUT;   // nullptr: no weighting
-	int mode;
-	double K, M, wu;
+	double2 *OUT = nullptr;   // nullptr: no weighting
+	int mode = 0;
+	double K = 0, M = 0, wu = 0;
+	// prefix outputs (convergence curves, ts_pws1f_lib.c:247-314): after trace b of the batch the weighted coefficients of the
+	// first k0 + b + 1 traces go to OUTP[b * outp_stride + i] (K = M = that count, mode1 when it is 1); the traces are added one by one
+	double2 *OUTP = nullptr;
+	size_t outp_stride = 0;
+	unsigned k0 = 0;
+	int mode1 = 0;
 };
 
 enum { SCR_Y = 0, SCR_PART, SCR_XT, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_JKTAB, SCR_N };
