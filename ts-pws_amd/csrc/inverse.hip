@@ -40,9 +40,9 @@ int tspws_weight_mode(double wu, int unbiased, unsigned K)
 }
 
 void tspws_weight_batched(tspws_hip_plan *p, double2 *OUT, const double2 *ST, const double2 *PS, int mode, double K, double wu, const double *d_Mv,
-                          unsigned nb, size_t y_out, size_t y_stack, hipStream_t st)
+                          unsigned nb, size_t y_out, size_t y_stack, hipStream_t st, double M)
 {
-	hipLaunchKernelGGL(k_weight, dim3((unsigned)((p->ncoef + 255) / 256), nb), dim3(256), 0, st, OUT, ST, PS, p->ncoef, mode, K, 0.0, wu, d_Mv, y_out, y_stack);
+	hipLaunchKernelGGL(k_weight, dim3((unsigned)((p->ncoef + 255) / 256), nb), dim3(256), 0, st, OUT, ST, PS, p->ncoef, mode, K, M, wu, d_Mv, y_out, y_stack);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -428,14 +428,13 @@ extern "C" int tspws_hip_subsample(tspws_hip_plan *pl, const t_tsPWS *p, const f
 	}
 	const float scale = (float)(1. / (double)K); // fa1 = W[m]/K with W = 1 (:580)
 	hipLaunchKernelGGL(k_sub_linear, dim3((unsigned)((N + 255) / 256), M), dim3(256), 0, st, d_x, ld, N, mtr, d_sel, scale, d_ls_out);
-	if ((rc = scratch(pl, SCR_JKOUT, (2 * nc + N) * sizeof(double), &v))) return rc;
-	double *OUT = (double *)v, *xr = OUT + 2 * nc;
-	for (unsigned m = 0; m < M; m++) {
-		if ((rc = tspws_hip_weight(pl, OUT, (double *)(STm + (size_t)m * nc), (double *)(PSm + (size_t)m * nc), (unsigned)K, (unsigned)K, p->wu,
-		                           p->unbiased, s))) return rc;
-		if ((rc = tspws_hip_inverse(pl, OUT, 1, xr, s))) return rc;
-		if ((rc = tspws_hip_epilogue(nullptr, d_ts_out + (size_t)m * N, nullptr, xr, N, 1, s))) return rc;
-	}
+	// weights, inverses and float casts of the M subsamples side by side (every subsample has K traces)
+	if ((rc = scratch(pl, SCR_JKOUT, (size_t)M * (2 * nc + N) * sizeof(double), &v))) return rc;
+	double *OUT = (double *)v, *xr = OUT + (size_t)M * 2 * nc;
+	tspws_weight_batched(pl, (double2 *)OUT, (const double2 *)STm, (const double2 *)PSm, tspws_weight_mode(p->wu, p->unbiased, (unsigned)K), (double)(unsigned)K,
+	                     p->wu, nullptr, M, nc, nc, st, (double)(unsigned)K);
+	if ((rc = tspws_hip_inverse(pl, OUT, M, xr, s))) return rc;
+	tspws_epilogue_rows(d_ts_out, xr, N, M, st);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st)); // `sel` goes out of scope
 	return 0;

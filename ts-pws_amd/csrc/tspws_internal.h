@@ -277,7 +277,7 @@ int  tspws_build_inverse(tspws_hip_plan *p);
 int  tspws_weight_mode(double wu, int unbiased, unsigned K);
 // OUT[j] = ST[j] * weight(PS[j]) for nb stacks side by side (y_out / y_stack doubles2 apart), trace counts d_Mv[j]
 void tspws_weight_batched(tspws_hip_plan *p, double2 *OUT, const double2 *ST, const double2 *PS, int mode, double K, double wu, const double *d_Mv,
-                          unsigned nb, size_t y_out, size_t y_stack, hipStream_t st);
+                          unsigned nb, size_t y_out, size_t y_stack, hipStream_t st, double M = 0.0); // d_Mv: per-stack trace counts (NULL: M for all)
 // the stack's pair of reconstructions (set 0 = OUT, set 1 = ST of Y) straight to the float outputs
 int  tspws_inverse_pair_out(tspws_hip_plan *p, const double2 *Y, float *d_ts, float *d_ls, float mtr, hipStream_t st);
 int  tspws_inverse_scales(tspws_hip_plan *p, const double2 *Y, double *x2, hipStream_t st, ScaleRange rg);
