@@ -336,8 +336,10 @@ extern "C" int tspws_subsampling_plan(char *sel, size_t J, size_t K)
 	return 0;
 }
 
-// ST_m += Y_b, PS_m += Y_b/|Y_b| for every mask m that contains trace b; one thread per coefficient, the
-// (<= 8) traces of the batch are normalised once and reused for all masks.
+// ST_m += Y_b, PS_m += Y_b/|Y_b| for every mask m that contains trace b; one thread per coefficient.  The running stacks of up
+// to 8 masks (blockIdx.y = group of 8 masks) stay in registers while the thread walks ALL traces of the batch in order: a trace is
+// summed over its splits and normalised once and goes to the masks that select it -- the planes are read and written once per
+// batch, not once per 8 traces.
 __global__ void __launch_bounds__(256) k_accumulate_masked(const double2 *__restrict__ part, size_t npart, const ScaleDesc *__restrict__ sc,
                                                            unsigned S, size_t ncoef, unsigned ntr, const char *__restrict__ sel, size_t mtr,
                                                            size_t t0, unsigned M, double2 *__restrict__ ST, double2 *__restrict__ PS)
@@ -352,27 +354,46 @@ __global__ void __launch_bounds__(256) k_accumulate_masked(const double2 *__rest
 	if (k >= Ns) return;
 	const size_t i = sc[lo].coef_off + k;
 	const double2 *p0 = part + sc[lo].part_off + k;
-	double2 v[8], u[8];
+	const unsigned m0 = blockIdx.y * 8u, nm = (M - m0) < 8u ? (M - m0) : 8u;
+	double2 st[8], ps[8];
+	bool any[8];
 #pragma unroll
-	for (int b = 0; b < 8; b++) {
-		v[b] = make_double2(0, 0); u[b] = make_double2(0, 0);
-		if ((unsigned)b < ntr) {
-			const double2 *p = p0 + (size_t)b * npart;
-			double2 a = p[0];
-			for (unsigned sp = 1; sp < nsplit; sp++) { const double2 t = p[(size_t)sp * Ns]; a.x += t.x; a.y += t.y; }
-			v[b] = a;
-			add_unit_phasor(u[b], a);
+	for (int m = 0; m < 8; m++) {
+		any[m] = false;
+		if ((unsigned)m < nm) { st[m] = ST[(size_t)(m0 + m) * ncoef + i]; ps[m] = PS[(size_t)(m0 + m) * ncoef + i]; }
+		else { st[m] = make_double2(0, 0); ps[m] = make_double2(0, 0); }
+	}
+	for (unsigned b0 = 0; b0 < ntr; b0 += 4) { // four traces at a time: their loads are independent, the additions stay in trace order
+		double2 a[4], u[4];
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			a[j] = make_double2(0, 0);
+			if (b0 + (unsigned)j < ntr) a[j] = p0[(size_t)(b0 + (unsigned)j) * npart];
+		}
+		for (unsigned sp = 1; sp < nsplit; sp++) {
+			double2 t[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++) t[j] = (b0 + (unsigned)j < ntr) ? p0[(size_t)(b0 + (unsigned)j) * npart + (size_t)sp * Ns] : make_double2(0, 0);
+#pragma unroll
+			for (int j = 0; j < 4; j++) { a[j].x += t[j].x; a[j].y += t[j].y; }
+		}
+#pragma unroll
+		for (int j = 0; j < 4; j++) { u[j] = make_double2(0, 0); add_unit_phasor(u[j], a[j]); }
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			if (b0 + (unsigned)j < ntr) {
+#pragma unroll
+				for (int m = 0; m < 8; m++) {
+					if ((unsigned)m < nm && sel[(size_t)(m0 + m) * mtr + t0 + b0 + (unsigned)j] == 1) { // (wave-uniform)
+						st[m].x += a[j].x; st[m].y += a[j].y; ps[m].x += u[j].x; ps[m].y += u[j].y; any[m] = true;
+					}
+				}
+			}
 		}
 	}
-	for (unsigned m = 0; m < M; m++) {
-		const char *row = sel + (size_t)m * mtr + t0;
-		double2 st = ST[(size_t)m * ncoef + i], ps = PS[(size_t)m * ncoef + i];
-		bool any = false;
 #pragma unroll
-		for (int b = 0; b < 8; b++)
-			if ((unsigned)b < ntr && row[b] == 1) { st.x += v[b].x; st.y += v[b].y; ps.x += u[b].x; ps.y += u[b].y; any = true; }
-		if (any) { ST[(size_t)m * ncoef + i] = st; PS[(size_t)m * ncoef + i] = ps; }
-	}
+	for (int m = 0; m < 8; m++)
+		if ((unsigned)m < nm && any[m]) { ST[(size_t)(m0 + m) * ncoef + i] = st[m]; PS[(size_t)(m0 + m) * ncoef + i] = ps[m]; }
 }
 
 // time-domain linear stacks of the subsamples with the reference's FLOAT accumulator, traces in order
@@ -412,19 +433,16 @@ extern "C" int tspws_hip_subsample(tspws_hip_plan *pl, const t_tsPWS *p, const f
 	if ((rc = scratch(pl, SCR_SUBST, (size_t)M * nc * 2 * sizeof(double2), &v))) return rc;
 	double2 *STm = (double2 *)v, *PSm = STm + (size_t)M * nc;
 	HIP_TRY(hipMemsetAsync(STm, 0, (size_t)M * nc * 2 * sizeof(double2), st));
-	// the traces are transformed 64 at a time (the forward kernels fill the GPU far better than with 8) and handed to the masked
-	// accumulation in its batches of 8, in trace order
+	// the traces are transformed 64 at a time (the forward kernels fill the GPU far better than with 8); the masked accumulation walks
+	// a batch in trace order
 	const size_t FB = std::min<size_t>(64, std::max<size_t>(8, (tspws_part_budget_bytes() / (pl->npart * sizeof(double2))) & ~(size_t)7));
 	if ((rc = scratch(pl, SCR_PART, FB * pl->npart * sizeof(double2), &v))) return rc;
 	double2 *part = (double2 *)v;
 	for (size_t t0 = 0; t0 < mtr; t0 += FB) {
 		const size_t nf = std::min(FB, mtr - t0);
 		if ((rc = tspws_forward_parts_f32(pl, d_x + t0 * ld, nf, ld, part, st, nullptr, ScaleRange()))) return rc;
-		for (size_t u0 = 0; u0 < nf; u0 += 8) {
-			const unsigned nb = (unsigned)std::min<size_t>(8, nf - u0);
-			hipLaunchKernelGGL(k_accumulate_masked, dim3(pl->acc_blocks), dim3(256), 0, st, (const double2 *)(part + u0 * pl->npart), pl->npart, pl->d_sc, pl->S,
-			                   nc, nb, d_sel, mtr, t0 + u0, M, STm, PSm);
-		}
+		hipLaunchKernelGGL(k_accumulate_masked, dim3(pl->acc_blocks, (M + 7) / 8), dim3(256), 0, st, (const double2 *)part, pl->npart, pl->d_sc, pl->S,
+		                   nc, (unsigned)nf, d_sel, mtr, t0, M, STm, PSm);
 	}
 	const float scale = (float)(1. / (double)K); // fa1 = W[m]/K with W = 1 (:580)
 	hipLaunchKernelGGL(k_sub_linear, dim3((unsigned)((N + 255) / 256), M), dim3(256), 0, st, d_x, ld, N, mtr, d_sel, scale, d_ls_out);
