@@ -405,8 +405,18 @@ __global__ void __launch_bounds__(256) k_sub_linear(const float *__restrict__ x,
 	if (n >= N) return;
 	const char *row = sel + (size_t)blockIdx.y * mtr;
 	float acc = 0.f;
-	for (size_t i = 0; i < mtr; i++)
-		if (row[i] == 1) acc = (float)((double)acc + (double)x[i * ld + n]);
+	for (size_t i0 = 0; i0 < mtr; i0 += 8) { // eight rows' loads in flight; the additions keep the trace order
+		float v[8];
+		bool on[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			on[j] = i0 + (size_t)j < mtr && row[i0 + (size_t)j] == 1; // (wave-uniform)
+			v[j] = on[j] ? x[(i0 + (size_t)j) * ld + n] : 0.f;
+		}
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+			if (on[j]) acc = (float)((double)acc + (double)v[j]);
+	}
 	out[(size_t)blockIdx.y * N + n] = acc * scale;
 }
 
