@@ -1,6 +1,8 @@
 // resample.hip -- jackknife (two-stage), random subsampling, convergence curves.
 // Reference citations are relative to /root/reference/src.
 #include "tspws_internal.h"
+#include <string>
+#include <unordered_map>
 
 #define is_two_stage tspws_is_two_stage
 
@@ -91,29 +93,42 @@ static int class_sums(tspws_hip_plan *pl, ClassSums &cs, unsigned KM, const floa
 	const size_t N = pl->N;
 	const unsigned W = C + (with_main ? 1u : 0u);
 	// signature of trace i: group index in every replica (0xFFFF = deleted)
+	// (the reference's floor((double)(k * KM) / (double)Kc), :766, is the integer quotient: k * KM < 2^53 and a non-integer
+	// quotient is at least 1 / Kc away from the next integer, far more than a rounding of the division)
 	cs.Kc.assign(C, 0);
-	for (unsigned c = 0; c < C; c++) for (size_t i = 0; i < mtr; i++) if (h_sel[(size_t)c * mtr + i] == 1) cs.Kc[c]++;
+	for (unsigned c = 0; c < C; c++) {
+		const char *row = h_sel + (size_t)c * mtr;
+		size_t n = 0;
+		for (size_t i = 0; i < mtr; i++) n += row[i] == 1;
+		cs.Kc[c] = n;
+	}
 	std::vector<unsigned short> sig((size_t)mtr * W);
 	for (unsigned c = 0; c < C; c++) {
+		const char *row = h_sel + (size_t)c * mtr;
+		const size_t Kc = std::max<size_t>(cs.Kc[c], 1);
 		size_t k = 0;
 		for (size_t i = 0; i < mtr; i++) {
-			if (h_sel[(size_t)c * mtr + i] == 1) {
-				sig[i * W + c] = (unsigned short)floor((double)(k * KM) / (double)cs.Kc[c]); // :766
-				k++;
-			} else sig[i * W + c] = 0xFFFF;
+			if (row[i] == 1) { sig[i * W + c] = (unsigned short)((k * KM) / Kc); k++; }
+			else sig[i * W + c] = 0xFFFF;
 		}
 	}
-	if (with_main) for (size_t i = 0; i < mtr; i++) sig[i * W + C] = (unsigned short)std::min<size_t>((size_t)floor((double)(i * KM) / (double)mtr), KM - 1);
+	if (with_main) for (size_t i = 0; i < mtr; i++) sig[i * W + C] = (unsigned short)std::min<size_t>((i * KM) / mtr, KM - 1);
 	cs.sig.clear(); cs.chunks.clear();
 	std::vector<std::vector<Chunk>> cls_chunks;
+	std::unordered_map<std::string, size_t> cls_of; // signature bytes -> class (classes numbered in order of first appearance)
 	const unsigned clen = tspws_chunk_len_for(N, std::max<size_t>(mtr_local, 1));
 	for (size_t i = lo; i < hi;) {
 		size_t j = i + 1;
 		while (j < hi && !memcmp(&sig[i * W], &sig[j * W], W * sizeof(unsigned short))) j++;
-		std::vector<unsigned short> sg(sig.begin() + i * W, sig.begin() + (i + 1) * W);
-		size_t id = 0;
-		for (; id < cs.sig.size(); id++) if (cs.sig[id] == sg) break;
-		if (id == cs.sig.size()) { cs.sig.push_back(sg); cls_chunks.emplace_back(); }
+		const std::string key((const char *)&sig[i * W], W * sizeof(unsigned short));
+		auto it = cls_of.find(key);
+		size_t id;
+		if (it == cls_of.end()) {
+			id = cs.sig.size();
+			cls_of.emplace(key, id);
+			cs.sig.emplace_back(sig.begin() + i * W, sig.begin() + (i + 1) * W);
+			cls_chunks.emplace_back();
+		} else id = it->second;
 		for (size_t t = i; t < j; t += clen) {
 			Chunk c; c.t0 = t - lo; c.count = (unsigned)std::min<size_t>(clen, j - t); c.row = (unsigned)id; // t0: row of d_x
 			cls_chunks[id].push_back(c);
