@@ -475,8 +475,9 @@ void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb
 	const LaunchRange lr = launch_range(p, rg);
 	const unsigned a0 = tl ? 0u : lr.acc0, a1 = tl ? tl->acc2_blocks : lr.acc1;
 	if (a1 <= a0) return;
-	hipLaunchKernelGGL(k_accumulate_parts, dim3(a1 - a0, nbatch), dim3(256), 0, st, part, tl ? tl->npart : p->npart,
-	                   tl ? tl->d_sc : p->d_sc, p->S, nb, ST, PS, zero_first,
+	auto kern = (wa && wa->OUTP) ? k_accumulate_parts<true> : k_accumulate_parts<false>;
+	hipLaunchKernelGGL(kern, dim3(a1 - a0, nbatch), dim3(256), 0, st, part, tl ? tl->npart : p->npart,
+	                   (const ScaleDesc *)(tl ? tl->d_sc : p->d_sc), p->S, nb, ST, PS, zero_first,
 	                   on ? (direct ? 1 : 2) : 0, on ? (const double2 *)fz->accST : nullptr, on ? (const double2 *)fz->accPS : nullptr,
 	                   on ? fz->stride : (size_t)0, nslices, y_part, y_stack, tl ? 1 : 0, wa ? *wa : w0, a0);
 }

@@ -413,6 +413,9 @@ __global__ void __launch_bounds__(256) k_gather_parts(const double2 *__restrict_
 // Scales without splits: 256 coefficients per block, one thread each.  Split scales (coarse scales: few coefficients,
 // up to 32 partials each): 4 coefficients per block, a wave each -- otherwise a handful of threads would walk hundreds of
 // dependent-latency loads and set the kernel's duration.
+// PREFIX: the convergence curves' instantiation (weighted coefficients after every trace: WeightArgs::OUTP); the stacks' own
+// instantiation carries none of its registers and code.
+template <bool PREFIX>
 __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restrict__ part, size_t npart, const ScaleDesc *__restrict__ sc,
                                                           unsigned S, unsigned ntr, double2 *__restrict__ ST, double2 *__restrict__ PS,
                                                           int zero_first, int fused, const double2 *__restrict__ fzST,
@@ -509,7 +512,7 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 					const double2 vj = make_double2(readlane_f64(v.x, 8 * j), readlane_f64(v.y, 8 * j));
 					st.x += vj.x; st.y += vj.y;
 					add_unit_phasor(ps, vj);
-					if (wa.OUTP && lane == 0) {
+					if (PREFIX && wa.OUTP && lane == 0) {
 						const unsigned cnt = wa.k0 + b0 + (unsigned)j + 1u;
 						wa.OUTP[(size_t)(b0 + (unsigned)j) * wa.outp_stride + i] = weight_value(st, ps, cnt == 1 ? wa.mode1 : wa.mode, (double)cnt, (double)cnt, wa.wu);
 					}
@@ -533,7 +536,7 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 		const double2 v = p0[(size_t)b * npart];
 		st.x += v.x; st.y += v.y;
 		add_unit_phasor(ps, v);
-		if (wa.OUTP) {
+		if (PREFIX && wa.OUTP) {
 			const unsigned cnt = wa.k0 + b + 1u;
 			wa.OUTP[(size_t)b * wa.outp_stride + i] = weight_value(st, ps, cnt == 1 ? wa.mode1 : wa.mode, (double)cnt, (double)cnt, wa.wu);
 		}
