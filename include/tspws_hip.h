@@ -220,6 +220,11 @@ int  tspws_subsampling_plan(char *sel, size_t J, size_t K);
  * Single-stage: tspws_subsmpl_float (:501-610); two-stage: TwoStage_subsmpl_float (:612-709). */
 int  tspws_hip_subsample(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_sigall, size_t ld, size_t mtr, unsigned M,
                          float *d_ls_out, float *d_ts_out, void *stream);
+/* The same with the M masks given (h_sel[M][mtr], 1 = kept: M calls of tspws_subsampling_plan with K = ceil(mtr * subsmpl_p)).
+ * tspws_main draws them BEFORE its first HIP call: the initialisation of the HIP runtime inside a process's first call consumes
+ * libc rand() values, and the masks are to come from the state the caller seeded, as in the reference. */
+int  tspws_hip_subsample_sel(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_sigall, size_t ld, size_t mtr, unsigned M,
+                             const char *h_sel, float *d_ls_out, float *d_ts_out, void *stream);
 
 /* ---- convergence curves ------------------------------------------------------------------------ */
 /* Similarity / misfit of the stack of the first i+1 traces against a reference, for i = 0..mtr-1

@@ -481,6 +481,19 @@ def test_convergence_vs_oracle(lib, kw):
         np.testing.assert_array_equal(a["conv_ts_steps"][-1], a["tsPWS"])
 
 
+def test_seeded_subsampling_in_a_fresh_process():
+    """srand(seed) followed by a process's FIRST tspws_main call: the random subsamples are the reference's (the masks are drawn
+    before the HIP runtime initialises, which consumes rand() values)."""
+    import subprocess
+    import sys as _sys
+    r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fresh_subsample.py")],
+                       capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("FRESH_SUBSAMPLE")]
+    assert line, r.stdout[-2000:] + r.stderr[-2000:]
+    _, rc_a, rc_b, worst = line[0].split()
+    assert rc_a == "0" and rc_b == "0" and float(worst) < TOL32, line[0]
+
+
 @pytest.mark.parametrize("kw", [dict(subsmpl_N=4, subsmpl_p=0.3), dict(subsmpl_N=3, subsmpl_p=0.7, Kmax=5, unbiased=1),
                                 dict(subsmpl_N=2, subsmpl_p=1.0, type=-3)])
 def test_random_subsampling_vs_oracle(lib, kw):

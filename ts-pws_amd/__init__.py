@@ -116,6 +116,7 @@ SYMBOLS = {
     "tspws_hip_jackknife_finish": (_i, [_vp, _vp, _sz, _vp, _u, _u, _u, _vp, _vp, _vp, _vp]),
     "tspws_subsampling_plan": (_i, [_vp, _sz, _sz]),
     "tspws_hip_subsample": (_i, [_vp, _vp, _vp, _sz, _sz, _u, _vp, _vp, _vp]),
+    "tspws_hip_subsample_sel": (_i, [_vp, _vp, _vp, _sz, _sz, _u, _vp, _vp, _vp, _vp]),
     "tspws_hip_convergence": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tspws_hip_synth": (_i, [_vp, _sz, _sz, _sz, C.c_uint64, _sz, _vp]),
     # several devices of one process (csrc/comm.hip)

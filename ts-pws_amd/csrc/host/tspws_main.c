@@ -230,8 +230,22 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 		printf("Engine: MI355X HIP path, device %d\n\n", dev);
 	}
 
+	/* Random subsampling (:324-333): the masks are drawn NOW, before the first HIP call of the process -- the initialisation of the
+	 * HIP runtime consumes libc rand() values, and the masks must come from the state the caller seeded (srand), as the reference's
+	 * do.  Nothing else on this path calls rand(), so the order of the draws is the reference's (SubsamplingPlan, :355-383). */
+	char *sub_sel = NULL;
+	const int want_sub = tspws->subsmpl_N > 0 && tspws->subsmpl_p > 0 && out->ls_subsmpl && out->tsPWS_subsmpl && mtr > 0 && tspws->J && tspws->V;
+	if (want_sub) {
+		const unsigned M = tspws->subsmpl_N;
+		const size_t K = (size_t)ceil((double)mtr * tspws->subsmpl_p);
+		sub_sel = (char *)malloc((size_t)M * mtr);
+		if (!sub_sel) return 4;
+		for (unsigned m = 0; m < M; m++) tspws_subsampling_plan(sub_sel + (size_t)m * mtr, mtr, K);
+	}
+
 	if (tspws_hip_device_count() <= dev) {
 		printf("tspws_main: no usable HIP device (%s)\n", tspws_hip_last_error());
+		free(sub_sel);
 		return TSPWS_E_NODEV;
 	}
 
@@ -250,17 +264,17 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 		const int needs_one = (tspws->convergence && out->ls_sim && out->tsPWS_sim && out->ls_misfit && out->tsPWS_misfit) ||
 		                      (tspws->subsmpl_N > 0 && tspws->subsmpl_p > 0 && out->ls_subsmpl && out->tsPWS_subsmpl);
 		if ((ndev > 1 || (ndev == 1 && getenv("TSPWS_COMM"))) && !needs_one && tspws->J && tspws->V)
-			return main_multi(tspws, out, in, mtr, do_fold, devs, ndev);
+			{ free(sub_sel); return main_multi(tspws, out, in, mtr, do_fold, devs, ndev); }
 	}
 
 	int frame_rc = get_plan(&plan, tspws, nsamp, dev);
 	if (frame_rc) {
 		printf("tspws_main: cannot build the wavelet frame (%s)\n", tspws_hip_last_error());
-		if (frame_rc == TSPWS_E_NODEV) return frame_rc;
+		if (frame_rc == TSPWS_E_NODEV) { free(sub_sel); return frame_rc; }
 		/* A frame that cannot be built (e.g. J resolved to 0: fmin above the first scale) surfaces as 4 in the reference,
 		 * when the coefficient containers are created (:199-204) -- i.e. AFTER fold and mean removal have rewritten
 		 * sigall (:71-88, :159-169): the prologue below still runs, then the call returns 4. */
-		if (!do_fold && !tspws->lrm) return TSPWS_E_NOMEM;
+		if (!do_fold && !tspws->lrm) { free(sub_sel); return TSPWS_E_NOMEM; }
 	}
 
 	TRY(get_trace_buffer(&d_sig, mtr * ld * sizeof(float), dev));
@@ -315,7 +329,8 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 		const unsigned M = tspws->subsmpl_N;
 		float *d_sub = NULL;
 		rc = tspws_hip_alloc((void **)&d_sub, 2 * (size_t)M * ld * sizeof(float), dev);
-		if (!rc) rc = tspws_hip_subsample(plan, tspws, d_sig, ld, mtr, M, d_sub, d_sub + (size_t)M * ld, NULL);
+		if (!rc) rc = sub_sel ? tspws_hip_subsample_sel(plan, tspws, d_sig, ld, mtr, M, sub_sel, d_sub, d_sub + (size_t)M * ld, NULL)
+		                      : tspws_hip_subsample(plan, tspws, d_sig, ld, mtr, M, d_sub, d_sub + (size_t)M * ld, NULL);
 		if (!rc) { stage = (float *)malloc(2 * (size_t)M * ld * sizeof(float)); if (!stage) rc = TSPWS_E_NOMEM; }
 		if (!rc) rc = tspws_hip_download(stage, d_sub, 2 * (size_t)M * ld * sizeof(float), NULL);
 		tspws_hip_free(d_sub);
@@ -347,6 +362,7 @@ int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 done:
 	if (rc) printf("tspws_main: HIP path failed (%d: %s)\n", rc, tspws_hip_last_error());
 done_quiet:
+	free(sub_sel);
 	free(stage);
 	free(jk_mtr);
 	free(sel);
