@@ -481,6 +481,31 @@ def test_convergence_vs_oracle(lib, kw):
         np.testing.assert_array_equal(a["conv_ts_steps"][-1], a["tsPWS"])
 
 
+def test_concurrent_callers_of_the_drop_in(lib):
+    """Two host threads call tspws_main at the same time with different ensembles and frames (the reference has no shared state;
+    this engine keeps a cached frame and trace buffer, so the calls are serialised inside): both get their own results."""
+    import threading
+    cases = [(dict(), abi.synth_traces(20, 4096, seed=41)), (dict(type=-3, Kmax=4, unbiased=1), abi.synth_traces(33, 3001, seed=42)),
+             (dict(w0=2 * np.pi), abi.synth_traces(12, 8192, seed=43))]
+    want = [abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), X) for kw, X in cases]
+    got = [[None] * 4 for _ in cases]
+
+    def work(i):
+        for r in range(4):
+            got[i][r] = abi.run_main(lib.tspws_main, abi.default_params(**cases[i][0]), cases[i][1])
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i, w in enumerate(want):
+        for r in range(4):
+            a = got[i][r]
+            assert a is not None and a["rc"] == 0
+            assert abi.relerr(a["ls"], w["ls"]) < TOL32 and abi.relerr(a["tsPWS"], w["tsPWS"]) < TOL32, (i, r)
+
+
 def test_seeded_subsampling_in_a_fresh_process():
     """srand(seed) followed by a process's FIRST tspws_main call: the random subsamples are the reference's (the masks are drawn
     before the HIP runtime initialises, which consumes rand() values)."""

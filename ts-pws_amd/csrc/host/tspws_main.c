@@ -26,6 +26,7 @@
  * tspws_main_release() frees them; TSPWS_PLAN_CACHE=0 disables the cache.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -62,12 +63,23 @@ static int cache_enabled(void)
 	return !(e && *e == '0');
 }
 
-void tspws_main_release(void)
+/* One call at a time: the cached frame, its scratch buffers and the device trace buffer belong to the call that holds the lock
+ * (the reference's tspws_main has no shared state; concurrent callers of this one are serialised -- the GPU is the shared resource). */
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static void release_locked(void)
 {
 	tspws_hip_plan_destroy(g_cache.plan);
 	tspws_hip_free(g_cache.d_sig);
 	tspws_hip_multi_destroy(g_cache.multi);
 	memset(&g_cache, 0, sizeof g_cache);
+}
+
+void tspws_main_release(void)
+{
+	pthread_mutex_lock(&g_lock);
+	release_locked();
+	pthread_mutex_unlock(&g_lock);
 }
 
 /* TSPWS_DEVICES: "all" or a comma-separated list of HIP device ids; returns the number of entries (0: not set) */
@@ -152,7 +164,7 @@ done:
 	if (rc) printf("tspws_main: HIP path failed (%d: %s)\n", rc, tspws_hip_last_error());
 	free(sel);
 	free(jk);
-	if (!cache_enabled()) tspws_main_release();
+	if (!cache_enabled()) release_locked();
 	return rc;
 }
 
@@ -187,9 +199,19 @@ static int get_trace_buffer(float **d_sig, size_t bytes, int dev)
 	return 0;
 }
 
+static int main_locked(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in);
+
 int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 {
 	if (tspws == NULL || out == NULL || in == NULL) { printf("tspws_main: NULL input\n"); return -1; }
+	pthread_mutex_lock(&g_lock);
+	const int rc = main_locked(tspws, out, in);
+	pthread_mutex_unlock(&g_lock);
+	return rc;
+}
+
+static int main_locked(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
+{
 
 	const int    max   = in->hdr.max;
 	size_t mtr = tspws->Nmax ? tspws->Nmax : in->hdr.mtr;
@@ -371,6 +393,6 @@ done_quiet:
 	tspws_hip_free(d_ref);
 	tspws_hip_free(d_jk);
 	tspws_hip_free(d_out);
-	if (!cache_enabled()) tspws_main_release(); /* else: the frame and the trace buffer serve the next call */
+	if (!cache_enabled()) release_locked(); /* else: the frame and the trace buffer serve the next call */
 	return rc;
 }
