@@ -240,7 +240,8 @@ int  tspws_hip_convergence(tspws_hip_plan *plan, const t_tsPWS *p, const float *
  * single-stage: of ST || PS (:486-494).  The devices' buffers are added by ONE RCCL all-reduce (fp64, sum) over xGMI.
  * RCCL is bound at run time (librccl.so.1), so single-device users never load it.
  *   TSPWS_COMM=local  own reduction kernel instead of RCCL; also chosen when the device list names a device twice (RCCL
- *                     refuses that) -- lets the N-way bookkeeping run on a one-GPU box; not a fallback
+ *                     refuses that) -- lets the N-way bookkeeping run on a one-GPU box; not a fallback: a list with
+ *                     DISTINCT devices is refused under it (several physical devices always reduce through RCCL)
  *   TSPWS_COMM=rccl   go through RCCL even for a single device */
 typedef struct tspws_hip_comm tspws_hip_comm;
 /* communicator over `ndev` devices of this process; devices == NULL: 0 .. ndev-1 */
@@ -280,10 +281,17 @@ int   tspws_hip_multi_stack_jackknife(tspws_hip_multi *m, const t_tsPWS *p, cons
                                       float *d_ls, float *d_tsPWS, const char *h_sel, unsigned C,
                                       float *h_ls_out, float *h_ts_out, unsigned *h_mtr_out);
 
-/* ---- the drop-in's cache ---------------------------------------------------------------------------
- * tspws_main keeps the frame and the device trace buffer of its last call for the next one (same parameters: nothing to
- * rebuild).  This frees them; TSPWS_PLAN_CACHE=0 in the environment disables the cache altogether. */
+/* ---- the drop-in on a named device, and its cache -----------------------------------------------------
+ * tspws_main (ts_pws1f_lib.h; reference: ts_pws1f_lib.h:104) runs on the device TSPWS_DEVICE names (default 0; a one-entry
+ * TSPWS_DEVICES means the same).  tspws_main_on is the same call on an explicit device -- no environment variable is
+ * consulted -- for hosts that run one stacking thread per GPU (several station pairs at once): calls on different devices
+ * run concurrently, calls on the same device are serialised (per-device lock).
+ * Each device keeps the frame and the device trace buffer of its last call for the next one (same parameters: nothing to
+ * rebuild; the memory stays allocated between calls).  tspws_main_release frees all of them; TSPWS_PLAN_CACHE=0 in the
+ * environment disables the cache altogether.  tspws_main_cached_devices: bit i set = device i holds a cached frame. */
+int  tspws_main_on(int device, t_tsPWS *tspws, t_tsPWS_out *out, t_data *in);
 void tspws_main_release(void);
+unsigned long long tspws_main_cached_devices(void);
 
 /* ---- synthetic ensembles for bench / tests ------------------------------------ */
 /* trace i = first+local, sample n: 0.2 sin(2pi(n-N/2)/200) exp(-((n-N/2)/(0.05N))^2/2) + U(-.5,.5) */

@@ -24,6 +24,10 @@ sel = np.zeros((Cn, mtr), np.int8)
 assert lib.tspws_jackknife_plan(sel.ctypes.data, times.ctypes.data, mtr, 1, 10, Cn) == 0
 
 
+if os.environ.get("TSPWS_FWD_CLASSES"):  # -DFL_ABLATE=1 builds: switch classes of k_fwd_lds off (results wrong, only the clock counts)
+    lib.tspws_hip_fwd_ablate()
+
+
 def jk():
     # the stack and its ten replicas from ONE pass over the traces
     pl.stack_jackknife(X, sel)

@@ -109,6 +109,8 @@ SYMBOLS = {
     "tspws_hip_jackknife": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _u, _vp, _vp, _vp, _vp]),
     "tspws_hip_stack_jackknife": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp]),
     "tspws_main_release": (None, []),
+    "tspws_main_on": (_i, [_i, _vp, _vp, _vp]),
+    "tspws_main_cached_devices": (C.c_ulonglong, []),
     "tspws_hip_finish_shard": (_i, [_vp, _vp, _sz, _u, _u, C.POINTER(_u), C.POINTER(_u)]),
     "tspws_hip_stack_finish_scales": (_i, [_vp, _vp, _sz, _u, _u, _vp, _vp]),
     "tspws_hip_jackknife_buffer": (_i, [_vp, _vp, _u, C.POINTER(_vp), C.POINTER(_sz)]),
@@ -397,7 +399,10 @@ class Plan:
             pass
 
 
-def stack_sharded(plan, traces, first=0, mtr_global=None, group=None):
+SCHEDULES = ("single", "split", "sharded-finish")
+
+
+def stack_sharded(plan, traces, first=0, mtr_global=None, group=None, schedule=None):
     """One tspws_main-equivalent call over a trace-sharded ensemble.
 
     Every rank holds a contiguous shard `traces` whose first row is global trace `first` of
@@ -406,16 +411,28 @@ def stack_sharded(plan, traces, first=0, mtr_global=None, group=None):
     (RCCL over xGMI on GPUs, backend "nccl") adds the shards; every rank then finishes (K forward
     CWTs, weight, two inverses) redundantly -- that part is tiny.  With world_size 1 (or no process
     group) there is no collective at all.  `plan` only needs stack_local / reduce_buffer /
-    stack_finish / N, so the CPU tests drive the same orchestration with an oracle-backed plan."""
+    stack_finish / N, so the CPU tests drive the same orchestration with an oracle-backed plan.
+
+    `schedule` (N > 1, two-stage; default: $TSPWS_SCHEDULE or "sharded-finish") -- three ways to place the one logical
+    reduction of P[Kmax][N], selectable so that a multi-GPU node can A/B them (bench.py --schedule):
+      "single"          north_star's wording: local half, ONE all-reduce of the whole buffer, redundant finish on every rank
+                        (bit-identical to the one-GPU result when the shards add exactly);
+      "split"           the groups in two pieces K/2 | K/2: the first reduction runs while the second piece is streamed, the
+                        second while the first half of the groups is transformed (redundant finish in pieces);
+      "sharded-finish"  pieces K-2 | 2, then every rank finishes only its share of the scales and a 2 N-double all-reduce adds
+                        the partial reconstructions (falls back to "split" when the plan has no sharded finish)."""
     import torch
     import torch.distributed as dist
     mtr_global = traces.shape[0] if mtr_global is None else mtr_global
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     K = getattr(getattr(plan, "params", None), "Kmax", 0)
-    if distributed and callable(getattr(plan, "partial_stacks_range", None)) and K >= 2 and K <= mtr_global:
+    schedule = schedule or os.environ.get("TSPWS_SCHEDULE") or "sharded-finish"
+    if schedule not in SCHEDULES:
+        raise TspwsError(f"schedule must be one of {SCHEDULES}, got {schedule!r}")
+    if distributed and schedule != "single" and callable(getattr(plan, "partial_stacks_range", None)) and K >= 2 and K <= mtr_global:
         # two-stage: the sum is row-separable, so the all-reduce of the first half of the groups runs (on the collective's
         # own stream) while the second half is still being streamed -- still one logical reduction of P[Kmax][N]
-        shard = _finish_shard(plan, mtr_global, group)
+        shard = _finish_shard(plan, mtr_global, group) if schedule == "sharded-finish" else None
         half = split_groups(K, shard is not None)
         buf = plan.reduce_buffer(mtr_global).view(K, plan.N)
         plan.partial_stacks_range(traces, first, mtr_global, 0, half)
@@ -522,24 +539,28 @@ def _finish_shard(plan, mtr_global, group=None):
     world = dist.get_world_size(group)
     if world < 2:
         return None
-    cache = getattr(plan, "_shard_agreed", None)  # agreed once per (ensemble size, group): no collective in later calls
-    key = (mtr_global, world, dist.get_rank(group), id(group))
-    if cache is not None and key in cache:
-        return cache[key]
+    # agreed once per (group, ensemble size, frame): no collective in later calls.  The cache is module-level and keyed by the
+    # frame's parameters, not by the plan object: a rank that rebuilds its plan hits the same entry as the ranks that kept
+    # theirs, so the ranks cannot diverge into different collective sequences.
+    pr = getattr(plan, "params", None)
+    frame = (pr.type, pr.J, pr.V, pr.s0, pr.b0, pr.w0, int(pr.uni), pr.Kmax) if pr is not None else (id(plan),)
+    key = (id(group), world, dist.get_rank(group), mtr_global, getattr(plan, "N", 0), frame, os.environ.get("TSPWS_SHARD_FINISH", "1"))
+    if key in _SHARD_AGREED:
+        return _SHARD_AGREED[key]
     mine = None
     if os.environ.get("TSPWS_SHARD_FINISH", "1") != "0" and callable(getattr(plan, "finish_shard", None)):
         mine = plan.finish_shard(mtr_global, dist.get_rank(group), world)
-    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    # the flag lives on the PLAN's device (not torch's current device: a caller that never ran torch.cuda.set_device would put
+    # every rank's tensor on cuda:0 and RCCL would hang)
+    dev = f"cuda:{getattr(plan, 'device', 0)}" if dist.get_backend(group) == "nccl" else "cpu"
     flag = torch.tensor([1 if mine is not None else 0], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     agreed = mine if int(flag.item()) == 1 else None
-    try:
-        if cache is None:
-            cache = plan._shard_agreed = {}
-        cache[key] = agreed
-    except AttributeError:
-        pass
+    _SHARD_AGREED[key] = agreed
     return agreed
+
+
+_SHARD_AGREED = {}
 
 
 def split_groups(K, sharded_finish=False):

@@ -12,9 +12,10 @@
 // RCCL is bound at run time (dlopen of librccl.so.1, prototypes from <rccl/rccl.h>): a single-GPU user never loads the
 // half-gigabyte library, and inside a Python process that already carries torch's copy the loader hands back that one.
 //
-// "local" backend (TSPWS_COMM=local, or a device list that names a device twice -- RCCL refuses duplicates): the devices of
-// the list may be the SAME device; the all-reduce is then this file's own kernel (rank order, deterministic).  It exists so
-// that the N-way bookkeeping of the sharded call can be exercised on a one-GPU box; it is not a fallback.
+// "local" backend (TSPWS_COMM=local, or a device list that names a device twice -- RCCL refuses duplicates): every entry of
+// the list must be the SAME device; the all-reduce is then this file's own kernel (rank order, deterministic).  It exists so
+// that the N-way bookkeeping of the sharded call can be exercised on a one-GPU box; it is not a fallback, and a list with
+// distinct devices is refused under it (comm_create): several physical devices always reduce through RCCL.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -70,8 +71,7 @@ struct tspws_hip_comm {
 	double **d_ptrs = nullptr;          // local backend: device copy of the buffer pointers
 };
 
-// buf[0][i] = buf[0][i] + buf[1][i] + ... in list order, then copied to the others (local backend; all buffers reachable
-// from the launching device: the same device, or peers)
+// buf[0][i] = buf[0][i] + buf[1][i] + ... in list order, then copied to the others (local backend: all buffers on the one device)
 __global__ void __launch_bounds__(256) k_local_allreduce(double *const *__restrict__ bufs, int n, size_t count)
 {
 	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -99,6 +99,14 @@ extern "C" int tspws_hip_comm_create(tspws_hip_comm **out, int ndev, const int *
 	const char *e = getenv("TSPWS_COMM");
 	c->local = dup || (e && !strcmp(e, "local"));
 	if (e && !strcmp(e, "rccl") && dup) { delete c; return fail(TSPWS_E_ARG, "comm_create: RCCL cannot take a device twice"); }
+	// the local backend is a test vehicle for ONE physical device named several times: with distinct devices in the list the
+	// sum has to go through RCCL / xGMI -- never through this file's own kernel and peer mappings
+	bool distinct = false;
+	for (int i = 1; i < ndev; i++) distinct |= c->dev[i] != c->dev[0];
+	if (c->local && distinct) {
+		delete c;
+		return fail(TSPWS_E_ARG, "comm_create: the local backend (TSPWS_COMM=local / a repeated device) takes one physical device only; distinct devices reduce through RCCL");
+	}
 	for (int i = 0; i < ndev; i++) {
 		hipStream_t s = nullptr;
 		hipEvent_t ev = nullptr;
@@ -113,8 +121,6 @@ extern "C" int tspws_hip_comm_create(tspws_hip_comm **out, int ndev, const int *
 			tspws_hip_comm_destroy(c);
 			return fail(TSPWS_E_HIP, "comm_create: local backend");
 		}
-		for (int i = 1; i < ndev; i++) // distinct devices under the local backend: peers must be mapped
-			if (c->dev[i] != c->dev[0]) { (void)hipDeviceEnablePeerAccess(c->dev[i], 0); (void)hipGetLastError(); }
 	} else {
 		int rc = rccl_load();
 		if (rc) { tspws_hip_comm_destroy(c); return rc; }

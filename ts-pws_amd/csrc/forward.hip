@@ -149,6 +149,13 @@ int tspws_build_forward(tspws_hip_plan *p)
 		p->n_fusable += d.fuse_ok;
 	}
 	p->fwd_waves = woff; p->lds_blocks = boff; p->npart = poff;
+	// Tap rows resident in LDS (fwd_lds.h: QT).  A scale with Q <= QT taps per phase keeps its taps in LDS for the whole trace
+	// slice and prefetches the next trace's window while it computes; one with more re-stages taps and window per tile and
+	// trace.  The default Morlet frames have Q <= 18; the Mexican hat's second voice of every octave has Q = 29 or 30: frames
+	// with such scales (24 < Q <= 32) take the QT = 32 instantiation (80 KB of LDS, still two workgroups per CU).
+	p->lds_qt = 24;
+	for (unsigned s = 0; s < S; s++) if (p->sc[s].use_lds && p->sc[s].Q > 24 && p->sc[s].Q <= 32) p->lds_qt = 32;
+	if (const char *e = getenv("TSPWS_FWD_QT")) { const int v = atoi(e); if (v == 24 || v == 32) p->lds_qt = (unsigned)v; } // (sweeps)
 	// two many-trace decompositions (see stacks_tl for the choice): sweeps on 128 .. 2048 traces x 8192 .. 32768 samples, Morlet
 	// and Mexican hat (round 3): batches of >= 12 trace blocks are fastest with the octaves of >= 33 outputs on the trace-lane
 	// kernel, smaller batches (and frames with two voices per octave) with >= 257 -- the trace-lane kernel has tl.wgs x blocks
@@ -317,13 +324,14 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 		const size_t per_launch = (size_t)tps * 65535;
 		for (size_t t0 = 0; t0 < ntr; t0 += per_launch) {
 			const unsigned nt = (unsigned)std::min<size_t>(ntr - t0, per_launch);
-			if (fuse)
-				hipLaunchKernelGGL((k_fwd_lds<TIn, true>), dim3(lr.lds1 - lr.lds0, (nt + tps - 1) / tps), dim3(FL_NT), FL_LDS_BYTES, st, d_x + t0 * ld, ld,
-				                   nt, tps, p->N, p->d_sc, p->S, p->d_w, d_part + t0 * p->npart, p->npart, fz->accST + (t0 / tps) * fz->stride,
-				                   fz->accPS + (t0 / tps) * fz->stride, fz->stride, lr.lds0);
-			else
-				hipLaunchKernelGGL((k_fwd_lds<TIn, false>), dim3(lr.lds1 - lr.lds0, (nt + tps - 1) / tps), dim3(FL_NT), FL_LDS_BYTES, st, d_x + t0 * ld, ld,
-				                   nt, tps, p->N, p->d_sc, p->S, p->d_w, d_part + t0 * p->npart, p->npart, (double2 *)nullptr, (double2 *)nullptr, (size_t)0, lr.lds0);
+			const dim3 grid(lr.lds1 - lr.lds0, (nt + tps - 1) / tps);
+			double2 *aS = fuse ? fz->accST + (t0 / tps) * fz->stride : nullptr, *aP = fuse ? fz->accPS + (t0 / tps) * fz->stride : nullptr;
+			const size_t astr = fuse ? fz->stride : 0;
+#define FL_LAUNCH(F, QT) hipLaunchKernelGGL((k_fwd_lds<TIn, F, QT>), grid, dim3(FL_NT), FL_LDS_BYTES_(QT), st, d_x + t0 * ld, ld, nt, tps, p->N, p->d_sc, p->S, \
+			                            p->d_w, d_part + t0 * p->npart, p->npart, aS, aP, astr, lr.lds0)
+			if (p->lds_qt == 32) { if (fuse) FL_LAUNCH(true, 32); else FL_LAUNCH(false, 32); }
+			else { if (fuse) FL_LAUNCH(true, 24); else FL_LAUNCH(false, 24); }
+#undef FL_LAUNCH
 		}
 		if (fuse) fz->applied = true;
 	}

@@ -46,9 +46,6 @@
 #pragma once
 
 #define FL_R 8
-#ifndef FL_QT
-#define FL_QT 24
-#endif
 #ifndef FL_WAVES
 #define FL_WAVES 4                              /* waves per workgroup */
 #endif
@@ -69,22 +66,20 @@
 #endif
 #define FL_NT (64 * FL_WAVES)                   /* threads per workgroup */
 #define FL_SLOTS (FL_WAVES * FL_PASSES)
-#if FL_QT % FL_R != 0
-#error FL_QT must be a multiple of FL_R
-#endif
-#define FL_TAPS_BYTES (FL_QT * 64 * 16)         /* 24 KiB */
-#define FL_TPW (FL_QT / FL_WAVES)               /* tap rows staged per wave (D >= 64) */
-#define FL_TSMALL ((FL_QT * 32 + FL_NT - 1) / FL_NT) /* tap values staged per thread (D < 64: <= FL_QT * 32 taps) */
-#if FL_QT % FL_WAVES != 0
-#error FL_QT must be a multiple of FL_WAVES
-#endif
-#define FL_XROWS (FL_SLOTS * FL_R + FL_QT)      /* rows staged when D >= 64 (FL_SLOTS*R + FL_QT - 1 needed); multiple of FL_WAVES */
-#define FL_XSMALL ((FL_SLOTS * 512 + 23 * 32 + FL_NT - 1) / FL_NT) /* D < 64: FL_NT-sample columns staged (window <= FL_SLOTS*512 + 23 D) */
+// QT = tap rows resident in LDS (taps per phase a workgroup handles without re-staging): a template parameter of the kernel,
+// chosen per plan (fl_pick_qt).  24: the default Morlet frames (Q <= 18), 70 KB of LDS per workgroup.  32: frames with 24 < Q <= 32
+// -- the Mexican hat's second voice of every octave has Q = 29 or 30 --, exactly 80 KB, so that two workgroups still share a CU
+// (round 4: cfg4's 110 transforms 1.36 -> 1.22 ms; with 64 doubles of slack on top, i.e. ONE workgroup per CU, 1.66 ms).
+#define FL_TAPS_BYTES_(QT) ((QT) * 64 * 16)      /* 24 KiB / 32 KiB */
+#define FL_XROWS_(QT) (FL_SLOTS * FL_R + (QT))   /* rows staged when D >= 64 (FL_SLOTS*R + QT - 1 needed); multiple of FL_WAVES */
+#define FL_XSMALL_(QT) ((FL_SLOTS * 512 + ((QT) - 1) * 32 + FL_NT - 1) / FL_NT) /* D < 64: FL_NT-sample columns staged (window <= FL_SLOTS*512 + (QT - 1) D) */
 #define FL_XPAD (FL_NT * 9 / 8)                 /* padded LDS distance of two columns */
 #define FL_SCR 528                              /* reduction scratch per wave: 8 rows x 65 (+8) doubles */
 #define FL_MAX2(a, b) ((a) > (b) ? (a) : (b))
-#define FL_X_ALLOC (FL_MAX2(FL_MAX2(FL_XROWS * 64, FL_XSMALL * FL_XPAD), FL_WAVES * FL_SCR) + 64)
-#define FL_LDS_BYTES (FL_TAPS_BYTES + FL_X_ALLOC * 8)
+#define FL_XSLACK_(QT) ((QT) <= 24 ? 64 : 0)    /* doubles past the image (reads of prefetched rows that are never used stay inside the allocation; beyond it LDS reads return zeros) */
+#define FL_X_ALLOC_(QT) (FL_MAX2(FL_MAX2(FL_XROWS_(QT) * 64, FL_XSMALL_(QT) * FL_XPAD), FL_WAVES * FL_SCR) + FL_XSLACK_(QT))
+#define FL_LDS_BYTES_(QT) (FL_TAPS_BYTES_(QT) + FL_X_ALLOC_(QT) * 8)
+static_assert(FL_LDS_BYTES_(32) * 2 <= 160 * 1024, "two workgroups of the QT = 32 kernel must fit the 160 KB of a CU");
 
 #ifndef FL_TIMING
 #define FL_TIMING 0                             /* 1: per-phase s_memtime totals per LOGD class (tools/fwd_timing.py) */
@@ -117,13 +112,16 @@ struct FlWrapYes { static constexpr bool value = false; };
 // coefficients for the whole trace slice, so it phase-normalises each one right after the lane reduction and keeps
 // ST += Y, PS += Y/|Y| (ts_pws1f_lib.c:489-492) in registers, in trace order; one store per coefficient and slice at
 // the end (accST / accPS are the slice's [ncoef] planes).  Split scales (D > 64) still write their partials.
-template <typename TIn, int LOGD, bool FUSE, int PASSES>
+template <typename TIn, int LOGD, bool FUSE, int PASSES, int QT>
 __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const size_t ld, const unsigned ntr, const unsigned N, const ScaleDesc &d,
                                              const double2 *__restrict__ ws, double *__restrict__ pout0, const size_t npart,
                                              const unsigned chunk, const unsigned bb, double2 *tL, double *xL,
                                              double2 *__restrict__ accST, double2 *__restrict__ accPS)
 {
+	static_assert(QT % FL_R == 0 && QT % FL_WAVES == 0 && QT % FL_BATCH == 0, "QT: a multiple of the window length, the waves and the burst");
 	constexpr int R = FL_R;
+	constexpr int TPW = QT / FL_WAVES;                        // tap rows staged per wave (D >= 64)
+	constexpr int TSMALL = (QT * 32 + FL_NT - 1) / FL_NT;     // tap values staged per thread (D < 64: <= QT * 32 taps)
 	constexpr bool SMALL = LOGD < 6;
 	constexpr int LG = SMALL ? LOGD : 0;
 	constexpr unsigned DC = 1u << (SMALL ? LOGD : 6);     // D when SMALL
@@ -132,8 +130,8 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 	// WIDE (D >= 64, two slots per wave): the wave's two slots are ADJACENT output groups and share one 16-output sliding
 	// window -- one x row and one tap row per 32 FMAs instead of per 16 (the tap row alone is a 1-KB LDS read per wave).
 	constexpr bool WIDE = !SMALL && PASSES == 2 && FL_WIDE;
-	constexpr int XROWS = SLOTS * FL_R + FL_QT;            // rows staged when D >= 64
-	constexpr int NXV = SMALL ? (SLOTS * 512 + 23 * 32 + FL_NT - 1) / FL_NT : XROWS / FL_WAVES; // x values staged per thread
+	constexpr int XROWS = SLOTS * FL_R + QT;            // rows staged when D >= 64
+	constexpr int NXV = SMALL ? (SLOTS * 512 + (QT - 1) * 32 + FL_NT - 1) / FL_NT : XROWS / FL_WAVES; // x values staged per thread
 	const unsigned D = SMALL ? DC : d.D;
 	const unsigned tid = threadIdx.x, lane = tid & 63;
 	const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,7 +141,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 	const unsigned m0 = SMALL ? 0u : chunk * 64u;
 	const unsigned m = m0 + lane;
 
-	const unsigned ntile = (d.Q + FL_QT - 1) / FL_QT, qt = (d.Q + ntile - 1) / ntile; // balanced tiles
+	const unsigned ntile = (d.Q + QT - 1) / QT, qt = (d.Q + ntile - 1) / ntile; // balanced tiles
 	const bool resident = ntile == 1;
 
 	// ---- trace-independent staging geometry -------------------------------------------------
@@ -214,31 +212,31 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 		}
 	};
 	auto stage_taps = [&](unsigned qa, unsigned qn) {
-		if (SMALL) { // qn * D <= FL_QT * 32 values, natural order
-			double2 tv[FL_TSMALL];
+		if (SMALL) { // qn * D <= QT * 32 values, natural order
+			double2 tv[TSMALL];
 #pragma unroll
-			for (int i = 0; i < FL_TSMALL; i++) {
+			for (int i = 0; i < TSMALL; i++) {
 				const unsigned e = tid + (unsigned)FL_NT * (unsigned)i, l = qa * DC + e;
 				tv[i] = (e < qn * DC && l < d.L) ? ws[l] : make_double2(0.0, 0.0);
 			}
 #pragma unroll
-			for (int i = 0; i < FL_TSMALL; i++) if (tid + FL_NT * i < FL_QT * 64) tL[tid + FL_NT * i] = tv[i];
-		} else {     // rows wv, wv+4, ... of the FL_QT-row tile
-			double2 tv[FL_TPW];
+			for (int i = 0; i < TSMALL; i++) if (tid + FL_NT * i < QT * 64) tL[tid + FL_NT * i] = tv[i];
+		} else {     // rows wv, wv+4, ... of the QT-row tile
+			double2 tv[TPW];
 			const unsigned l0 = (qa + wv) * D + m;
-			if (qn == FL_QT && full && (qa + FL_QT - 1u) * D + m0 + 63 < d.L) { // a full tile whose every tap exists
+			if (qn == QT && full && (qa + QT - 1u) * D + m0 + 63 < d.L) { // a full tile whose every tap exists
 #pragma unroll
-				for (int i = 0; i < FL_TPW; i++) tv[i] = ws[l0 + (unsigned)FL_WAVES * D * (unsigned)i];
+				for (int i = 0; i < TPW; i++) tv[i] = ws[l0 + (unsigned)FL_WAVES * D * (unsigned)i];
 			} else {
 #pragma unroll
-				for (int i = 0; i < FL_TPW; i++) {
+				for (int i = 0; i < TPW; i++) {
 					const unsigned q = wv + (unsigned)FL_WAVES * (unsigned)i, l = l0 + (unsigned)FL_WAVES * D * (unsigned)i;
 					tv[i] = (m < D && q < qn && l < d.L) ? ws[l] : make_double2(0.0, 0.0);
 				}
 			}
 			double2 *tdst = tL + wv * 64 + lane;
 #pragma unroll
-			for (int i = 0; i < FL_TPW; i++) tdst[FL_NT * i] = tv[i];
+			for (int i = 0; i < TPW; i++) tdst[FL_NT * i] = tv[i];
 		}
 	};
 
@@ -302,12 +300,12 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 				for (int u = 0; u < FL_BATCH; u++) { xw[(u + R2 - 1) % RING] = xb[(u + R2 - 1) * 64]; tn[0][u] = tb[u * 64]; }
 				const bool first_tile = qa == 0;
 #pragma unroll
-				for (int h = 0; h < FL_QT / FL_BATCH; h++) {
+				for (int h = 0; h < QT / FL_BATCH; h++) {
 					if ((unsigned)(h * FL_BATCH) < qn) {
-						if (h + 1 < FL_QT / FL_BATCH) {
+						if (h + 1 < QT / FL_BATCH) {
 #pragma unroll
 							for (int u = 0; u < FL_BATCH; u++) {
-								xw[((h + 1) * FL_BATCH + u + R2 - 1) % RING] = xb[((h + 1) * FL_BATCH + u + R2 - 1) * 64]; // (last row read: 16 wv + FL_QT + 14 < XROWS)
+								xw[((h + 1) * FL_BATCH + u + R2 - 1) % RING] = xb[((h + 1) * FL_BATCH + u + R2 - 1) * 64]; // (last row read: 16 wv + QT + 14 < XROWS)
 								tn[(h + 1) & 1][u] = tb[((h + 1) * FL_BATCH + u) * 64];
 							}
 							asm volatile("" ::: "memory"); // the scheduler otherwise sinks these reads to just in front of their FMAs
@@ -361,9 +359,9 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 				for (int u = 0; u < FL_BATCH; u++) { xw[(u + R - 1) % RING] = xb[FL_XOFF(u + R - 1)]; tn[0][u] = tb[u * XS]; }
 				const bool first_tile = qa == 0;
 #pragma unroll
-				for (int h = 0; h < FL_QT / FL_BATCH; h++) {
+				for (int h = 0; h < QT / FL_BATCH; h++) {
 					if ((unsigned)(h * FL_BATCH) < qn) {
-						if (h + 1 < FL_QT / FL_BATCH) {
+						if (h + 1 < QT / FL_BATCH) {
 #pragma unroll
 							for (int u = 0; u < FL_BATCH; u++) {
 								xw[((h + 1) * FL_BATCH + u + R - 1) % RING] = xb[FL_XOFF((h + 1) * FL_BATCH + u + R - 1)];
@@ -399,7 +397,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 					for (int r = 0; r < R; r++) { ar[p][r] = 0; ai[p][r] = 0; }
 				}
 #pragma unroll
-				for (int h = 0; h < FL_QT / FL_BATCH; h++) { // LDS reads of FL_BATCH steps are issued together, then their FMAs
+				for (int h = 0; h < QT / FL_BATCH; h++) { // LDS reads of FL_BATCH steps are issued together, then their FMAs
 					if ((unsigned)(h * FL_BATCH) < qn) {
 						double xn[FL_BATCH];
 						double2 tn[FL_BATCH];
@@ -544,14 +542,14 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 // grid = (workgroups of all LDS scales, trace slices); a workgroup handles traces [slice*tps, min(ntr, (slice+1)*tps))
 // FUSE: accST / accPS + slice * acc_stride are the [ncoef] planes that receive the slice's stacks of the unsplit scales.
 // one workgroup of the LDS kernel: `bid` = its index among the lds_blocks workgroups of a trace slice, `slice` = trace slice
-template <typename TIn, bool FUSE>
+template <typename TIn, bool FUSE, int QT>
 __device__ __forceinline__ void fwd_lds_workgroup(const unsigned bid, const unsigned slice, char *smem, const TIn *__restrict__ x, size_t ld,
                                                   unsigned ntr, unsigned tps, unsigned N, const ScaleDesc *__restrict__ sc, unsigned S,
                                                   const double2 *__restrict__ w, double2 *__restrict__ part, size_t npart,
                                                   double2 *__restrict__ accST, double2 *__restrict__ accPS, size_t acc_stride)
 {
 	double2 *tL = (double2 *)smem;
-	double *xL = (double *)(smem + FL_TAPS_BYTES);
+	double *xL = (double *)(smem + FL_TAPS_BYTES_(QT));
 	// scale of this workgroup: last s with lds_off[s] <= bid among the scales that use this kernel
 	unsigned lo = 0, hi = S;
 	while (hi - lo > 1) {
@@ -570,14 +568,14 @@ __device__ __forceinline__ void fwd_lds_workgroup(const unsigned bid, const unsi
 #if FL_ABLATE
 	if (!((fl_class_mask >> (d.D >= 64 ? 6u : d.logDL)) & 1u)) return;
 #endif
-	if (d.D >= 64) { fwd_lds_body<TIn, 6, FUSE, FL_PASSES>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); return; }
+	if (d.D >= 64) { fwd_lds_body<TIn, 6, FUSE, FL_PASSES, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); return; }
 	switch (d.logDL) {
-	case 0: fwd_lds_body<TIn, 0, FUSE, FL_PASSES_FINE>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break; // D = 1 (Mexican hat, uni): 8 coefficients per lane
-	case 1: fwd_lds_body<TIn, 1, FUSE, FL_PASSES_FINE>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
-	case 2: fwd_lds_body<TIn, 2, FUSE, FL_PASSES_FINE>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
-	case 3: fwd_lds_body<TIn, 3, FUSE, FL_PASSES>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
-	case 4: fwd_lds_body<TIn, 4, FUSE, FL_PASSES>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
-	default: fwd_lds_body<TIn, 5, FUSE, FL_PASSES>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
+	case 0: fwd_lds_body<TIn, 0, FUSE, FL_PASSES_FINE, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break; // D = 1 (Mexican hat, uni): 8 coefficients per lane
+	case 1: fwd_lds_body<TIn, 1, FUSE, FL_PASSES_FINE, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
+	case 2: fwd_lds_body<TIn, 2, FUSE, FL_PASSES_FINE, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
+	case 3: fwd_lds_body<TIn, 3, FUSE, FL_PASSES, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
+	case 4: fwd_lds_body<TIn, 4, FUSE, FL_PASSES, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
+	default: fwd_lds_body<TIn, 5, FUSE, FL_PASSES, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
 	}
 }
 
@@ -588,7 +586,7 @@ __device__ __forceinline__ void fwd_lds_workgroup(const unsigned bid, const unsi
 #else
 #define FL_VGPR_ATTR
 #endif
-template <typename TIn, bool FUSE>
+template <typename TIn, bool FUSE, int QT>
 __global__ void __launch_bounds__(FL_NT, 2) FL_VGPR_ATTR k_fwd_lds(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
                                                  const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
                                                  double2 *__restrict__ part, size_t npart, double2 *__restrict__ accST,
@@ -600,5 +598,5 @@ __global__ void __launch_bounds__(FL_NT, 2) FL_VGPR_ATTR k_fwd_lds(const TIn *__
 	// the launch with short workgroups.
 	// bid0: first workgroup of the launch in the plan's list (a launch may cover a sub-range of the scales: sharded finish)
 	const unsigned bid = bid0 + (gridDim.x - 1u - blockIdx.x);
-	fwd_lds_workgroup<TIn, FUSE>(bid, blockIdx.y, smem, x, ld, ntr, tps, N, sc, S, w, part, npart, accST, accPS, acc_stride);
+	fwd_lds_workgroup<TIn, FUSE, QT>(bid, blockIdx.y, smem, x, ld, ntr, tps, N, sc, S, w, part, npart, accST, accPS, acc_stride);
 }

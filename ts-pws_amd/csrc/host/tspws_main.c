@@ -20,10 +20,16 @@
  * subsampling need the whole ensemble on one device and take the single-
  * device path.
  *
- * The frame (plan) and the device trace buffer of the last call are kept: a
- * caller that stacks many ensembles of the same length with the same wavelet
- * parameters (the CLI in a loop, the MATLAB gateway) pays for the frame once.
- * tspws_main_release() frees them; TSPWS_PLAN_CACHE=0 disables the cache.
+ * The frame (plan) and the device trace buffer of the last call ON EACH DEVICE
+ * are kept: a caller that stacks many ensembles of the same length with the
+ * same wavelet parameters (the CLI in a loop, the MATLAB gateway) pays for the
+ * frame once.  The cache is a small table with one slot and one lock per
+ * device: tspws_main() uses the device TSPWS_DEVICE names (default 0), the
+ * additive entry tspws_main_on(device, ...) any device, so a host that runs
+ * one stacking thread per GPU is not serialised (calls on the SAME device
+ * are: the slot's frame, scratch and trace buffer belong to one call at a
+ * time).  tspws_main_release() frees everything; TSPWS_PLAN_CACHE=0 disables
+ * the cache (each call then frees its device memory before it returns).
  */
 #include <math.h>
 #include <pthread.h>
@@ -41,21 +47,33 @@ static int device_from_env(void)
 
 #define TRY(call) do { rc = (call); if (rc) goto done; } while (0)
 
-/* ---- frame / trace-buffer cache (one entry: the last call's) ------------------------------------------------------ */
+/* ---- frame / trace-buffer cache: one slot per device, the last call's ---------------------------------------------------- */
 #define TSPWS_MAX_DEVICES 64
-static struct {
+typedef struct {
+	pthread_mutex_t lock;  /* one call at a time per device: the slot's frame, its scratch buffers and the trace buffer belong to the holder */
 	tspws_hip_plan *plan;
-	int type, uni, dev;
+	int type, uni;
 	unsigned J, V, N;
 	double s0, b0, w0;
-	float *d_sig;          /* device trace buffer, grown on demand */
+	float *d_sig;          /* device trace buffer ON THIS SLOT'S DEVICE, grown on demand */
 	size_t sig_bytes;
-	/* several devices: plans + communicator + shard buffers, keyed on the same frame parameters and the device list */
+} dev_slot;
+static dev_slot g_slot[TSPWS_MAX_DEVICES];
+
+/* several devices in one call (TSPWS_DEVICES): plans + communicator + shard buffers, keyed on the frame parameters and the device list */
+static struct {
 	tspws_hip_multi *multi;
 	int mtype, muni, mndev, mdevs[TSPWS_MAX_DEVICES];
 	unsigned mJ, mV, mN;
 	double ms0, mb0, mw0;
 } g_cache;
+static pthread_mutex_t g_multi_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static pthread_once_t g_once = PTHREAD_ONCE_INIT;
+static void init_slots(void)
+{
+	for (int i = 0; i < TSPWS_MAX_DEVICES; i++) pthread_mutex_init(&g_slot[i].lock, NULL);
+}
 
 static int cache_enabled(void)
 {
@@ -63,23 +81,43 @@ static int cache_enabled(void)
 	return !(e && *e == '0');
 }
 
-/* One call at a time: the cached frame, its scratch buffers and the device trace buffer belong to the call that holds the lock
- * (the reference's tspws_main has no shared state; concurrent callers of this one are serialised -- the GPU is the shared resource). */
-static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
-
-static void release_locked(void)
+static void slot_release_locked(dev_slot *sl)
 {
-	tspws_hip_plan_destroy(g_cache.plan);
-	tspws_hip_free(g_cache.d_sig);
+	tspws_hip_plan_destroy(sl->plan);
+	tspws_hip_free(sl->d_sig);
+	sl->plan = NULL; sl->d_sig = NULL; sl->sig_bytes = 0;
+}
+
+static void multi_release_locked(void)
+{
 	tspws_hip_multi_destroy(g_cache.multi);
 	memset(&g_cache, 0, sizeof g_cache);
 }
 
 void tspws_main_release(void)
 {
-	pthread_mutex_lock(&g_lock);
-	release_locked();
-	pthread_mutex_unlock(&g_lock);
+	pthread_once(&g_once, init_slots);
+	for (int i = 0; i < TSPWS_MAX_DEVICES; i++) {
+		pthread_mutex_lock(&g_slot[i].lock);
+		slot_release_locked(&g_slot[i]);
+		pthread_mutex_unlock(&g_slot[i].lock);
+	}
+	pthread_mutex_lock(&g_multi_lock);
+	multi_release_locked();
+	pthread_mutex_unlock(&g_multi_lock);
+}
+
+/* test hook: which devices hold a cached frame right now (bit i = device i < 64) */
+unsigned long long tspws_main_cached_devices(void)
+{
+	unsigned long long m = 0;
+	pthread_once(&g_once, init_slots);
+	for (int i = 0; i < TSPWS_MAX_DEVICES; i++) {
+		pthread_mutex_lock(&g_slot[i].lock);
+		if (g_slot[i].plan) m |= 1ull << i;
+		pthread_mutex_unlock(&g_slot[i].lock);
+	}
+	return m;
 }
 
 /* TSPWS_DEVICES: "all" or a comma-separated list of HIP device ids; returns the number of entries (0: not set) */
@@ -123,6 +161,24 @@ static int get_multi(tspws_hip_multi **m, const t_tsPWS *p, unsigned N, const in
 	return 0;
 }
 
+/* fold / mean removal of the host traces on `dev`, mirrored back (what is left of a call whose frame cannot be built: the
+ * reference rewrites sigall, :71-88 and :159-169, before it fails with 4 at :199-204) */
+static int prologue_only(t_data *in, size_t mtr, int do_fold, int lrm, int dev)
+{
+	const size_t ld = (size_t)in->hdr.max, bytes = mtr * ld * sizeof(float);
+	float *d = NULL;
+	int rc = 0;
+	if ((!do_fold && !lrm) || !bytes) return 0;
+	TRY(tspws_hip_alloc((void **)&d, bytes, dev));
+	TRY(tspws_hip_upload(d, in->sigall, bytes, NULL));
+	if (do_fold) TRY(tspws_hip_fold(d, mtr, ld, ld, NULL));
+	if (lrm) TRY(tspws_hip_remove_mean(d, mtr, ld, ld, NULL));
+	TRY(tspws_hip_download(in->sigall, d, bytes, NULL));
+done:
+	tspws_hip_free(d);
+	return rc;
+}
+
 /* The call over trace shards on several devices (no convergence curves, no random subsampling: the caller checked). */
 static int main_multi(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in, size_t mtr, int do_fold, const int *devs, int ndev)
 {
@@ -135,7 +191,10 @@ static int main_multi(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in, size_t mtr, 
 	int rc = get_multi(&m, tspws, nsamp, devs, ndev);
 	if (rc) {
 		printf("tspws_main: cannot set up the devices / the wavelet frame (%s)\n", tspws_hip_last_error());
-		return rc == TSPWS_E_NODEV ? rc : TSPWS_E_NOMEM;
+		if (rc == TSPWS_E_NODEV) return rc;
+		/* like the single-device path and the reference: a frame that cannot be built fails AFTER the prologue has rewritten sigall */
+		(void)prologue_only(in, mtr, do_fold, tspws->lrm, devs[0]);
+		return TSPWS_E_NOMEM;
 	}
 	TRY(tspws_hip_multi_upload(m, in->sigall, ld, mtr, &d_shards, &d_ls, &d_ts));
 	TRY(tspws_hip_multi_prologue(m, in->sigall, ld, ld, mtr, do_fold, tspws->lrm));
@@ -164,61 +223,66 @@ done:
 	if (rc) printf("tspws_main: HIP path failed (%d: %s)\n", rc, tspws_hip_last_error());
 	free(sel);
 	free(jk);
-	if (!cache_enabled()) release_locked();
+	if (!cache_enabled()) multi_release_locked();
 	return rc;
 }
 
-/* the frame of (type, J, V, N, s0, b0, w0, uni) on `dev`: the cached one when every parameter matches bit for bit */
-static int get_plan(tspws_hip_plan **plan, const t_tsPWS *p, unsigned N, int dev)
+/* the frame of (type, J, V, N, s0, b0, w0, uni) on the slot's device: the cached one when every parameter matches bit for bit */
+static int get_plan(dev_slot *sl, tspws_hip_plan **plan, const t_tsPWS *p, unsigned N, int dev)
 {
-	if (g_cache.plan && g_cache.type == p->type && g_cache.J == p->J && g_cache.V == p->V && g_cache.N == N && g_cache.s0 == p->s0 &&
-	    g_cache.b0 == p->b0 && g_cache.w0 == p->w0 && g_cache.uni == (int)p->uni && g_cache.dev == dev) {
-		*plan = g_cache.plan;
+	if (sl->plan && sl->type == p->type && sl->J == p->J && sl->V == p->V && sl->N == N && sl->s0 == p->s0 &&
+	    sl->b0 == p->b0 && sl->w0 == p->w0 && sl->uni == (int)p->uni) {
+		*plan = sl->plan;
 		return 0;
 	}
 	tspws_hip_plan *fresh = NULL;
 	int rc = tspws_hip_plan_create(&fresh, p->type, p->J, p->V, N, p->s0, p->b0, p->w0, (int)p->uni, dev);
 	if (rc) return rc;
-	tspws_hip_plan_destroy(g_cache.plan);
-	g_cache.plan = fresh;
-	g_cache.type = p->type; g_cache.J = p->J; g_cache.V = p->V; g_cache.N = N; g_cache.s0 = p->s0; g_cache.b0 = p->b0; g_cache.w0 = p->w0;
-	g_cache.uni = (int)p->uni; g_cache.dev = dev;
+	tspws_hip_plan_destroy(sl->plan);
+	sl->plan = fresh;
+	sl->type = p->type; sl->J = p->J; sl->V = p->V; sl->N = N; sl->s0 = p->s0; sl->b0 = p->b0; sl->w0 = p->w0;
+	sl->uni = (int)p->uni;
 	*plan = fresh;
 	return 0;
 }
 
-static int get_trace_buffer(float **d_sig, size_t bytes, int dev)
+/* the slot's trace buffer lives on the slot's device by construction (slot index == device) */
+static int get_trace_buffer(dev_slot *sl, float **d_sig, size_t bytes, int dev)
 {
-	if (g_cache.d_sig && (g_cache.sig_bytes < bytes || g_cache.dev != dev)) { tspws_hip_free(g_cache.d_sig); g_cache.d_sig = NULL; g_cache.sig_bytes = 0; }
-	if (!g_cache.d_sig) {
-		int rc = tspws_hip_alloc((void **)&g_cache.d_sig, bytes, dev);
+	if (sl->d_sig && sl->sig_bytes < bytes) { tspws_hip_free(sl->d_sig); sl->d_sig = NULL; sl->sig_bytes = 0; }
+	if (!sl->d_sig) {
+		int rc = tspws_hip_alloc((void **)&sl->d_sig, bytes, dev);
 		if (rc) return rc;
-		g_cache.sig_bytes = bytes;
+		sl->sig_bytes = bytes;
 	}
-	*d_sig = g_cache.d_sig;
+	*d_sig = sl->d_sig;
 	return 0;
 }
 
-static int main_locked(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in);
+static int run_call(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in, int dev, int allow_multi);
+static int main_single(dev_slot *sl, t_tsPWS *tspws, t_tsPWS_out *out, t_data *in, size_t mtr, int do_fold, int dev, char *sub_sel);
 
 int tspws_main(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 {
 	if (tspws == NULL || out == NULL || in == NULL) { printf("tspws_main: NULL input\n"); return -1; }
-	pthread_mutex_lock(&g_lock);
-	const int rc = main_locked(tspws, out, in);
-	pthread_mutex_unlock(&g_lock);
-	return rc;
+	return run_call(tspws, out, in, device_from_env(), 1);
 }
 
-static int main_locked(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
+/* tspws_main on an explicit device (additive: include/tspws_hip.h).  TSPWS_DEVICE / TSPWS_DEVICES are not consulted: a host
+ * that runs one stacking thread per GPU names the device itself, and calls on different devices run concurrently. */
+int tspws_main_on(int device, t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 {
+	if (tspws == NULL || out == NULL || in == NULL) { printf("tspws_main: NULL input\n"); return -1; }
+	return run_call(tspws, out, in, device, 0);
+}
 
+static int run_call(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in, int dev, int allow_multi)
+{
 	const int    max   = in->hdr.max;
 	size_t mtr = tspws->Nmax ? tspws->Nmax : in->hdr.mtr;
 	const float  beg   = in->hdr.beg, dt = in->hdr.dt;
 	const unsigned nsamp = (unsigned)max;
-	const int dev = device_from_env();
-	int rc = 0, do_fold = 0;
+	int do_fold = 0;
 
 	/* The reference reads past the end of sigall when Nmax exceeds the trace count (:65, unchecked); here the request
 	 * is clamped instead of faulting. */
@@ -252,11 +316,13 @@ static int main_locked(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 		printf("Engine: MI355X HIP path, device %d\n\n", dev);
 	}
 
+	if (!mtr) return 0; /* the reference builds the family and returns 0 without touching out (:194) -- with or without a device */
+
 	/* Random subsampling (:324-333): the masks are drawn NOW, before the first HIP call of the process -- the initialisation of the
 	 * HIP runtime consumes libc rand() values, and the masks must come from the state the caller seeded (srand), as the reference's
 	 * do.  Nothing else on this path calls rand(), so the order of the draws is the reference's (SubsamplingPlan, :355-383). */
 	char *sub_sel = NULL;
-	const int want_sub = tspws->subsmpl_N > 0 && tspws->subsmpl_p > 0 && out->ls_subsmpl && out->tsPWS_subsmpl && mtr > 0 && tspws->J && tspws->V;
+	const int want_sub = tspws->subsmpl_N > 0 && tspws->subsmpl_p > 0 && out->ls_subsmpl && out->tsPWS_subsmpl && tspws->J && tspws->V;
 	if (want_sub) {
 		const unsigned M = tspws->subsmpl_N;
 		const size_t K = (size_t)ceil((double)mtr * tspws->subsmpl_p);
@@ -265,12 +331,42 @@ static int main_locked(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 		for (unsigned m = 0; m < M; m++) tspws_subsampling_plan(sub_sel + (size_t)m * mtr, mtr, K);
 	}
 
-	if (tspws_hip_device_count() <= dev) {
+	int devs[TSPWS_MAX_DEVICES];
+	int ndev = allow_multi ? devices_from_env(devs, TSPWS_MAX_DEVICES) : 0;
+	/* a one-entry TSPWS_DEVICES names THE device of the call (the sharded path on one device only under TSPWS_COMM: tests) */
+	if (ndev == 1 && !getenv("TSPWS_COMM")) { dev = devs[0]; ndev = 0; }
+
+	if (dev < 0 || dev >= TSPWS_MAX_DEVICES || tspws_hip_device_count() <= dev) {
 		printf("tspws_main: no usable HIP device (%s)\n", tspws_hip_last_error());
 		free(sub_sel);
 		return TSPWS_E_NODEV;
 	}
+	pthread_once(&g_once, init_slots);
 
+	if (ndev >= 1) { /* several devices (or TSPWS_COMM set: the sharded path even on one device -- tests) */
+		const int needs_one = (tspws->convergence && out->ls_sim && out->tsPWS_sim && out->ls_misfit && out->tsPWS_misfit) ||
+		                      (tspws->subsmpl_N > 0 && tspws->subsmpl_p > 0 && out->ls_subsmpl && out->tsPWS_subsmpl);
+		if (!needs_one && tspws->J && tspws->V) {
+			free(sub_sel);
+			pthread_mutex_lock(&g_multi_lock);
+			const int rc = main_multi(tspws, out, in, mtr, do_fold, devs, ndev);
+			pthread_mutex_unlock(&g_multi_lock);
+			return rc;
+		}
+	}
+
+	dev_slot *sl = &g_slot[dev];
+	pthread_mutex_lock(&sl->lock);
+	const int rc = main_single(sl, tspws, out, in, mtr, do_fold, dev, sub_sel);
+	pthread_mutex_unlock(&sl->lock);
+	return rc;
+}
+
+static int main_single(dev_slot *sl, t_tsPWS *tspws, t_tsPWS_out *out, t_data *in, size_t mtr, int do_fold, int dev, char *sub_sel)
+{
+	const int max = in->hdr.max;
+	const unsigned nsamp = (unsigned)max;
+	int rc = 0;
 	tspws_hip_plan *plan = NULL;
 	float *d_sig = NULL, *d_out = NULL, *d_jk = NULL, *d_ref = NULL, *d_steps_ts = NULL, *d_steps_ls = NULL;
 	char *sel = NULL;
@@ -278,18 +374,7 @@ static int main_locked(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 	float *stage = NULL;
 	const size_t ld = (size_t)max;
 
-	if (!mtr) return 0; /* the reference builds the family and returns 0 without touching out (:194) */
-
-	{ /* several devices (or TSPWS_COMM set: the sharded path even on one device -- tests) */
-		int devs[TSPWS_MAX_DEVICES];
-		const int ndev = devices_from_env(devs, TSPWS_MAX_DEVICES);
-		const int needs_one = (tspws->convergence && out->ls_sim && out->tsPWS_sim && out->ls_misfit && out->tsPWS_misfit) ||
-		                      (tspws->subsmpl_N > 0 && tspws->subsmpl_p > 0 && out->ls_subsmpl && out->tsPWS_subsmpl);
-		if ((ndev > 1 || (ndev == 1 && getenv("TSPWS_COMM"))) && !needs_one && tspws->J && tspws->V)
-			{ free(sub_sel); return main_multi(tspws, out, in, mtr, do_fold, devs, ndev); }
-	}
-
-	int frame_rc = get_plan(&plan, tspws, nsamp, dev);
+	int frame_rc = get_plan(sl, &plan, tspws, nsamp, dev);
 	if (frame_rc) {
 		printf("tspws_main: cannot build the wavelet frame (%s)\n", tspws_hip_last_error());
 		if (frame_rc == TSPWS_E_NODEV) { free(sub_sel); return frame_rc; }
@@ -299,7 +384,7 @@ static int main_locked(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in)
 		if (!do_fold && !tspws->lrm) { free(sub_sel); return TSPWS_E_NOMEM; }
 	}
 
-	TRY(get_trace_buffer(&d_sig, mtr * ld * sizeof(float), dev));
+	TRY(get_trace_buffer(sl, &d_sig, mtr * ld * sizeof(float), dev));
 	TRY(tspws_hip_upload(d_sig, in->sigall, mtr * ld * sizeof(float), NULL));
 
 	/* in-place prologue on the device, then mirrored back: the caller sees the same mutated
@@ -393,6 +478,6 @@ done_quiet:
 	tspws_hip_free(d_ref);
 	tspws_hip_free(d_jk);
 	tspws_hip_free(d_out);
-	if (!cache_enabled()) release_locked(); /* else: the frame and the trace buffer serve the next call */
+	if (!cache_enabled()) slot_release_locked(sl); /* else: the frame and the trace buffer serve the next call on this device */
 	return rc;
 }

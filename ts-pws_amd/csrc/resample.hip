@@ -73,9 +73,10 @@ __global__ void __launch_bounds__(256) k_jk_linear(const double *__restrict__ P,
 //
 // A ClassSums object belongs to ONE call: it owns the host tables whose uploads may still be in flight, so the call
 // synchronises its stream before the object goes out of scope (cs_done).
+static constexpr unsigned SIG_DELETED = ~0u; // (32-bit signatures: Kmax is an unsigned in t_tsPWS, any value is a legal group count)
 struct ClassSums {
 	unsigned C = 0, KM = 0, ncls = 0;
-	std::vector<std::vector<unsigned short>> sig;   // per class: group in each replica (0xFFFF = deleted) [+ plain group]
+	std::vector<std::vector<unsigned>> sig;         // per class: group in each replica (SIG_DELETED = deleted) [+ plain group]
 	std::vector<size_t> Kc;                         // traces per replica
 	std::vector<Chunk> chunks;
 	std::vector<unsigned> row_first;
@@ -103,7 +104,7 @@ static int class_sums(tspws_hip_plan *pl, ClassSums &cs, unsigned KM, const floa
 	                 memo.clen == clen && memo.with_main == with_main && memo.sel.size() == (size_t)C * mtr && !memcmp(memo.sel.data(), h_sel, (size_t)C * mtr);
 	if (hit) { cs.sig = memo.cs.sig; cs.Kc = memo.cs.Kc; cs.chunks = memo.cs.chunks; cs.row_first = memo.cs.row_first; }
 	else {
-	// signature of trace i: group index in every replica (0xFFFF = deleted)
+	// signature of trace i: group index in every replica (SIG_DELETED = deleted)
 	// (the reference's floor((double)(k * KM) / (double)Kc), :766, is the integer quotient: k * KM < 2^53 and a non-integer
 	// quotient is at least 1 / Kc away from the next integer, far more than a rounding of the division)
 	cs.Kc.assign(C, 0);
@@ -113,24 +114,24 @@ static int class_sums(tspws_hip_plan *pl, ClassSums &cs, unsigned KM, const floa
 		for (size_t i = 0; i < mtr; i++) n += row[i] == 1;
 		cs.Kc[c] = n;
 	}
-	std::vector<unsigned short> sig((size_t)mtr * W);
+	std::vector<unsigned> sig((size_t)mtr * W);
 	for (unsigned c = 0; c < C; c++) {
 		const char *row = h_sel + (size_t)c * mtr;
 		const size_t Kc = std::max<size_t>(cs.Kc[c], 1);
 		size_t k = 0;
 		for (size_t i = 0; i < mtr; i++) {
-			if (row[i] == 1) { sig[i * W + c] = (unsigned short)((k * KM) / Kc); k++; }
-			else sig[i * W + c] = 0xFFFF;
+			if (row[i] == 1) { sig[i * W + c] = (unsigned)((k * KM) / Kc); k++; }
+			else sig[i * W + c] = SIG_DELETED;
 		}
 	}
-	if (with_main) for (size_t i = 0; i < mtr; i++) sig[i * W + C] = (unsigned short)std::min<size_t>((i * KM) / mtr, KM - 1);
+	if (with_main) for (size_t i = 0; i < mtr; i++) sig[i * W + C] = (unsigned)std::min<size_t>((i * KM) / mtr, KM - 1);
 	cs.sig.clear(); cs.chunks.clear();
 	std::vector<std::vector<Chunk>> cls_chunks;
 	std::unordered_map<std::string, size_t> cls_of; // signature bytes -> class (classes numbered in order of first appearance)
 	for (size_t i = lo; i < hi;) {
 		size_t j = i + 1;
-		while (j < hi && !memcmp(&sig[i * W], &sig[j * W], W * sizeof(unsigned short))) j++;
-		const std::string key((const char *)&sig[i * W], W * sizeof(unsigned short));
+		while (j < hi && !memcmp(&sig[i * W], &sig[j * W], W * sizeof(unsigned))) j++;
+		const std::string key((const char *)&sig[i * W], W * sizeof(unsigned));
 		auto it = cls_of.find(key);
 		size_t id;
 		if (it == cls_of.end()) {

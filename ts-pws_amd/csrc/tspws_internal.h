@@ -134,6 +134,7 @@ struct tspws_hip_plan {
 	unsigned acc_blocks = 0;   // blocks of k_accumulate_masked (256 coefficients each)
 	unsigned acc2_blocks = 0;  // blocks of k_accumulate_parts
 	unsigned lds_blocks = 0;   // workgroups per trace slice of k_fwd_lds
+	unsigned lds_qt = 24;      // tap rows resident in LDS: the k_fwd_lds instantiation of this frame (24 or 32, tspws_build_forward)
 	unsigned n_fusable = 0;    // scales whose stacks the fused forward kernel keeps in registers
 	// many-trace decompositions (fwd_tl.h): tl[0] for batches of many 64-trace blocks, tl[1] for few (more scales on the
 	// direct kernel, whose parallelism is in the taps): see TlTable
