@@ -44,6 +44,13 @@ def parse():
     ap.add_argument("--traces", type=int, default=None, help="traces per GPU (overrides --config)")
     ap.add_argument("--samples", type=int, default=131072)
     ap.add_argument("--kmax", type=int, default=10)
+    ap.add_argument("--schedule", choices=["single", "split", "sharded-finish"], default=None,
+                    help="N > 1: placement of the one logical reduction of P[K][N] (ts-pws_amd.stack_sharded): single = ONE all-reduce + redundant "
+                         "finish (north_star's wording), split = two halves overlapped with streaming / transforms, sharded-finish (default) = "
+                         "pieces K-2 | 2 + scale-sharded finish")
+    ap.add_argument("--shard-of", type=int, default=None,
+                    help="one GPU only: treat the traces as rank 0's shard of an ensemble this many times larger (cfg5 on one GPU: 12 500 of 100 000; "
+                         "default 8 for --config cfg5 --gpus 1, else 1)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline, host-path and other-config legs")
     ap.add_argument("--no-extra", action="store_true", help="skip the host-path and other-config legs only")
     return ap.parse_args()
@@ -111,8 +118,13 @@ def run(args):
 
     mtr_local = args.traces if args.traces is not None else (12500 if args.config == "cfg5" else 10000)
     N, K = args.samples, args.kmax
-    mtr_global = mtr_local * world
+    # one GPU, cfg5: the traces are rank 0's shard of the 8-times larger ensemble of BASELINE configs[4] -- the group index comes
+    # from the GLOBAL trace index (ts_pws1f_lib.c:876), so the shard fills groups 0 and 1 and leaves zero rows, as on a node
+    shard_of = args.shard_of if args.shard_of is not None else (8 if (args.config == "cfg5" and world == 1) else 1)
+    assert shard_of == 1 or world == 1, "--shard-of is the one-GPU stand-in for a shard of a larger ensemble"
+    mtr_global = mtr_local * world * shard_of
     first = rank * mtr_local
+    schedule = args.schedule or os.environ.get("TSPWS_SCHEDULE") or "sharded-finish"
     params = tspws.resolve(abi.default_params(Kmax=K, unbiased=1), N)
     t_plan = time.perf_counter()
     plan = tspws.Plan(params, N, device=local)  # frame geometry + tap generation on the device (outside the timed region)
@@ -124,11 +136,14 @@ def run(args):
     ts = torch.empty(N, dtype=torch.float32, device=X.device)
     red = plan.reduce_buffer(mtr_global)
 
-    single = world == 1
+    single = world == 1 and shard_of == 1
     # N > 1: share of the scales this rank finishes (None: no sharded finish -- agreed across the ranks)
-    shard = tspws._finish_shard(plan, mtr_global) if world > 1 else None
+    shard = tspws._finish_shard(plan, mtr_global) if (world > 1 and schedule == "sharded-finish") else None
+    if world > 1 and schedule == "sharded-finish" and shard is None:
+        schedule = "split"   # this frame / these parameters have no sharded finish
     x2 = torch.empty(2 * N, dtype=torch.float64, device=X.device)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    # events on the launch stream of every timed step: start, end of streaming, reductions done (finish may start), end
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     launches = [0]
 
     def piece(g0, g1, count):
@@ -142,19 +157,32 @@ def run(args):
             # call and its streaming stage on the launch stream
             plan.stack_single(X, ls, ts)
             return
-        # N > 1: the streaming stage in two pieces of the groups; the all-reduce of the first piece (RCCL, its own stream)
-        # overlaps the streaming of the second -- one logical fp64 reduction of P[Kmax][N] (ts-pws_amd.stack_sharded)
-        half = tspws.split_groups(K, shard is not None)
         buf = red.view(K, N)
         if i is not None:
             ev[i][0].record()
-        if half == 0:  # a single group: nothing to overlap
+        if world == 1:
+            # one GPU standing in for one rank of a larger job: the shard-local half with the global group index, no collective
+            # (there is no peer), then the finish stage on the shard's own buffer
+            plan.stack_local(X, first, mtr_global)
+            if count:
+                launches[0] += lib.tspws_hip_stream_launches(plan.h)
+            if i is not None:
+                ev[i][1].record()
+                ev[i][2].record()
+            plan.stack_finish(mtr_global, ls, ts)
+        elif schedule == "single" or K < 2:
+            # north_star's wording: ONE all-reduce of the whole buffer between the halves, every rank finishes redundantly
             piece(0, K, count)
             if i is not None:
                 ev[i][1].record()
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            if i is not None:
+                ev[i][2].record()
             plan.stack_finish(mtr_global, ls, ts)
         else:
+            # the streaming stage in two pieces of the groups; the all-reduce of the first piece (RCCL, its own stream) overlaps the
+            # streaming of the second -- still one logical fp64 reduction of P[Kmax][N] (ts-pws_amd.stack_sharded)
+            half = max(1, tspws.split_groups(K, shard is not None))
             piece(0, half, count)
             w1 = dist.all_reduce(buf[:half], op=dist.ReduceOp.SUM, async_op=True)
             piece(half, K, count)
@@ -166,6 +194,8 @@ def run(args):
                 # add their partial reconstructions (2 N doubles) and every rank ends with the outputs
                 w1.wait()
                 w2.wait()
+                if i is not None:
+                    ev[i][2].record()
                 plan.stack_finish_scales(mtr_global, shard[0], shard[1], x2)
                 dist.all_reduce(x2, op=dist.ReduceOp.SUM)
                 plan.epilogue(x2, mtr_global, ls, ts)
@@ -173,10 +203,12 @@ def run(args):
                 w1.wait()
                 plan.stack_finish_range(mtr_global, 0, half)   # transforms of the reduced half run beside the second reduction
                 w2.wait()
+                if i is not None:
+                    ev[i][2].record()
                 plan.stack_finish_range(mtr_global, half, K)
                 plan.stack_finish_tail(mtr_global, ls, ts)
         if i is not None:
-            ev[i][2].record()
+            ev[i][3].record()
 
     for w in range(max(1, args.warmup)):
         step(count=(w == 0))
@@ -204,30 +236,39 @@ def run(args):
         nlaunch = max(1, lib.tspws_hip_stream_launches(plan.h))
     else:
         stage_ms = np.array([e[0].elapsed_time(e[1]) for e in ev])
-        call_ms = np.array([e[0].elapsed_time(e[2]) for e in ev])
+        call_ms = np.array([e[0].elapsed_time(e[3]) for e in ev])
         nlaunch = max(1, launches[0])
     stream_ms = float(np.mean(stage_ms))
     alg_bytes = 4.0 * mtr_local * N + 8.0 * K * N   # read every float32 sample once + write the K fp64 partials
     achieved = alg_bytes / (stream_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes of profiles/collect_pmc.sh (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs): a record
+    # is quoted only for the exact launch shape AND the exact source of the streaming kernel it was measured on (sha256 of
+    # csrc/stream.hip, written by profiles/collect_round.sh) -- a changed kernel reports null until its counters are collected again
     traffic = None
     tf = os.path.join(ROOT, "profiles", "pmc_partial_stacks.json")
-    if os.path.exists(tf) and (mtr_local, N, K) == (10000, 131072, 10):  # the PMC record is for this exact launch shape
+    if os.path.exists(tf) and (mtr_local, N, K, shard_of) == (10000, 131072, 10, 1):
         try:
             rec = json.load(open(tf))
-            traffic = rec.get("hbm_bytes_per_launch") if rec.get("launches_per_call") == nlaunch else None
+            same_src = rec.get("stream_hip_sha256") == file_sha256(os.path.join(ROOT, "ts-pws_amd", "csrc", "stream.hip"))
+            traffic = rec.get("hbm_bytes_per_launch") if (rec.get("launches_per_call") == nlaunch and same_src) else None
         except Exception:
             traffic = None
 
-    which = ("BASELINE configs[4]: 100k traces over 8 GPUs" if (mtr_local == 12500) else
+    which = ("BASELINE configs[4]-shard: one rank's 12 500 of the 100 000 traces (global group index, rows of foreign groups zero), no peer to reduce with"
+             if (mtr_local == 12500 and world == 1 and shard_of == 8) else
+             "BASELINE configs[4]: 100k traces over 8 GPUs" if (mtr_local == 12500 and world == 8) else
+             "BASELINE configs[4] shard size, other rank count" if mtr_local == 12500 else
              "BASELINE configs[2]" if (mtr_local, N, K) == (10000, 131072, 10) else "custom size")
-    if shard is not None:
-        par = (f"trace-sharded x{world}: fp64 all-reduce of P[K][N] in two pieces (the first, K-2 groups, overlaps the streaming of the last two), then a "
+    if world == 1:
+        par = "one GPU: no collective" + (f" (rank 0 of a virtual {shard_of}-rank job: shard-local half + finish)" if shard_of > 1 else "")
+    elif schedule == "sharded-finish":
+        par = (f"schedule=sharded-finish, trace-sharded x{world}: fp64 all-reduce of P[K][N] in two pieces (the first, K-2 groups, overlaps the streaming of the last two), then a "
                f"scale-sharded finish stage: every rank transforms / weights / reconstructs its share of the scales, all-reduce of the 2 N partial reconstructions")
-    elif world > 1:
-        par = (f"trace-sharded x{world}, fp64 all-reduce of P[K][N] in two halves: the first overlaps the streaming of the second, the second the "
+    elif schedule == "split":
+        par = (f"schedule=split, trace-sharded x{world}: fp64 all-reduce of P[K][N] in two halves: the first overlaps the streaming of the second, the second the "
                f"transforms of the first; every rank finishes redundantly")
     else:
-        par = "one GPU: no collective"
+        par = f"schedule=single, trace-sharded x{world}: ONE fp64 all-reduce of P[K][N] between the shard-local half and the redundant finish stage"
     res = {
         "metric": baseline_metric(),
         "value": mtr_global * N * args.steps / dt,
@@ -251,7 +292,21 @@ def run(args):
         "whole_call_frac_of_hbm_roofline": (alg_bytes / (dt / args.steps) / 1e9) / HBM_PEAK_GBS,
     }
 
-    if world == 1 and rank == 0:
+    if not single:
+        # where a step's time goes on every rank (HIP events on the launch stream): streaming, the part of the reduction(s) that is
+        # NOT hidden behind streaming or transforms (end of streaming -> all partial stacks reduced), the rest (finish stage incl. its
+        # own small all-reduce under sharded-finish)
+        mine = [float(np.mean([e[0].elapsed_time(e[1]) for e in ev])), float(np.mean([e[1].elapsed_time(e[2]) for e in ev])),
+                float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))]
+        if world > 1:
+            t3 = torch.tensor(mine, dtype=torch.float64, device=X.device)
+            allr = [torch.zeros_like(t3) for _ in range(world)]
+            dist.all_gather(allr, t3)
+            per_rank = [[round(float(v), 4) for v in t.tolist()] for t in allr]
+        else:
+            per_rank = [[round(v, 4) for v in mine]]
+        res["per_rank_ms"] = {"columns": ["stream", "exposed_collective", "finish"], "ranks": per_rank, "schedule": schedule if world > 1 else None}
+    if world == 1 and shard_of == 1 and rank == 0:
         res["with_output_d2h"] = with_d2h(torch, plan, X, ls, ts, N, mtr_local, args.steps)
         if not args.no_cpu:
             Xh = X.cpu().numpy()
@@ -265,6 +320,12 @@ def run(args):
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def file_sha256(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
 
 
 def rccl_version(torch):
@@ -427,6 +488,18 @@ def other_configs(abi, tspws, lib, torch, X, N):
     sel = np.zeros((Cn, mtr), np.int8)
     assert lib.tspws_jackknife_plan(sel.ctypes.data, times.ctypes.data, mtr, 1, 10, Cn) == 0
     sec = timeit(torch, lambda: pl4.stack_jackknife(X, sel), 10, 3)
+    # the class structure of a selection is kept per host thread (keyed by content): the figure above is the steady state of a
+    # caller that repeats its time stamps (the same days for every station pair); a NEW selection pays the host-side class
+    # construction again -- timed by alternating between two different selections
+    times_b = times + 86400 * 5
+    sel_b = np.zeros((Cn, mtr), np.int8)
+    assert lib.tspws_jackknife_plan(sel_b.ctypes.data, times_b.ctypes.data, mtr, 1, 10, Cn) == 0
+    flip = [0]
+
+    def changed():
+        flip[0] ^= 1
+        pl4.stack_jackknife(X, sel_b if flip[0] else sel)
+    sec_changed = timeit(torch, changed, 10, 2)
     alg = 4.0 * mtr * N + 8.0 * N + 8.0 * 10 * N + 8.0 * Cn * N
     nsub = min(mtr, 1000)
     sel_s = np.zeros((Cn, nsub), np.int8)
@@ -435,7 +508,9 @@ def other_configs(abi, tspws, lib, torch, X, N):
     torch.cuda.synchronize()
     r = call_main(abi, cpu_fn, pin, X[:nsub].cpu().numpy(), N, nsub, times=times[:nsub].copy(), C_rep=Cn)
     out["cfg4_mexhat_twostage_jackknife_n10_d1"] = {
-        "ms_per_call": sec * 1e3, "timed_calls": 10, "warmup_calls": 3, "value": mtr * N / sec, "unit": "samples/s", "replicas": Cn, "traces": mtr, "V": p4.V, "J": p4.J, "scales": pl4.S,
+        "ms_per_call": sec * 1e3, "ms_per_call_changed_selection": sec_changed * 1e3,
+        "selection": "ms_per_call: the same selection every call (class structure found in the per-thread memo); ms_per_call_changed_selection: a different selection every call",
+        "timed_calls": 10, "warmup_calls": 3, "value": mtr * N / sec, "unit": "samples/s", "replicas": Cn, "traces": mtr, "V": p4.V, "J": p4.J, "scales": pl4.S,
         "roofline": {"bound": "hbm", "algorithmic_bytes": alg, "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg / sec / 1e9 / HBM_PEAK_GBS,
                      "note": "every sample read once (the stack and all replicas share ONE pass) + K partials + outputs; the 110 transforms "

@@ -16,4 +16,4 @@ def golden():
     import numpy as np
 
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    return {k: np.load(os.path.join(here, k + ".npz"), allow_pickle=False) for k in ("frames", "cwt", "mains", "example32")}
+    return {k: np.load(os.path.join(here, k + ".npz"), allow_pickle=False) for k in ("frames", "cwt", "mains", "example32", "extra")}

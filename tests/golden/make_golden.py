@@ -252,5 +252,26 @@ def main():
     print("golden fixtures written to", HERE)
 
 
+def extra():
+    """Round 4 additions, in a file of their own (the fixtures above stay byte for byte what they were)."""
+    lib = ref_lib()
+    P = abi.default_params
+    X = abi.synth_traces(16, 2048, seed=3)
+    # leap-day quirk of JackknifePlans (ts_pws1f_lib.c:398-401): tm_yday == 365 (31 December of a leap year) gives bin == n,
+    # which no combination deletes -- traces 14 and 15 (31 Dec 2012, 31 Dec 2016) stay in EVERY replica
+    times = 1325376000 + 86400 * 23 * np.arange(16)          # 2012-01-01 + 23-day steps
+    times[14] = 1325376000 + 86400 * 365                      # 2012-12-31: day 366 of a leap year
+    times[15] = 1451606400 + 86400 * 365                      # 2016-12-31
+    ex = {"X": X}
+    for name, p in (("jk_leapday_n4_d1", P(Kmax=4, jackknife_n=4, jackknife_d=1)), ("jk_leapday_n6_d2", P(Kmax=3, unbiased=1, jackknife_n=6, jackknife_d=2))):
+        ex.update(main_case(lib, name, p, X, times=times))
+        ex[f"{name}/input"] = "X"
+    np.savez_compressed(os.path.join(HERE, "extra.npz"), **ex)
+    print("extra fixtures written")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        extra()
+    else:
+        main()

@@ -92,6 +92,28 @@ def test_no_cpu_fallback_without_device(lib):
     assert b"device" in lib.tspws_hip_last_error()
 
 
+def test_per_device_entry_and_cache_table(lib):
+    """tspws_main_on (additive: include/tspws_hip.h) names the device itself; the cache is a table with one slot and one lock per
+    device.  Without a GPU the table logic is what can run: out-of-range and absent devices fail with 5 before anything is cached,
+    an EMPTY ensemble returns 0 like the reference (ts_pws1f_lib.c:194) with or without a device, NULL arguments give -1, and
+    releasing an empty table is harmless."""
+    assert lib.tspws_main_on(0, None, None, None) == -1
+    X = abi.synth_traces(4, 256, seed=1)
+    fn = lambda dev: (lambda p, o, d: lib.tspws_main_on(dev, p, o, d))
+    for dev in (-1, 64, 1000):
+        assert abi.run_main(fn(dev), abi.default_params(), X)["rc"] == 5
+    if lib.tspws_hip_device_count() == 0:
+        assert abi.run_main(fn(0), abi.default_params(), X)["rc"] == 5
+        assert lib.tspws_main_cached_devices() == 0
+    # no traces: the reference returns 0 and leaves the outputs alone -- also where there is no device at all
+    r = abi.run_main(fn(0), abi.default_params(), X[:0].reshape(0, 256))
+    assert r["rc"] == 0 and not r["ls"].any()
+    r = abi.run_main(lib.tspws_main, abi.default_params(Kmax=3), X[:0].reshape(0, 256))
+    assert r["rc"] == 0
+    lib.tspws_main_release()
+    assert lib.tspws_main_cached_devices() == 0
+
+
 def test_shard_ranges_cover_everything():
     for mtr, w in [(10000, 8), (100000, 8), (17, 4), (3, 8), (1, 2)]:
         seen = []

@@ -174,3 +174,32 @@ def test_bench_single_gpu_line_has_the_contract_keys():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r["roofline"])
     assert r["cpu_baseline"]["rc"] == 0 and r["cpu_baseline"]["gpu_vs_cpu_relerr"]["tsPWS"] < 1e-5 and r["cpu_baseline"]["gpu_vs_cpu_relerr"]["ls"] < 1e-5
     assert r["step_ms_gpu"]["n"] == 5
+
+
+@pytest.mark.parametrize("bad,field", [(2, "dt"), (5, "dt"), (3, "beg")])
+def test_mismatching_sac_file_is_skipped_like_the_reference(tmp_path, bad, field):
+    """The reference's reader (ts_pws1f.c:680-708) "skips" a trace whose dt is off by more than 1 % (or whose b is off by more than
+    dt) by letting the next accepted trace overwrite its slot, and keeps the trace count at the FILE count (:708 updates a local):
+    a skipped trace in the middle leaves a trailing all-zero row in the stack, a skipped LAST trace stays in its slot and IS stacked.
+    The CLI reproduces that reader; the expected outputs are the oracle's tspws_main on the rows as the reference leaves them."""
+    n, mtr, dt, beg = 3000, 6, 0.5, -10.0
+    X = abi.synth_traces(mtr, n, seed=77)
+    names = []
+    for i in range(mtr):
+        p = tmp_path / f"s{i}.sac"
+        d, b = (dt * 1.05 if (i == bad and field == "dt") else dt), (beg + 3 * dt if (i == bad and field == "beg") else beg)
+        abi.write_sac(str(p), X[i], d, b, year=2011, jday=10 + i)
+        names.append(str(p))
+    (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
+    out = run_cli(tmp_path, "list.txt", "osac=skip", "TwoStage=3", "unbiased")
+    assert f"skipping trace {bad}" in out and ("different dt" if field == "dt" else "different beg") in out
+    rows = np.zeros((mtr, n), np.float32)          # calloc'd like the reference's sigall
+    k = 0
+    for i in range(mtr):
+        rows[k] = X[i]                              # read into slot i - nskip ...
+        if i != bad:
+            k += 1                                  # ... and kept only when accepted
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(Kmax=3, unbiased=1), rows, dt=dt, beg=beg)
+    ts, ls = abi.read_sac(tmp_path / "ts_pws_skip.sac"), abi.read_sac(tmp_path / "tl_skip.sac")
+    assert abi.relerr(ts["data"], want["tsPWS"]) < 2e-6 and abi.relerr(ls["data"], want["ls"]) < 2e-6
+    assert ts["f"][40] == float(mtr)                # user0 = the trace count the reference passes on: the file count

@@ -236,6 +236,13 @@ def test_tspws_main_golden(lib, golden):
         check_main(lib.tspws_main, g, name, TOL32)
 
 
+def test_leap_day_jackknife_goldens(lib, golden):
+    """31 December of a leap year (tm_yday == 365) lands in bin n and is never deleted (ts_pws1f_lib.c:398-401): reference goldens."""
+    g = golden["extra"]
+    for name in main_case_names(g):
+        check_main(lib.tspws_main, g, name, TOL32)
+
+
 def test_tspws_main_example_data(lib, golden):
     g = golden["example32"]
     for name in ("ex1", "ex2", "ex3", "ex_mexhat"):
@@ -504,6 +511,68 @@ def test_concurrent_callers_of_the_drop_in(lib):
             a = got[i][r]
             assert a is not None and a["rc"] == 0
             assert abi.relerr(a["ls"], w["ls"]) < TOL32 and abi.relerr(a["tsPWS"], w["tsPWS"]) < TOL32, (i, r)
+
+
+def test_per_device_slots_and_the_device_list_run_side_by_side(lib, monkeypatch):
+    """The drop-in's cache is a table with one slot and one lock per device plus one entry for the several-device call.  On a one-GPU
+    box two different cache entries of device 0 can be busy at once: thread A stacks through tspws_main_on(0, ...) (the device-0
+    slot), thread B through tspws_main under TSPWS_DEVICES=0,0 (the several-device entry: two virtual shards) -- concurrently, each
+    with its own frame, both right.  Afterwards the device-0 slot holds A's frame; tspws_main_release empties the table."""
+    import threading
+    lib.tspws_main_release()
+    assert lib.tspws_main_cached_devices() == 0
+    XA, XB = abi.synth_traces(24, 4096, seed=51), abi.synth_traces(31, 2048, seed=52)
+    kwA, kwB = dict(Kmax=6, unbiased=1), dict(type=-3, Kmax=4)
+    wantA = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kwA), XA)
+    wantB = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kwB), XB)
+    monkeypatch.setenv("TSPWS_DEVICES", "0,0")
+    got = {"A": [], "B": []}
+
+    def A():
+        for _ in range(6):
+            got["A"].append(abi.run_main(lambda p, o, d: lib.tspws_main_on(0, p, o, d), abi.default_params(**kwA), XA))
+
+    def B():
+        for _ in range(6):
+            got["B"].append(abi.run_main(lib.tspws_main, abi.default_params(**kwB), XB))
+
+    th = [threading.Thread(target=A), threading.Thread(target=B)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    try:
+        for r in got["A"]:
+            assert r["rc"] == 0 and abi.relerr(r["tsPWS"], wantA["tsPWS"]) < TOL32 and abi.relerr(r["ls"], wantA["ls"]) < TOL32
+        for r in got["B"]:
+            assert r["rc"] == 0 and abi.relerr(r["tsPWS"], wantB["tsPWS"]) < TOL32 and abi.relerr(r["ls"], wantB["ls"]) < TOL32
+        assert lib.tspws_main_cached_devices() == 1          # the device-0 slot (A's frame); B used the several-device entry
+        # the environment names the device of tspws_main; tspws_main_on ignores it
+        monkeypatch.setenv("TSPWS_DEVICES", "0")
+        r = abi.run_main(lib.tspws_main, abi.default_params(**kwA), XA)
+        assert r["rc"] == 0 and abi.relerr(r["tsPWS"], wantA["tsPWS"]) < TOL32
+        monkeypatch.setenv("TSPWS_DEVICES", "7")            # no such device on this box
+        assert abi.run_main(lib.tspws_main, abi.default_params(**kwA), XA)["rc"] == 5
+        assert abi.run_main(lambda p, o, d: lib.tspws_main_on(0, p, o, d), abi.default_params(**kwA), XA)["rc"] == 0
+    finally:
+        lib.tspws_main_release()
+    assert lib.tspws_main_cached_devices() == 0
+
+
+def test_local_backend_is_refused_for_distinct_devices(lib, monkeypatch):
+    """TSPWS_COMM=local is the one-GPU test vehicle: with distinct devices in the list it must not stand in for RCCL.  A one-GPU box
+    can only show the refusal of a list that is not all one device through the argument check (device 1 does not exist here: 5),
+    and that repeated-device lists still select it."""
+    h = C.c_void_p()
+    arr = (C.c_int * 2)(0, 0)
+    assert lib.tspws_hip_comm_create(C.byref(h), 2, arr) == 0
+    assert lib.tspws_hip_comm_backend(h).decode() == "local"
+    lib.tspws_hip_comm_destroy(h)
+    if lib.tspws_hip_device_count() >= 2:
+        monkeypatch.setenv("TSPWS_COMM", "local")
+        arr = (C.c_int * 2)(0, 1)
+        assert lib.tspws_hip_comm_create(C.byref(h), 2, arr) == -1
+        assert b"local backend" in lib.tspws_hip_last_error()
 
 
 def test_seeded_subsampling_in_a_fresh_process():

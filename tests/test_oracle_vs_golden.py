@@ -1,5 +1,7 @@
 """Pin the oracle (oracle/tspws_oracle.c) against the golden vectors produced by
 the reference itself (tests/golden/make_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -171,3 +173,52 @@ def test_empty_frame_returns_4_like_the_reference():
         r = abi.run_main(ref.tspws_main, p, X)
         assert r["rc"] == 4 and r["params"].J == 0
         np.testing.assert_array_equal(b["sigall"], r["sigall"])
+
+
+def test_leap_day_jackknife_goldens(golden):
+    """JackknifePlans' leap-day quirk (ts_pws1f_lib.c:398-401): tm_yday == 365 -- 31 December of a leap year -- falls into bin n,
+    which no combination deletes, so such a trace is part of EVERY replica.  Reference goldens with two such traces."""
+    g = golden["extra"]
+    fn = abi.oracle().orc_tspws_main
+    for name in main_case_names(g):
+        check_main(fn, g, name, 2e-7)
+    sizes = g["jk_leapday_n4_d1/jk_mtr"]
+    assert sizes.min() >= 12 and sizes.sum() == 3 * 14 + 2 * 4  # 14 ordinary traces, each deleted from exactly one of the 4 replicas; the 2 leap-day traces from none
+
+
+EXAMPLES = "/root/reference/examples/ECH.00Z.CAN.00Z_500days"
+
+
+@pytest.mark.skipif(not os.path.isdir(EXAMPLES), reason="the reference's 499 shipped traces exist in the build container only")
+def test_cfg1_full_example_known_answers():
+    """BASELINE configs[0] at its REAL size: the 499 shipped daily correlations (`ls -1` order, 16 501 samples) through the oracle,
+    against the known answers SURVEY.md section 8c records from the reference build (%.9g); the committed fixture holds only the
+    first 32 files.  Runs where /root/reference exists (never on the GPU box)."""
+    files = sorted(f for f in os.listdir(EXAMPLES) if f.endswith(".sac"))
+    assert len(files) == 499
+    tr = [abi.read_sac(os.path.join(EXAMPLES, f)) for f in files]
+    dt, beg = float(tr[0]["f"][0]), float(tr[0]["f"][5])
+    X = np.stack([t["data"] for t in tr]).astype(np.float32)
+    assert X.shape == (499, 16501) and dt == 4.0 and beg == -33000.0
+    P = abi.default_params
+    fn = abi.oracle().orc_tspws_main_mt   # (bit-identical to the serial restatement; falls back to it for fold / rm)
+    known = [
+        (P(), dict(V=4, J=11), 12.3319202, 0.117945968, -0.000774812186, -1.02215949e-06),
+        (P(lrm=1, fold=1, fmin=0.004, J=3), dict(J=3), 9.10524467, 0.166975489, -0.000304688438, 2.20529478e-06),
+        (P(lrm=1, fold=1, fmin=0.004, J=3, Kmax=10, unbiased=1), dict(J=3), None, 2.17871652, None, -6.55123658e-05),
+        (P(Kmax=10, unbiased=1), dict(V=4, J=11), None, 2.23467754, None, -5.29589925e-05),
+        (P(type=-3), dict(V=2, J=10), 12.2323905, 0.1037363, None, None),
+    ]
+    for p, res, sum_ls, sum_ts, ls_mid, ts_mid in known:
+        r = abi.run_main(fn, p, X, dt=dt, beg=beg)
+        assert r["rc"] == 0
+        for k, v in res.items():
+            assert getattr(r["params"], k) == v
+        if sum_ls is not None:
+            assert float(np.abs(r["ls"].astype(np.float64)).sum()) == pytest.approx(sum_ls, rel=2e-6)
+        assert float(np.abs(r["tsPWS"].astype(np.float64)).sum()) == pytest.approx(sum_ts, rel=2e-6)
+        if ls_mid is not None:
+            assert float(r["ls"][8250]) == pytest.approx(ls_mid, rel=2e-6)
+        if ts_mid is not None:
+            assert float(r["tsPWS"][8250]) == pytest.approx(ts_mid, rel=2e-5)
+    assert known[1][1]["J"] == 3 and abs(abi.resolve(known[1][0], 16501, dt).s0 - 7.890778) < 1e-6

@@ -474,7 +474,7 @@ extern "C" int tspws_hip_accumulate(tspws_hip_plan *p, const double *d_Y, size_t
 // launches k_accumulate_parts for `nb` transformed traces; fz = what the forward launch left behind (may be NULL / not applied)
 void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb, double2 *ST, double2 *PS, int zero_first, const FuseOut *fz,
                              unsigned nslices, hipStream_t st, unsigned nbatch, size_t y_part, size_t y_stack, const TlTable *tl, const WeightArgs *wa,
-                             ScaleRange rg)
+                             ScaleRange rg, size_t trace_stride)
 {
 	const WeightArgs w0;
 	const bool on = fz && fz->applied;
@@ -484,7 +484,7 @@ void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb
 	const unsigned a0 = tl ? 0u : lr.acc0, a1 = tl ? tl->acc2_blocks : lr.acc1;
 	if (a1 <= a0) return;
 	auto kern = (wa && wa->OUTP) ? k_accumulate_parts<true> : k_accumulate_parts<false>;
-	hipLaunchKernelGGL(kern, dim3(a1 - a0, nbatch), dim3(256), 0, st, part, tl ? tl->npart : p->npart,
+	hipLaunchKernelGGL(kern, dim3(a1 - a0, nbatch), dim3(256), 0, st, part, trace_stride ? trace_stride : (tl ? tl->npart : p->npart),
 	                   (const ScaleDesc *)(tl ? tl->d_sc : p->d_sc), p->S, nb, ST, PS, zero_first,
 	                   on ? (direct ? 1 : 2) : 0, on ? (const double2 *)fz->accST : nullptr, on ? (const double2 *)fz->accPS : nullptr,
 	                   on ? fz->stride : (size_t)0, nslices, y_part, y_stack, tl ? 1 : 0, wa ? *wa : w0, a0);

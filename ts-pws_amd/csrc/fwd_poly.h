@@ -426,6 +426,10 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 	// blockIdx.y = independent stack (jackknife replica): its ntr transformed traces start y_part further in `part`, its
 	// ST / PS y_stack further (the fused forward kernel wrote the fuse_ok scales there directly: fused == 1)
 	part += (size_t)blockIdx.y * y_part; ST += (size_t)blockIdx.y * y_stack; PS += (size_t)blockIdx.y * y_stack;
+	if (wa.Mv) wa.M = wa.Mv[blockIdx.y]; // (replicas side by side: each with its own trace count and weighted-coefficient set)
+	// stacks that are only needed as weighted coefficients are not written (few-trace branches below; zero_first callers only)
+	const bool planes = wa.planes_batch == -1 || (int)blockIdx.y == wa.planes_batch;
+	if (wa.OUT) wa.OUT += (size_t)blockIdx.y * wa.out_stride;
 	unsigned lo = 0, hi = S;
 	while (hi - lo > 1) {
 		const unsigned mid = (lo + hi) >> 1;
@@ -520,7 +524,7 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 			}
 		}
 		if (lane == 0) {
-			ST[i] = st; PS[i] = ps;
+			if (planes) { ST[i] = st; PS[i] = ps; }
 			if (wa.OUT) wa.OUT[i] = weight_value(st, ps, wa.mode, wa.K, wa.M, wa.wu);
 		}
 		return;
@@ -532,15 +536,23 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 	const double2 *p0 = part + sc[lo].part_off + k;
 	double2 st = make_double2(0, 0), ps = make_double2(0, 0);
 	if (!zero_first) { st = ST[i]; ps = PS[i]; }
-	for (unsigned b = 0; b < ntr; b++) {
-		const double2 v = p0[(size_t)b * npart];
-		st.x += v.x; st.y += v.y;
-		add_unit_phasor(ps, v);
-		if (PREFIX && wa.OUTP) {
-			const unsigned cnt = wa.k0 + b + 1u;
-			wa.OUTP[(size_t)b * wa.outp_stride + i] = weight_value(st, ps, cnt == 1 ? wa.mode1 : wa.mode, (double)cnt, (double)cnt, wa.wu);
+	for (unsigned b0 = 0; b0 < ntr; b0 += 4) { // four traces' loads in flight (independent addresses); the additions keep the trace order
+		double2 v[4];
+#pragma unroll
+		for (int j = 0; j < 4; j++) v[j] = p0[(size_t)(b0 + (unsigned)j < ntr ? b0 + (unsigned)j : ntr - 1u) * npart];
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const unsigned b = b0 + (unsigned)j;
+			if (b < ntr) {
+				st.x += v[j].x; st.y += v[j].y;
+				add_unit_phasor(ps, v[j]);
+				if (PREFIX && wa.OUTP) {
+					const unsigned cnt = wa.k0 + b + 1u;
+					wa.OUTP[(size_t)b * wa.outp_stride + i] = weight_value(st, ps, cnt == 1 ? wa.mode1 : wa.mode, (double)cnt, (double)cnt, wa.wu);
+				}
+			}
 		}
 	}
-	ST[i] = st; PS[i] = ps;
+	if (planes) { ST[i] = st; PS[i] = ps; }
 	if (wa.OUT) wa.OUT[i] = weight_value(st, ps, wa.mode, wa.K, wa.M, wa.wu);
 }

@@ -148,37 +148,40 @@ static int read_data(t_data *in, const char *filein, int bin, int verbose)
 		printf("tspws_main: Out of memory when reading %s (mtr = %u, npts = %d)\n", filein, nfiles, npts);
 		return 4;
 	}
+	/* The reference's reader, literally (ts_pws1f.c:680-708): trace i is read into slot i - nskip; a trace whose dt differs by more
+	 * than 1 % or whose b differs by more than dt is "skipped" by letting the next accepted trace overwrite its slot -- the rows are
+	 * not cleared in between (a shorter trace keeps the tail of what its slot held), a skipped LAST trace stays in its slot, and the
+	 * trace count handed to tspws_main stays the FILE count (:708 updates a local only), so every skipped trace in the middle
+	 * leaves one trailing all-zero row in the stack.  Reproduced as is: the outputs are the reference's. */
 	const float dt1 = hdr->dt, beg1 = hdr->beg;
-	unsigned kept = 0;
+	unsigned nskip = 0;
 	for (unsigned i = 0; i < nfiles; i++) {
-		float *dst = in->sigall + (size_t)kept * max;
+		float *dst = in->sigall + (size_t)(i - nskip) * max;
 		int n = 0;
-		memset(dst, 0, max * sizeof(float));
 		rc = sac_read(files[i], &h, dst, npts, &n);
 		if (rc) { printf("tspws_main: Error reading %s file (nerr=%d)\n", files[i], rc); return -2; }
 		if (n > npts) printf("tspws_main: WARNING: using only %d samples on %u trace\n", npts, i);
 		else if (n < npts) printf("tspws_main: WARNING: trace %u has only %d samples\n", i, n);
-		if (fabs(h.f[SAC_F_DELTA] - dt1) > dt1 * 0.01) { /* :695-706 */
+		if (fabs(h.f[SAC_F_DELTA] - dt1) > dt1 * 0.01) { /* :695-700 */
 			printf("tspws_main: WARNING: trace %u has a different dt !\ntspws_main: WARNING: skipping trace %u\n", i, i);
+			nskip++;
 			continue;
 		}
-		if (fabs(beg1 - h.f[SAC_F_B]) > dt1) {
+		if (fabs(beg1 - h.f[SAC_F_B]) > dt1) { /* :701-706 */
 			printf("tspws_main: WARNING: trace %u has a different beg !\ntspws_main: WARNING: skipping trace %u\n", i, i);
+			nskip++;
 			continue;
 		}
-		in->time[kept] = sac_reference_time(&h);
-		kept++;
+		in->time[i - nskip] = sac_reference_time(&h); /* (addition: the reference leaves time[] zero for SAC lists) */
 	}
-	/* The reference keeps hdr->mtr at the file count even when traces were skipped (:708), which makes it
-	 * stack trailing zero rows; this front-end stacks exactly the traces it kept. */
-	hdr->mtr = kept;
+	const unsigned kept = nfiles - nskip;
 	for (unsigned i = 0; i < nfiles; i++) free(files[i]);
 	free(files);
 	for (unsigned i = 0; i < kept; i++) {
 		const float *x = in->sigall + (size_t)i * max;
 		size_t n = 0;
 		while (n < max && x[n] == 0.f) n++;
-		if (n == max) printf("tspws_main: %s, trace %u of %u is ZERO\n", filein, i, kept);
+		if (n == max) printf("tspws_main: %s, trace %u of %u is ZERO\n", filein, i, kept); /* (the reference checks the kept traces only, :713-718) */
 	}
 	return 0;
 }

@@ -28,6 +28,7 @@ int tspws_scratch(tspws_hip_plan *p, int slot, size_t bytes, void **out)
 			else (void)hipFree(p->scr[slot]);
 		}
 		if (slot == SCR_TAB) p->ck_dev = false; // the device chunk table lived in the old block
+		if (slot == SCR_TAB || slot == SCR_JKTAB) p->jk_gen = 0; // ... and so did the masked replicas' tables
 		p->scr[slot] = fresh;
 		p->scr_bytes[slot] = bytes;
 	}
@@ -224,6 +225,8 @@ extern "C" void tspws_hip_plan_destroy(tspws_hip_plan *p)
 	if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
 	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
 	if (p->side) (void)hipStreamDestroy(p->side);
+	if (p->xf) (void)hipStreamDestroy(p->xf);
+	for (hipEvent_t e : p->stage_ev) (void)hipEventDestroy(e);
 	if (p->d_oc) (void)hipFree(p->d_oc);
 	for (TlTable &T : p->tl) { if (T.d_sc) (void)hipFree(T.d_sc); if (T.d_items) (void)hipFree(T.d_items); }
 	if (p->d_sc) (void)hipFree(p->d_sc);

@@ -1,6 +1,7 @@
 // resample.hip -- jackknife (two-stage), random subsampling, convergence curves.
 // Reference citations are relative to /root/reference/src.
 #include "tspws_internal.h"
+#include <atomic>
 #include <string>
 #include <unordered_map>
 
@@ -51,15 +52,16 @@ __global__ void __launch_bounds__(256) k_combine_classes(const double *__restric
 }
 
 // replica linear stack in the time domain, :799-811: (sum_g P[g]) * (1/K)
+// rows of replica c: P + c * y_rep + g * y_grp (replica-major rows: y_rep = Kmax N, y_grp = N; group-major: y_rep = N, y_grp = W N)
 __global__ void __launch_bounds__(256) k_jk_linear(const double *__restrict__ P, unsigned Kmax, size_t N, const double *__restrict__ Mv,
-                                                   float *__restrict__ out)
+                                                   float *__restrict__ out, size_t y_rep, size_t y_grp)
 {
 	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (n >= N) return;
-	P += (size_t)blockIdx.y * Kmax * N; out += (size_t)blockIdx.y * N; // blockIdx.y = replica
+	P += (size_t)blockIdx.y * y_rep; out += (size_t)blockIdx.y * N; // blockIdx.y = replica
 	const double invK = 1. / Mv[blockIdx.y];
 	double acc = P[n];
-	for (unsigned g = 1; g < Kmax; g++) acc += P[(size_t)g * N + n];
+	for (unsigned g = 1; g < Kmax; g++) acc += P[(size_t)g * y_grp + n];
 	out[n] = (float)(acc * invK);
 }
 
@@ -186,6 +188,7 @@ static int combine_classes(tspws_hip_plan *pl, ClassSums &cs, unsigned col0, uns
 		}
 	tab[nrow] = (unsigned)(tab.size() - (nrow + 1));
 	if ((cs.tab_used + tab.size()) * sizeof(unsigned) > pl->scr_bytes[SCR_JKTAB]) return fail(TSPWS_E_ARG, "combine_classes: table block too small");
+	pl->jk_gen = 0; // (the table block no longer holds a pipelined call's tables)
 	unsigned *d_rp = (unsigned *)pl->scr[SCR_JKTAB] + cs.tab_used, *d_cols = d_rp + nrow + 1;
 	cs.tab_used += tab.size();
 	HIP_TRY(hipMemcpyAsync(d_rp, tab.data(), tab.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
@@ -251,12 +254,244 @@ static int finish_replicas(tspws_hip_plan *pl, const t_tsPWS *p, double *d_P, co
 		tspws_weight_batched(pl, (double2 *)OUT, (const double2 *)STr, (const double2 *)STr + nc, tspws_weight_mode(p->wu, p->unbiased, KM), (double)KM, p->wu,
 		                     (const double *)(d_Mv + c0), nr, nc, 2 * nc, st);
 		hipLaunchKernelGGL(k_jk_linear, dim3((unsigned)((N + 255) / 256), nr), dim3(256), 0, st, d_P + (size_t)c0 * KM * N, KM, N, (const double *)(d_Mv + c0),
-		                   d_ls_out + (size_t)c0 * N);
+		                   d_ls_out + (size_t)c0 * N, (size_t)KM * N, N);
 		if ((rc = tspws_hip_inverse(pl, OUT, nr, xr, s))) return rc;
 		tspws_epilogue_rows(d_ts_out + (size_t)c0 * N, xr, N, nr, st);
 	}
 	HIP_TRY(hipGetLastError());
 	return cs_done(st); // host tables above go out of scope
+}
+
+// ------------------------------------------------------------------------------------------
+// The masked replicas as a pipeline (round 4).  Replica groups are contiguous in selected-trace order (ts_pws1f_lib.c:758-772,
+// g = floor(k Kmax / K)), so once the traces up to the end of group g of EVERY column (replica / plain stack) have been
+// streamed, row g of all columns is final: its forward transforms (the FP64-bound half of the call: 110 transforms at cfg4)
+// run on a second stream while the next groups are streamed (the HBM-bound half).
+//   stage s = groups [s gps, (s + 1) gps) of every column;
+//   class  -> stage = (smallest group index in its signature) / gps: all traces of the class lie before the end of that group
+//             in the column that holds it, i.e. a stage's rows only need classes of stages <= s;
+//   rows   are GROUP-major, row = g W + column (W = C [+ 1 for the plain stack]), so a stage's rows are one run: the
+//             forward launch of a stage transforms its gps W rows into per-trace coefficients (no in-register stacks: a
+//             stage holds one or two traces of each stack), and ONE accumulation at the end adds the Kmax transformed rows of
+//             every stack in group order -- the reference's order (:897-904) -- and writes the weighted coefficients.
+// Everything that depends on the selection only (classes, chunk table, combine lists, trace counts) is built once per
+// selection (per host thread, keyed by content) AND stays on the device while the plan's table blocks are not reused
+// (plan->jk_gen): a repeated selection issues no host-to-device copy at all.
+// ------------------------------------------------------------------------------------------
+struct MaskedPlan {
+	// key
+	size_t mtr = 0;
+	unsigned C = 0, KM = 0, clen = 0, gps = 0;
+	bool with_main = false, valid = false;
+	std::vector<char> sel;
+	// products
+	unsigned long long gen = 0;
+	unsigned W = 0, ncls = 0, nstage = 0;
+	std::vector<size_t> Kc;
+	std::vector<Chunk> chunks;          // sorted by class, classes numbered in stage order
+	std::vector<unsigned> row_first;    // per class: first chunk
+	std::vector<unsigned> cls0;         // per stage: first class (nstage + 1)
+	std::vector<unsigned> tab;          // combine lists: [KM W + 1] row pointers | class ids; row = g W + column
+	std::vector<double> Mv;             // trace count per column (replicas: selected traces; plain stack: mtr)
+};
+
+static unsigned long long next_masked_gen()
+{
+	static std::atomic<unsigned long long> g{0};
+	return ++g;
+}
+
+static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, unsigned C, unsigned KM, bool with_main, unsigned gps)
+{
+	static thread_local MaskedPlan mp;
+	const unsigned clen = tspws_chunk_len_for(N, std::max<size_t>(mtr, 1));
+	if (mp.valid && mp.mtr == mtr && mp.C == C && mp.KM == KM && mp.clen == clen && mp.gps == gps && mp.with_main == with_main &&
+	    mp.sel.size() == (size_t)C * mtr && !memcmp(mp.sel.data(), h_sel, (size_t)C * mtr)) return mp;
+	mp.valid = false;
+	const unsigned W = C + (with_main ? 1u : 0u);
+	mp.Kc.assign(C, 0);
+	std::vector<unsigned> sig((size_t)mtr * W);
+	for (unsigned c = 0; c < C; c++) {
+		const char *row = h_sel + (size_t)c * mtr;
+		size_t n = 0;
+		for (size_t i = 0; i < mtr; i++) n += row[i] == 1;
+		mp.Kc[c] = n;
+		const size_t Kc = std::max<size_t>(n, 1);
+		size_t k = 0;
+		// (the reference's floor((double)(k * KM) / (double)Kc), :766, is the integer quotient: see class_sums)
+		for (size_t i = 0; i < mtr; i++) {
+			if (row[i] == 1) { sig[i * W + c] = (unsigned)((k * KM) / Kc); k++; }
+			else sig[i * W + c] = SIG_DELETED;
+		}
+	}
+	if (with_main) for (size_t i = 0; i < mtr; i++) sig[i * W + C] = (unsigned)std::min<size_t>((i * KM) / mtr, KM - 1);
+	// classes in order of first appearance, with their runs of traces
+	std::vector<std::vector<unsigned>> csig;
+	std::vector<std::vector<Chunk>> cls_chunks;
+	std::unordered_map<std::string, size_t> cls_of;
+	for (size_t i = 0; i < mtr;) {
+		size_t j = i + 1;
+		while (j < mtr && !memcmp(&sig[i * W], &sig[j * W], W * sizeof(unsigned))) j++;
+		const std::string key((const char *)&sig[i * W], W * sizeof(unsigned));
+		auto it = cls_of.find(key);
+		size_t id;
+		if (it == cls_of.end()) {
+			id = csig.size();
+			cls_of.emplace(key, id);
+			csig.emplace_back(sig.begin() + i * W, sig.begin() + (i + 1) * W);
+			cls_chunks.emplace_back();
+		} else id = it->second;
+		for (size_t t = i; t < j; t += clen) {
+			Chunk c; c.t0 = t; c.count = (unsigned)std::min<size_t>(clen, j - t); c.row = 0;
+			cls_chunks[id].push_back(c);
+		}
+		i = j;
+	}
+	// stage of a class; classes deleted from every column are never streamed
+	const unsigned nstage = (KM + gps - 1) / gps;
+	std::vector<unsigned> stage(csig.size());
+	std::vector<std::vector<unsigned>> by_stage(nstage);
+	for (size_t id = 0; id < csig.size(); id++) {
+		unsigned g = SIG_DELETED;
+		for (unsigned c = 0; c < W; c++) g = std::min(g, csig[id][c]);
+		if (g == SIG_DELETED) { stage[id] = ~0u; continue; }
+		stage[id] = std::min(g, KM - 1) / gps;
+		by_stage[stage[id]].push_back((unsigned)id);
+	}
+	std::vector<unsigned> new_id(csig.size(), ~0u);
+	mp.chunks.clear(); mp.row_first.clear(); mp.cls0.assign(nstage + 1, 0);
+	unsigned n = 0;
+	for (unsigned sgi = 0; sgi < nstage; sgi++) {
+		mp.cls0[sgi] = n;
+		for (unsigned id : by_stage[sgi]) {
+			new_id[id] = n;
+			mp.row_first.push_back((unsigned)mp.chunks.size());
+			for (Chunk c : cls_chunks[id]) { c.row = n; mp.chunks.push_back(c); }
+			n++;
+		}
+	}
+	mp.cls0[nstage] = n;
+	mp.row_first.push_back((unsigned)mp.chunks.size());
+	mp.ncls = n;
+	// combine lists, rows group-major
+	const unsigned nrow = KM * W;
+	std::vector<std::vector<unsigned>> lists(nrow);
+	for (size_t id = 0; id < csig.size(); id++) {
+		if (new_id[id] == ~0u) continue;
+		for (unsigned c = 0; c < W; c++) if (csig[id][c] != SIG_DELETED) lists[(size_t)std::min(csig[id][c], KM - 1) * W + c].push_back(new_id[id]);
+	}
+	mp.tab.assign((size_t)nrow + 1, 0);
+	for (unsigned r = 0; r < nrow; r++) {
+		mp.tab[r] = (unsigned)(mp.tab.size() - (nrow + 1));
+		std::sort(lists[r].begin(), lists[r].end()); // class order = trace order of first appearance within a stage: a fixed, data-independent order
+		mp.tab.insert(mp.tab.end(), lists[r].begin(), lists[r].end());
+	}
+	mp.tab[nrow] = (unsigned)(mp.tab.size() - (nrow + 1));
+	mp.Mv.assign(W, 0.0);
+	for (unsigned c = 0; c < C; c++) mp.Mv[c] = (double)mp.Kc[c];
+	if (with_main) mp.Mv[C] = (double)(unsigned)mtr;
+	mp.mtr = mtr; mp.C = C; mp.KM = KM; mp.clen = clen; mp.gps = gps; mp.with_main = with_main; mp.W = W; mp.nstage = nstage;
+	mp.sel.assign(h_sel, h_sel + (size_t)C * mtr);
+	mp.gen = next_masked_gen();
+	mp.valid = true;
+	return mp;
+}
+
+static unsigned masked_walk()
+{
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("TSPWS_JK_WALK"); v = e ? std::max(0, atoi(e)) : 256; }
+	return (unsigned)v;
+}
+
+static unsigned masked_gps()
+{
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("TSPWS_JK_GPS"); v = e ? std::max(1, atoi(e)) : 1; }
+	return (unsigned)v;
+}
+
+// 1: the pipelined call is possible for this plan / shape (per-trace coefficients of all KM W rows fit the scratch budget)
+static bool masked_pipeline_ok(const tspws_hip_plan *pl, unsigned KM, unsigned W)
+{
+	static int off = -1;
+	if (off < 0) { const char *e = getenv("TSPWS_JK_PIPELINE"); off = (e && *e == '0') ? 1 : 0; }
+	if (off || tspws_generic_forward()) return false;
+	return (size_t)KM * W * pl->npart * sizeof(double2) <= tspws_part_budget_bytes();
+}
+
+static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, const char *h_sel, unsigned C,
+                                      float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s, bool with_stack, float *d_ls, float *d_ts)
+{
+	hipStream_t st = S_(s);
+	const unsigned KM = p->Kmax;
+	const size_t N = pl->N, nc = pl->ncoef;
+	const MaskedPlan &mp = masked_plan(N, mtr, h_sel, C, KM, with_stack, masked_gps());
+	const unsigned W = mp.W, nrow = KM * W;
+	int rc;
+	void *v;
+	// device blocks: class rows, group-major partial-stack rows, per-trace coefficients, stacks + weighted sets + reconstructions
+	if ((rc = scratch(pl, SCR_CLS, std::max<size_t>((size_t)mp.ncls * N, 1) * sizeof(double), &v))) return rc;
+	double *d_cls = (double *)v;
+	if ((rc = scratch(pl, SCR_JKP, ((size_t)nrow * N + W) * sizeof(double), &v))) return rc;
+	double *d_rows = (double *)v;
+	if ((rc = scratch(pl, SCR_PART, (size_t)nrow * pl->npart * sizeof(double2), &v))) return rc;
+	double2 *part = (double2 *)v;
+	const unsigned nrec = W + (with_stack ? 1u : 0u); // reconstructions: OUT of every column (+ ST of the plain stack)
+	if ((rc = scratch(pl, SCR_JKOUT, ((size_t)(nrec + 2 * W) * 2 * nc + (size_t)nrec * N) * sizeof(double), &v))) return rc;
+	double *OUT = (double *)v, *STr = OUT + (size_t)nrec * 2 * nc, *xr = STr + (size_t)W * 4 * nc;
+	const size_t tab_bytes = mp.tab.size() * sizeof(unsigned), tab_al = (tab_bytes + 7) & ~(size_t)7;
+	if ((rc = scratch(pl, SCR_JKTAB, tab_al + W * sizeof(double), &v))) return rc;
+	unsigned *d_rp = (unsigned *)v, *d_cols = d_rp + nrow + 1;
+	double *d_Mv = (double *)((char *)v + tab_al);
+	if ((rc = scratch(pl, SCR_CHUNK, 16, &v))) return rc; // (grown by the launches)
+	if (!pl->xf) {
+		int lo = 0, hi = 0;
+		HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi)); // (lo = least urgent)
+		const char *e = getenv("TSPWS_JK_XFPRIO");
+		HIP_TRY(hipStreamCreateWithPriority(&pl->xf, hipStreamNonBlocking, e ? (atoi(e) > 0 ? hi : lo) : 0));
+	}
+	while (pl->stage_ev.size() < mp.nstage + 1) {
+		hipEvent_t e;
+		HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+		pl->stage_ev.push_back(e);
+	}
+	// tables: only when the blocks do not hold this selection's already
+	if (pl->jk_gen != mp.gen || !pl->scr[SCR_TAB]) {
+		if ((rc = tspws_chunks_upload(pl, mp.chunks, mp.row_first, mp.ncls, st, false))) return rc; // (resets jk_gen)
+		HIP_TRY(hipMemcpyAsync(d_rp, mp.tab.data(), tab_bytes, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(d_Mv, mp.Mv.data(), W * sizeof(double), hipMemcpyHostToDevice, st));
+		pl->jk_gen = mp.gen;
+	}
+	const unsigned nbx = (unsigned)((N + 255) / 256);
+	for (unsigned sg = 0; sg < mp.nstage; sg++) {
+		// HBM-bound half of the stage on the caller's stream: class sums of the stage's traces, then its rows
+		if ((rc = tspws_chunks_launch(pl, d_x, ld, N, mp.chunks, mp.row_first, mp.ncls, d_cls, N, st, mp.cls0[sg], mp.cls0[sg + 1], masked_walk()))) return rc;
+		const unsigned r0 = sg * mp.gps * W, r1 = std::min(KM, (sg + 1) * mp.gps) * W;
+		hipLaunchKernelGGL(k_combine_classes, dim3(nbx, r1 - r0), dim3(256), 0, st, (const double *)d_cls, N, (const unsigned *)(d_rp + r0), (const unsigned *)d_cols,
+		                   d_rows + (size_t)r0 * N, N);
+		HIP_TRY(hipEventRecord(pl->stage_ev[sg], st));
+		// FP64-bound half on the second stream: forward transforms of the stage's rows into per-trace coefficients
+		HIP_TRY(hipStreamWaitEvent(pl->xf, pl->stage_ev[sg], 0));
+		if ((rc = tspws_forward_parts_f64(pl, d_rows + (size_t)r0 * N, r1 - r0, N, part + (size_t)r0 * pl->npart, pl->xf, nullptr, ScaleRange()))) return rc;
+	}
+	HIP_TRY(hipEventRecord(pl->stage_ev[mp.nstage], pl->xf));
+	// time-domain linear stacks of the replicas (:799-811) while the last transforms run
+	if (C) hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, N, (size_t)W * N);
+	HIP_TRY(hipStreamWaitEvent(st, pl->stage_ev[mp.nstage], 0));
+	// stacks of every column from its KM transformed rows, in group order, weights by the same launch (K = KM, M = the column's traces)
+	WeightArgs wa;
+	wa.OUT = (double2 *)OUT; wa.out_stride = nc; wa.mode = tspws_weight_mode(p->wu, p->unbiased, KM); wa.K = (double)KM; wa.wu = p->wu; wa.Mv = d_Mv;
+	wa.planes_batch = with_stack ? (int)C : -2; // only the plain stack's ST is reconstructed (ls); the replicas need their weighted coefficients only
+	tspws_launch_accumulate(pl, (const double2 *)part, KM, (double2 *)STr, (double2 *)STr + nc, 1, nullptr, 0, st, W, pl->npart, 2 * nc, nullptr, &wa, ScaleRange(),
+	                        (size_t)W * pl->npart);
+	if (with_stack) HIP_TRY(hipMemcpyAsync(OUT + (size_t)W * 2 * nc, STr + (size_t)C * 4 * nc, nc * sizeof(double2), hipMemcpyDeviceToDevice, st)); // ST of the plain stack: the last set
+	if ((rc = tspws_hip_inverse(pl, OUT, nrec, xr, s))) return rc;
+	if (C) tspws_epilogue_rows(d_ts_out, xr, N, C, st);
+	if (with_stack && (rc = tspws_hip_epilogue(d_ls, d_ts, xr + (size_t)(C + 1) * N, xr + (size_t)C * N, N, (unsigned)mtr, s))) return rc;
+	for (unsigned c = 0; c < C; c++) h_mtr_out[c] = (unsigned)mp.Kc[c];
+	HIP_TRY(hipGetLastError());
+	return cs_done(st); // (the memo's tables may still be on their way; the caller reads h_mtr_out and, usually, the outputs next)
 }
 
 // All C masked two-stage replicas from ONE pass over the traces (shared by the jackknife and the two-stage
@@ -269,6 +504,11 @@ static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d
 	hipStream_t st = S_(s);
 	const unsigned KM = p->Kmax;
 	int rc;
+	if (masked_pipeline_ok(pl, KM, C + (with_stack ? 1u : 0u))) {
+		rc = masked_two_stage_pipelined(pl, p, d_x, ld, mtr, h_sel, C, d_ls_out, d_ts_out, h_mtr_out, s, with_stack, d_ls, d_ts);
+		if (rc) { (void)hipStreamSynchronize(pl->xf); (void)cs_done(st); }
+		return rc;
+	}
 	ClassSums cs;
 	if ((rc = class_sums(pl, cs, KM, d_x, ld, mtr, h_sel, C, with_stack, st, 0, mtr))) { (void)cs_done(st); return rc; }
 	double *d_P;

@@ -96,9 +96,14 @@ __global__ void __launch_bounds__(256) k_partial(const float *__restrict__ x, si
 #pragma unroll
 			for (int j = 0; j < 8; j++) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
 		}
-		for (; t < ck.count; t++) {
-			const v4f v = __builtin_nontemporal_load((const v4f *)(src + (size_t)t * ld));
-			a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+		if (t < ck.count) { // the remainder as ONE batch (rows past the end re-read the last row and are not added): one round trip, not up to seven
+			const unsigned nv = ck.count - t, last = ck.count - 1u;
+			v4f v[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)(t + (unsigned)j < ck.count ? t + (unsigned)j : last) * ld));
+#pragma unroll
+			for (int j = 0; j < 8; j++)
+				if ((unsigned)j < nv) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
 		}
 	} else {
 		const unsigned rem = (N - col) < 4 ? (unsigned)(N - col) : 4u;
@@ -116,6 +121,101 @@ __global__ void __launch_bounds__(256) k_partial(const float *__restrict__ x, si
 		*(double2 *)(dst + 2) = make_double2(a2, a3);
 	} else {
 		const unsigned rem = (N - col) < 4 ? (unsigned)(N - col) : 4u;
+		dst[0] = a0;
+		if (rem > 1) dst[1] = a1;
+		if (rem > 2) dst[2] = a2;
+		if (rem > 3) dst[3] = a3;
+	}
+}
+
+// The same sums by a FIXED number of workgroups that walk the (chunk, column block) items of the launch, column blocks of a
+// chunk first.  For passes that share the GPU with another kernel (the pipelined masked replicas, resample.hip: the forward
+// transforms of finished groups run beside the streaming of the next ones): an ordinary launch of thousands of short-lived
+// workgroups takes every wave slot and register it can get, and the resident set of the transform kernel (two 80-KB
+// workgroups per CU, 432 of the 512 VGPRs of a SIMD) shrinks whenever one of its workgroups retires -- the transforms ran
+// 2x slower beside such a launch.  One or two walking workgroups per CU hold a fixed 40-80 VGPRs per SIMD for the whole pass.
+template <bool VEC4>
+__global__ void __launch_bounds__(256) k_partial_walk(const float *__restrict__ x, size_t ld, size_t N, const Chunk *__restrict__ chunks,
+                                                      unsigned nchunks, unsigned bx, double *__restrict__ pc, size_t ldpc)
+{
+	const unsigned nitems = nchunks * bx;
+#ifdef WALK_PRIO
+	__builtin_amdgcn_s_setprio(WALK_PRIO);
+#endif
+	if (VEC4) {
+		// The items of this workgroup as ONE sequence of 8-trace batches with two batches in flight: the loads of the next batch
+		// (of the same item or of the next one) are issued before the current batch is added, and a short last batch of a chunk
+		// is a batch like any other (rows past the end re-read the last row and are not added) -- the class chunks of masked
+		// replicas are ~30 traces long, and one load at a time for the remainder cost as many round trips as the full batches.
+		typedef float v4f __attribute__((ext_vector_type(4)));
+		unsigned item = blockIdx.x;
+		if (item >= nitems) return;
+		const unsigned lane4 = threadIdx.x * 4;
+		auto locate = [&](unsigned it, Chunk &ck, size_t &col) {
+			const unsigned ci = it / bx, cb = it - ci * bx;
+			ck = chunks[ci];
+			col = (size_t)cb * 1024 + lane4;
+			return ci;
+		};
+		Chunk ck; size_t col;
+		unsigned ci = locate(item, ck, col);
+		unsigned t = 0;
+		v4f va[8], vb[8];
+		auto issue = [&](v4f (&v)[8], const Chunk &c, size_t cl, unsigned t0) {
+			const float *src = x + c.t0 * ld + (cl < N ? cl : 0);
+			const unsigned last = c.count - 1u;
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const unsigned r = t0 + (unsigned)j < c.count ? t0 + (unsigned)j : last; // (wave-uniform)
+				v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)r * ld));
+			}
+		};
+		issue(va, ck, col, 0);
+		double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+		for (;;) {
+			// where the batch after this one comes from
+			Chunk nck = ck; size_t ncol = col; unsigned nci = ci, nt = t + 8, nitem = item;
+			bool more = true;
+			if (nt >= ck.count) {
+				nitem = item + gridDim.x;
+				if (nitem < nitems) { nci = locate(nitem, nck, ncol); nt = 0; } else more = false;
+			}
+			if (more) issue(vb, nck, ncol, nt);
+			const unsigned nv = ck.count - t < 8u ? ck.count - t : 8u;
+#pragma unroll
+			for (int j = 0; j < 8; j++)
+				if ((unsigned)j < nv) { a0 += (double)va[j].x; a1 += (double)va[j].y; a2 += (double)va[j].z; a3 += (double)va[j].w; }
+			if (nt == 0 || !more) { // the chunk is complete: its row
+				if (col < N) {
+					double *dst = pc + (size_t)ci * ldpc + col;
+					*(double2 *)dst = make_double2(a0, a1);
+					*(double2 *)(dst + 2) = make_double2(a2, a3);
+				}
+				a0 = a1 = a2 = a3 = 0;
+			}
+			if (!more) break;
+#pragma unroll
+			for (int j = 0; j < 8; j++) va[j] = vb[j];
+			ck = nck; col = ncol; ci = nci; t = nt; item = nitem;
+		}
+		return;
+	}
+	for (unsigned item = blockIdx.x; item < nitems; item += gridDim.x) {
+		const unsigned ci = item / bx, cb = item - ci * bx;
+		const Chunk ck = chunks[ci];
+		const size_t col = ((size_t)cb * 256 + threadIdx.x) * 4;
+		if (col >= N) continue;
+		const float *src = x + ck.t0 * ld + col;
+		double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+		const unsigned rem = (N - col) < 4 ? (unsigned)(N - col) : 4u;
+		for (unsigned t = 0; t < ck.count; t++) {
+			const float *r = src + (size_t)t * ld;
+			a0 += (double)r[0];
+			if (rem > 1) a1 += (double)r[1];
+			if (rem > 2) a2 += (double)r[2];
+			if (rem > 3) a3 += (double)r[3];
+		}
+		double *dst = pc + (size_t)ci * ldpc + col;
 		dst[0] = a0;
 		if (rem > 1) dst[1] = a1;
 		if (rem > 2) dst[2] = a2;
@@ -164,23 +264,62 @@ static int chunk_tables(tspws_hip_plan *p, const std::vector<Chunk> &chunks, con
 	return 0;
 }
 
-// Launch the streaming pass for an arbitrary chunk table (rows destinations).
+// Launch the streaming pass for an arbitrary chunk table (rows destinations): table upload + launches.
 int tspws_run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, const std::vector<Chunk> &chunks,
                      const std::vector<unsigned> &row_first, unsigned rows, double *d_P, size_t ldP, hipStream_t st, bool cached,
                      unsigned row_begin, unsigned row_end)
+{
+	int rc;
+	if ((rc = tspws_chunks_upload(p, chunks, row_first, rows, st, cached))) return rc;
+	return tspws_chunks_launch(p, d_x, ld, N, chunks, row_first, rows, d_P, ldP, st, row_begin, row_end);
+}
+
+// Device copy of a chunk table into the plan's table block (see chunk_tables); `fresh` false: the caller knows the block still
+// holds this very table (masked replicas with a repeated selection: plan->jk_gen) and only the stream ordering is needed.
+int tspws_chunks_upload(tspws_hip_plan *p, const std::vector<Chunk> &chunks, const std::vector<unsigned> &row_first, unsigned rows, hipStream_t st,
+                        bool cached)
+{
+	Chunk *d_chunks = nullptr;
+	unsigned *d_rf = nullptr;
+	if (!cached) p->jk_gen = 0; // whatever masked-replica table the block held is gone
+	return chunk_tables(p, chunks, row_first, rows, st, cached, &d_chunks, &d_rf);
+}
+
+// The launches of the streaming pass for the destination rows [row_begin, row_end) of a table that tspws_chunks_upload has put
+// into the plan's table block (the host copies give the launch geometry).
+int tspws_chunks_launch(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, const std::vector<Chunk> &chunks,
+                        const std::vector<unsigned> &row_first, unsigned rows, double *d_P, size_t ldP, hipStream_t st,
+                        unsigned row_begin, unsigned row_end, unsigned walk)
 {
 	row_end = std::min(row_end, rows);
 	const size_t nck = chunks.size();
 	const size_t ldpc = (N + 3) & ~(size_t)3;
 	void *d_pc = nullptr;
-	Chunk *d_chunks = nullptr;
-	unsigned *d_rf = nullptr;
 	int rc;
 	if ((rc = scratch(p, SCR_CHUNK, std::max<size_t>(nck * ldpc * sizeof(double), 16), &d_pc))) return rc;
-	if ((rc = chunk_tables(p, chunks, row_first, rows, st, cached, &d_chunks, &d_rf))) return rc;
+	if (!p->scr[SCR_TAB]) return fail(TSPWS_E_ARG, "chunks_launch: no table uploaded");
+	Chunk *d_chunks = (Chunk *)p->scr[SCR_TAB];
+	unsigned *d_rf = (unsigned *)((char *)p->scr[SCR_TAB] + nck * sizeof(Chunk));
+	if (row_begin >= row_end) return 0;
 	const unsigned bx = (unsigned)((N + 1023) / 1024);
 	const bool vec = (N % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x & 15) == 0);
 	const size_t ck0 = row_first[row_begin], ck1 = row_first[row_end]; // chunks are sorted by destination row
+	if (walk && ck1 - ck0 <= 0xFFFFFFFFull / std::max(1u, bx)) {
+		// a fixed number of walking workgroups (see k_partial_walk), chunk rows then reduced per destination as below
+		p->last_stream_launches = 1;
+		const unsigned nck_l = (unsigned)(ck1 - ck0);
+		if (nck_l) {
+			const unsigned grid = (unsigned)std::min<size_t>((size_t)nck_l * bx, walk);
+			if (vec) hipLaunchKernelGGL(k_partial_walk<true>, dim3(grid), dim3(256), 0, st, d_x, ld, N, (const Chunk *)(d_chunks + ck0), nck_l, bx, (double *)d_pc + ck0 * ldpc, ldpc);
+			else hipLaunchKernelGGL(k_partial_walk<false>, dim3(grid), dim3(256), 0, st, d_x, ld, N, (const Chunk *)(d_chunks + ck0), nck_l, bx, (double *)d_pc + ck0 * ldpc, ldpc);
+		}
+		for (unsigned r0 = row_begin; r0 < row_end; r0 += 65535) {
+			const unsigned ny = std::min(row_end - r0, 65535u);
+			hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((N + 255) / 256), ny), dim3(256), 0, st, (const double *)d_pc, ldpc, d_rf + r0, d_P + (size_t)r0 * ldP, ldP, N);
+		}
+		HIP_TRY(hipGetLastError());
+		return 0;
+	}
 	// every destination row fed by exactly ONE chunk: the streaming kernel writes the rows themselves, no chunk reduction
 	bool direct = ck1 - ck0 == (size_t)(row_end - row_begin) && ck1 - ck0 <= 65535 && (!vec || ldP % 2 == 0);
 	for (unsigned r = row_begin; r < row_end && direct; r++) direct = row_first[r + 1] - row_first[r] == 1;

@@ -106,6 +106,10 @@ struct WeightArgs {
 	size_t outp_stride = 0;
 	unsigned k0 = 0;
 	int mode1 = 0;
+	// stacks side by side in one launch (grid.y: jackknife replicas) with their own trace counts: M = Mv[blockIdx.y]
+	const double *Mv = nullptr;
+	size_t out_stride = 0;    // ... and their own weighted-coefficient sets: OUT + blockIdx.y * out_stride
+	int planes_batch = -1;    // -1: every stack's ST / PS planes are written; -2: none (only OUT is wanted); b >= 0: those of stack b only
 };
 
 enum { SCR_Y = 0, SCR_PART, SCR_XT, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_JKTAB, SCR_N };
@@ -173,6 +177,11 @@ struct tspws_hip_plan {
 	hipEvent_t ck_ev = nullptr;
 	hipStream_t ck_stream = nullptr;
 	unsigned last_stream_launches = 0; // k_partial launches of the last streaming pass (bench.py: per-launch roofline figures)
+	// masked replicas (resample.hip): generation of the class / combine tables the table blocks (SCR_TAB, SCR_JKTAB) hold right
+	// now (0: none -- any other upload into those blocks resets it); a call with the same selection skips the uploads
+	unsigned long long jk_gen = 0;
+	hipStream_t xf = nullptr;          // second stream of the pipelined masked-replica call: transforms of finished groups
+	std::vector<hipEvent_t> stage_ev;  // ... one event per hand-over
 	// blocks of exported slots (tspws_hip_reduce_buffer hands out SCR_P / SCR_STPS, tspws_hip_jackknife_buffer SCR_JKP) that
 	// were outgrown: a caller may still hold the old pointer (e.g. as the buffer of an in-flight collective), so they live
 	// until plan_destroy
@@ -268,7 +277,7 @@ int  tspws_stacks_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, size_t l
 // k_accumulate_parts for nb transformed traces (nbatch independent stacks side by side: y_part / y_stack apart)
 void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb, double2 *ST, double2 *PS, int zero_first, const FuseOut *fz,
                              unsigned nslices, hipStream_t st, unsigned nbatch, size_t y_part, size_t y_stack, const TlTable *tl, const WeightArgs *wa,
-                             ScaleRange rg);
+                             ScaleRange rg, size_t trace_stride = 0); // trace_stride: distance of consecutive transformed traces of a stack in `part` (0: npart)
 bool tspws_fused_forward(const tspws_hip_plan *p);        // the few-trace forward kernel stacks some scales in registers
 bool tspws_many_trace_path(const tspws_hip_plan *p, size_t ntr); // a batch this size goes to the trace-lane kernel
 size_t tspws_part_budget_bytes();
@@ -289,6 +298,11 @@ void tspws_epilogue_rows(float *d_ts, const double *d_x, size_t N, unsigned nb, 
 int  tspws_run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, const std::vector<Chunk> &chunks,
                       const std::vector<unsigned> &row_first, unsigned rows, double *d_P, size_t ldP, hipStream_t st, bool cached,
                       unsigned row_begin = 0, unsigned row_end = ~0u);
+int  tspws_chunks_upload(tspws_hip_plan *p, const std::vector<Chunk> &chunks, const std::vector<unsigned> &row_first, unsigned rows, hipStream_t st,
+                         bool cached);
+int  tspws_chunks_launch(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, const std::vector<Chunk> &chunks,
+                         const std::vector<unsigned> &row_first, unsigned rows, double *d_P, size_t ldP, hipStream_t st,
+                         unsigned row_begin = 0, unsigned row_end = ~0u, unsigned walk = 0); // walk: a fixed number of walking workgroups (k_partial_walk)
 unsigned tspws_chunk_len_for(size_t N, size_t mtr);
 // stack.hip
 bool tspws_is_two_stage(const t_tsPWS *p, size_t mtr_global);
