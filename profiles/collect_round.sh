@@ -17,6 +17,8 @@ python3 profiles/pmc_record.py gpurun_out/pmc_$TAG > gpurun_out/pmc_partial_stac
 python3 tools/cfg1_run.py 2>/dev/null | grep cfg1 > gpurun_out/${TAG}_cfg1.txt
 # kernel stats of the other configs (bench.py's other_configs leg times them; these are the per-kernel breakdowns)
 bash tools/gpu_prof_cfg.sh ${TAG}cfg2 tools/cfg2_run.py > /dev/null 2>&1; cp gpurun_out/stats_${TAG}cfg2.txt gpurun_out/${TAG}_stats_cfg2.txt
-bash tools/gpu_prof_cfg.sh ${TAG}cfg4 tools/cfg4_run.py > /dev/null 2>&1; cp gpurun_out/stats_${TAG}cfg4.txt gpurun_out/${TAG}_stats_cfg4.txt
-rm -rf gpurun_out/prof_${TAG}* gpurun_out/pmc_$TAG
+bash tools/gpu_timeline_cfg.sh ${TAG}cfg4 70 tools/cfg4_run.py > /dev/null 2>&1; cp gpurun_out/stats_${TAG}cfg4.txt gpurun_out/${TAG}_stats_cfg4.txt; cp gpurun_out/timeline_${TAG}cfg4.txt gpurun_out/${TAG}_timeline_cfg4.txt
+# counters of the forward kernel on the Mexican-hat frame (VALU vs FMA instruction counts: separate --pmc passes)
+PMC_CMD="tools/cfg4_run.py" PMC_SETS="sq sq2" bash profiles/collect_pmc.sh ${TAG}cfg4 > /dev/null 2>&1; cp gpurun_out/pmc_${TAG}cfg4.txt gpurun_out/${TAG}_pmc_cfg4.txt
+rm -rf gpurun_out/prof_${TAG}* gpurun_out/pmc_$TAG gpurun_out/pmc_${TAG}cfg4
 tail -c 3500 gpurun_out/${TAG}_bench_line.json; cat gpurun_out/${TAG}_stats.txt gpurun_out/${TAG}_timeline.txt gpurun_out/${TAG}_cfg1.txt gpurun_out/${TAG}_stats_cfg2.txt gpurun_out/${TAG}_stats_cfg4.txt; grep -A30 "k_partial" gpurun_out/pmc_$TAG.txt | head -40

@@ -262,3 +262,19 @@ def test_empty_shard_reaches_the_collective(tmp_path):
     for r in range(world):
         assert abi.relerr(np.load(tmp_path / f"ls{r}.npy"), want["ls"]) < 2e-6
         assert abi.relerr(np.load(tmp_path / f"ts{r}.npy"), want["tsPWS"]) < 2e-6
+
+
+@pytest.mark.parametrize("schedule", ["single", "split", "sharded-finish"])
+def test_three_schedules_over_gloo_cpu(tmp_path, schedule, monkeypatch):
+    """The three placements of the one logical reduction (stack_sharded(schedule=...), bench.py --schedule, TSPWS_SCHEDULE): ONE
+    all-reduce + redundant finish (north_star's wording), two halves overlapped with streaming / transforms, pieces + scale-sharded
+    finish.  World 3 with ragged shards; every rank must end with the unsharded oracle call's outputs, and an unknown name is refused."""
+    kw, mtr, N, world = dict(Kmax=5, unbiased=1), 23, 1024, 3
+    monkeypatch.setenv("TSPWS_SCHEDULE", schedule)
+    mp.spawn(_worker, args=(world, _free_port(), kw, mtr, N, str(tmp_path)), nprocs=world, join=True)
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), abi.synth_traces(mtr, N, seed=17))
+    for r in range(world):
+        assert abi.relerr(np.load(tmp_path / f"ls{r}.npy"), want["ls"]) < 2e-6
+        assert abi.relerr(np.load(tmp_path / f"ts{r}.npy"), want["tsPWS"]) < 2e-6
+    with pytest.raises(tspws.TspwsError):
+        tspws.stack_sharded(OraclePlan(abi.default_params(**kw), N), torch.zeros((2, N)), 0, 2, schedule="ring")
