@@ -274,6 +274,18 @@ static LaunchRange launch_range(const tspws_hip_plan *p, ScaleRange rg)
 	return r;
 }
 
+// The side stream of the direct kernel.  TSPWS_SIDE_PRIO=1 / -1 creates it with the highest / lowest stream priority (sweeps: does
+// the coarse-scale kernel finish inside the main kernel's time when it is dispatched first?); default: plain.
+static hipError_t tspws_side_stream(tspws_hip_plan *p)
+{
+	const char *e = getenv("TSPWS_SIDE_PRIO");
+	if (!e || !atoi(e)) return hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+	int lo = 0, hi = 0;
+	hipError_t rc = hipDeviceGetStreamPriorityRange(&lo, &hi);
+	if (rc != hipSuccess) return rc;
+	return hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, atoi(e) > 0 ? hi : lo);
+}
+
 // Two independent kernels transform disjoint sets of scales: the LDS kernel (FP64-bound) and the direct kernel (coarse
 // scales, latency-bound).  They run side by side: a side stream is forked from and joined back into the caller's stream.
 template <typename TIn>
@@ -290,7 +302,7 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 #endif
 	if (has_lds && has_poly && !serial) {
 		const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence; // device-local ordering only
-		if (!p->side) HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+		if (!p->side) HIP_TRY(tspws_side_stream(p));
 		if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, evf));
 		if (!p->ev_join) HIP_TRY(hipEventCreateWithFlags(&p->ev_join, evf));
 		// fork: the side stream waits for the producer of d_x -- its launch carried the event (plan->le.ready) or a record here
@@ -474,8 +486,9 @@ extern "C" int tspws_hip_accumulate(tspws_hip_plan *p, const double *d_Y, size_t
 // launches k_accumulate_parts for `nb` transformed traces; fz = what the forward launch left behind (may be NULL / not applied)
 void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb, double2 *ST, double2 *PS, int zero_first, const FuseOut *fz,
                              unsigned nslices, hipStream_t st, unsigned nbatch, size_t y_part, size_t y_stack, const TlTable *tl, const WeightArgs *wa,
-                             ScaleRange rg, size_t trace_stride)
+                             ScaleRange rg, const AccExtra *ex)
 {
+	const size_t trace_stride = ex ? ex->trace_stride : 0;
 	const WeightArgs w0;
 	const bool on = fz && fz->applied;
 	const bool direct = on && fz->accST == ST; // the single slice went straight into ST / PS
@@ -487,7 +500,8 @@ void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb
 	hipLaunchKernelGGL(kern, dim3(a1 - a0, nbatch), dim3(256), 0, st, part, trace_stride ? trace_stride : (tl ? tl->npart : p->npart),
 	                   (const ScaleDesc *)(tl ? tl->d_sc : p->d_sc), p->S, nb, ST, PS, zero_first,
 	                   on ? (direct ? 1 : 2) : 0, on ? (const double2 *)fz->accST : nullptr, on ? (const double2 *)fz->accPS : nullptr,
-	                   on ? fz->stride : (size_t)0, nslices, y_part, y_stack, tl ? 1 : 0, wa ? *wa : w0, a0);
+	                   on ? fz->stride : (size_t)0, nslices, y_part, y_stack, tl ? 1 : 0, wa ? *wa : w0, a0, ex ? ex->y_fz : (size_t)0,
+	                   ex ? ex->rowmap : (const unsigned *)nullptr);
 }
 
 // slice length of the fused forward kernel for a batch of nb traces: whole batch when it is small (two-stage: the K
@@ -525,7 +539,7 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 		hipStream_t sp = st;
 		if (T.waves) {
 			const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
-			if (!p->side) HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+			if (!p->side) HIP_TRY(tspws_side_stream(p));
 			if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, evf));
 			if (!p->ev_join) HIP_TRY(hipEventCreateWithFlags(&p->ev_join, evf));
 			HIP_TRY(hipEventRecord(p->ev_fork, st)); // (after the previous batch's accumulation: `part` is free again)

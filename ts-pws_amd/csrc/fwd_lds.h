@@ -442,7 +442,11 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 					for (int i = 0; i < NACC; i++) {
 						const double2 y = make_double2(v[2 * i], -v[2 * i + 1]); // conj
 						fst[p][i].x += y.x; fst[p][i].y += y.y;
+#ifdef FL_NONORM /* timing ablation (results wrong): what does the phase normalisation cost inside this kernel? */
+						fps[p][i].x += y.x; fps[p][i].y -= y.y;
+#else
 						add_unit_phasor(fps[p][i], y);
+#endif
 					}
 				} else {
 					double re, im;
@@ -450,7 +454,11 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 					valu_reduce_cplx64(v, lane, re, im, first);
 					const double2 y = make_double2(re, -im);
 					fst[p][0].x += y.x; fst[p][0].y += y.y;
+#ifdef FL_NONORM
+					fps[p][0].x += y.x; fps[p][0].y -= y.y;
+#else
 					add_unit_phasor(fps[p][0], y);
+#endif
 				}
 			}
 			FL_STAMP(5); // lane reduction + phase normalisation

@@ -420,12 +420,17 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
                                                           unsigned S, unsigned ntr, double2 *__restrict__ ST, double2 *__restrict__ PS,
                                                           int zero_first, int fused, const double2 *__restrict__ fzST,
                                                           const double2 *__restrict__ fzPS, size_t fz_stride, unsigned nslices,
-                                                          size_t y_part, size_t y_stack, int many, WeightArgs wa, unsigned blk0)
+                                                          size_t y_part, size_t y_stack, int many, WeightArgs wa, unsigned blk0,
+                                                          size_t y_fz, const unsigned *__restrict__ rowmap)
 {
 	const unsigned bx = blk0 + blockIdx.x; // (blk0: the launch may cover a sub-range of the scales)
 	// blockIdx.y = independent stack (jackknife replica): its ntr transformed traces start y_part further in `part`, its
 	// ST / PS y_stack further (the fused forward kernel wrote the fuse_ok scales there directly: fused == 1)
 	part += (size_t)blockIdx.y * y_part; ST += (size_t)blockIdx.y * y_stack; PS += (size_t)blockIdx.y * y_stack;
+	// y_fz: the slice planes of stack blockIdx.y start y_fz further (stacks whose slices interleave: the staged masked replicas);
+	// rowmap (few-trace branches): transformed trace b of stack y sits rowmap[y ntr + b] trace strides into `part` (y_part unused)
+	if (fzST) { fzST += (size_t)blockIdx.y * y_fz; fzPS += (size_t)blockIdx.y * y_fz; }
+	if (rowmap) rowmap += (size_t)blockIdx.y * ntr;
 	if (wa.Mv) wa.M = wa.Mv[blockIdx.y]; // (replicas side by side: each with its own trace count and weighted-coefficient set)
 	// stacks that are only needed as weighted coefficients are not written (few-trace branches below; zero_first callers only)
 	const bool planes = wa.planes_batch == -1 || (int)blockIdx.y == wa.planes_batch;
@@ -454,7 +459,7 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 			const double2 a = fzST[(size_t)j * fz_stride + i], b = fzPS[(size_t)j * fz_stride + i];
 			st.x += a.x; st.y += a.y; ps.x += b.x; ps.y += b.y;
 		}
-		ST[i] = st; PS[i] = ps;
+		if (planes) { ST[i] = st; PS[i] = ps; }
 		if (wa.OUT) wa.OUT[i] = weight_value(st, ps, wa.mode, wa.K, wa.M, wa.wu);
 		return;
 	}
@@ -498,7 +503,8 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 		if (!zero_first) { st = ST[i]; ps = PS[i]; }
 		for (unsigned b0 = 0; b0 < ntr; b0 += 8) {
 			const bool on = b0 + bt < ntr;
-			const double2 *p = p0 + (size_t)(on ? b0 + bt : 0u) * npart;
+			const unsigned tb_ = on ? b0 + bt : 0u;
+			const double2 *p = p0 + (size_t)(rowmap ? rowmap[tb_] : tb_) * npart;
 			double2 v = make_double2(0.0, 0.0);
 			for (unsigned sp = sub; sp < nsplit; sp += 32) {
 				double2 t[4];
@@ -539,7 +545,10 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 	for (unsigned b0 = 0; b0 < ntr; b0 += 4) { // four traces' loads in flight (independent addresses); the additions keep the trace order
 		double2 v[4];
 #pragma unroll
-		for (int j = 0; j < 4; j++) v[j] = p0[(size_t)(b0 + (unsigned)j < ntr ? b0 + (unsigned)j : ntr - 1u) * npart];
+		for (int j = 0; j < 4; j++) {
+			const unsigned tb_ = b0 + (unsigned)j < ntr ? b0 + (unsigned)j : ntr - 1u;
+			v[j] = p0[(size_t)(rowmap ? rowmap[tb_] : tb_) * npart];
+		}
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const unsigned b = b0 + (unsigned)j;

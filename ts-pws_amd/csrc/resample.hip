@@ -52,16 +52,24 @@ __global__ void __launch_bounds__(256) k_combine_classes(const double *__restric
 }
 
 // replica linear stack in the time domain, :799-811: (sum_g P[g]) * (1/K)
-// rows of replica c: P + c * y_rep + g * y_grp (replica-major rows: y_rep = Kmax N, y_grp = N; group-major: y_rep = N, y_grp = W N)
+// rows of replica c.  gps == 0: replica-major rows, P[(c Kmax + g) N]; gps > 0: the staged layout of the pipelined call,
+// row(g, c) = g0 W + c ng + (g - g0) with g0 = g / gps * gps, ng = min(gps, Kmax - g0)
 __global__ void __launch_bounds__(256) k_jk_linear(const double *__restrict__ P, unsigned Kmax, size_t N, const double *__restrict__ Mv,
-                                                   float *__restrict__ out, size_t y_rep, size_t y_grp)
+                                                   float *__restrict__ out, unsigned W, unsigned gps)
 {
 	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (n >= N) return;
-	P += (size_t)blockIdx.y * y_rep; out += (size_t)blockIdx.y * N; // blockIdx.y = replica
-	const double invK = 1. / Mv[blockIdx.y];
-	double acc = P[n];
-	for (unsigned g = 1; g < Kmax; g++) acc += P[(size_t)g * y_grp + n];
+	const unsigned c = blockIdx.y; // replica
+	out += (size_t)c * N;
+	const double invK = 1. / Mv[c];
+	double acc = 0;
+	for (unsigned g = 0; g < Kmax; g++) {
+		size_t row;
+		if (gps) { const unsigned g0 = g / gps * gps, ng = (Kmax - g0) < gps ? (Kmax - g0) : gps; row = (size_t)g0 * W + (size_t)c * ng + (g - g0); }
+		else row = (size_t)c * Kmax + g;
+		const double v = P[row * N + n];
+		acc = g ? acc + v : v;
+	}
 	out[n] = (float)(acc * invK);
 }
 
@@ -254,7 +262,7 @@ static int finish_replicas(tspws_hip_plan *pl, const t_tsPWS *p, double *d_P, co
 		tspws_weight_batched(pl, (double2 *)OUT, (const double2 *)STr, (const double2 *)STr + nc, tspws_weight_mode(p->wu, p->unbiased, KM), (double)KM, p->wu,
 		                     (const double *)(d_Mv + c0), nr, nc, 2 * nc, st);
 		hipLaunchKernelGGL(k_jk_linear, dim3((unsigned)((N + 255) / 256), nr), dim3(256), 0, st, d_P + (size_t)c0 * KM * N, KM, N, (const double *)(d_Mv + c0),
-		                   d_ls_out + (size_t)c0 * N, (size_t)KM * N, N);
+		                   d_ls_out + (size_t)c0 * N, 0u, 0u);
 		if ((rc = tspws_hip_inverse(pl, OUT, nr, xr, s))) return rc;
 		tspws_epilogue_rows(d_ts_out + (size_t)c0 * N, xr, N, nr, st);
 	}
@@ -263,36 +271,60 @@ static int finish_replicas(tspws_hip_plan *pl, const t_tsPWS *p, double *d_P, co
 }
 
 // ------------------------------------------------------------------------------------------
-// The masked replicas as a pipeline (round 4).  Replica groups are contiguous in selected-trace order (ts_pws1f_lib.c:758-772,
+// The masked replicas in stages (round 4).  Replica groups are contiguous in selected-trace order (ts_pws1f_lib.c:758-772,
 // g = floor(k Kmax / K)), so once the traces up to the end of group g of EVERY column (replica / plain stack) have been
 // streamed, row g of all columns is final: its forward transforms (the FP64-bound half of the call: 110 transforms at cfg4)
 // run on a second stream while the next groups are streamed (the HBM-bound half).
-//   stage s = groups [s gps, (s + 1) gps) of every column;
-//   class  -> stage = (smallest group index in its signature) / gps: all traces of the class lie before the end of that group
-//             in the column that holds it, i.e. a stage's rows only need classes of stages <= s;
-//   rows   are GROUP-major, row = g W + column (W = C [+ 1 for the plain stack]), so a stage's rows are one run: the
-//             forward launch of a stage transforms its gps W rows into per-trace coefficients (no in-register stacks: a
-//             stage holds one or two traces of each stack), and ONE accumulation at the end adds the Kmax transformed rows of
-//             every stack in group order -- the reference's order (:897-904) -- and writes the weighted coefficients.
-// Everything that depends on the selection only (classes, chunk table, combine lists, trace counts) is built once per
-// selection (per host thread, keyed by content) AND stays on the device while the plan's table blocks are not reused
+//   stage s = groups [s gps, (s + 1) gps) of every column (two stages by default), its traces = [T(s - 1), T(s)) with T(s) = the
+//             end of the last trace that belongs to a group of stage <= s in any column;
+//   streaming side: RUNNING sums.  The traces are cut into runs of one signature (= the group of the trace in every column);
+//             a segment of a stage walks its runs in trace order without resetting its accumulators and stores a snapshot after
+//             every run (k_prefix_walk, stream.hip).  A row -- group g of column c -- is the sum over the maximal stretches
+//             [a, b) of consecutive runs that belong to it: sum of G(b) - G(a), G(k) = snapshot before run k (+ the final
+//             snapshots of the earlier segments of its stage): ~10 signed snapshots per row (k_combine_terms) instead of a
+//             chunk reduction + ~15 class rows per row -- 1.30 -> 1.17 ms for the streaming side of cfg4 (the 326 MB of snapshot
+//             writes cost 0.25 ms of the 1.02-ms walk: with the stores aimed at two rows only it takes 0.78 ms);
+//   rows   are STAGE-major and, inside a stage, column-major: row(g, c) = g0 W + c ng + (g - g0)  (W = C [+ 1 for the plain
+//             stack], g0 / ng = first group / groups of the stage), so the rows of a stage are one run and the ng rows of a
+//             column in it are consecutive: the stage's forward launch is the FUSED kernel with one slice per column -- the
+//             linear / phase stacks of the stage's groups stay in registers and leave one plane pair per (stage, column); the
+//             scales with phase splits leave per-trace partials as always.  ONE accumulation at the end adds a column's
+//             plane pairs in stage order and its split partials in group order -- the reference's order (:897-904) -- and
+//             writes the weighted coefficients; the inverses of all columns share one batched launch.
+// What the two halves cost each other (tools/probes/corun_probe.hip, tools/experiments/corun_fwd.py, profiles/r04_*cfg4*): a
+// register-only FP64 stream keeps its rate beside a streaming kernel (which drops to 70 %), but k_fwd_lds beside the streaming
+// side loses as much as the overlap gains: ten stages of one group each 2.82 ms (and 4.0 ms with fused slices of one trace),
+// three stages 2.82, two 2.68-2.74, one (no overlap at all) 2.73-2.77; the round-3 call was 3.13 ms.  Stream / wave priorities,
+// the cache policy of the streaming loads and the number of streaming workgroups change nothing.
+// Everything that depends on the selection only (runs, segments, term lists, row map, trace counts) is built once per
+// selection (per host thread, keyed by content) AND stays on the device while the plan's table block is not reused
 // (plan->jk_gen): a repeated selection issues no host-to-device copy at all.
 // ------------------------------------------------------------------------------------------
 struct MaskedPlan {
 	// key
-	size_t mtr = 0;
-	unsigned C = 0, KM = 0, clen = 0, gps = 0;
+	size_t mtr = 0, N = 0;
+	unsigned C = 0, KM = 0, gps = 0;
 	bool with_main = false, valid = false;
 	std::vector<char> sel;
 	// products
 	unsigned long long gen = 0;
-	unsigned W = 0, ncls = 0, nstage = 0;
+	unsigned W = 0, nstage = 0;
 	std::vector<size_t> Kc;
-	std::vector<Chunk> chunks;          // sorted by class, classes numbered in stage order
-	std::vector<unsigned> row_first;    // per class: first chunk
-	std::vector<unsigned> cls0;         // per stage: first class (nstage + 1)
-	std::vector<unsigned> tab;          // combine lists: [KM W + 1] row pointers | class ids; row = g W + column
+	std::vector<Chunk> runs;            // maximal runs of consecutive traces with one signature (cut at the stage ends), trace order
+	std::vector<unsigned> seg_first;    // per stage: the first runs of its segments + the end (nseg + 1 entries), stages concatenated
+	std::vector<unsigned> stage_seg0;   // per stage: its first entry in seg_first (nstage + 1)
+	std::vector<unsigned> carry;        // per stage: snapshots whose sum is the prefix sum at the stage's start
+	std::vector<unsigned> carry_ptr;    // (nstage + 1)
+	std::vector<unsigned> trow_ptr;     // rows as signed sums of snapshots: [KM W + 1] pointers, rows in stage / column / group order
+	std::vector<unsigned> tidx;
+	std::vector<float> tcoef;
+	std::vector<unsigned> rowmap;       // [W][KM]: row of (column, group)
 	std::vector<double> Mv;             // trace count per column (replicas: selected traces; plain stack: mtr)
+	unsigned row_of(unsigned g, unsigned c) const
+	{
+		const unsigned g0 = g / gps * gps, ng = std::min(gps, KM - g0);
+		return g0 * W + c * ng + (g - g0);
+	}
 };
 
 static unsigned long long next_masked_gen()
@@ -304,11 +336,13 @@ static unsigned long long next_masked_gen()
 static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, unsigned C, unsigned KM, bool with_main, unsigned gps)
 {
 	static thread_local MaskedPlan mp;
-	const unsigned clen = tspws_chunk_len_for(N, std::max<size_t>(mtr, 1));
-	if (mp.valid && mp.mtr == mtr && mp.C == C && mp.KM == KM && mp.clen == clen && mp.gps == gps && mp.with_main == with_main &&
+	if (mp.valid && mp.mtr == mtr && mp.N == N && mp.C == C && mp.KM == KM && mp.gps == gps && mp.with_main == with_main &&
 	    mp.sel.size() == (size_t)C * mtr && !memcmp(mp.sel.data(), h_sel, (size_t)C * mtr)) return mp;
 	mp.valid = false;
 	const unsigned W = C + (with_main ? 1u : 0u);
+	mp.KM = KM; mp.gps = gps; mp.W = W;
+	const unsigned nstage = (KM + gps - 1) / gps;
+	// signature of trace i: its group in every column (SIG_DELETED: not in that replica)
 	mp.Kc.assign(C, 0);
 	std::vector<unsigned> sig((size_t)mtr * W);
 	for (unsigned c = 0; c < C; c++) {
@@ -325,90 +359,134 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 		}
 	}
 	if (with_main) for (size_t i = 0; i < mtr; i++) sig[i * W + C] = (unsigned)std::min<size_t>((i * KM) / mtr, KM - 1);
-	// classes in order of first appearance, with their runs of traces
-	std::vector<std::vector<unsigned>> csig;
-	std::vector<std::vector<Chunk>> cls_chunks;
-	std::unordered_map<std::string, size_t> cls_of;
-	for (size_t i = 0; i < mtr;) {
-		size_t j = i + 1;
-		while (j < mtr && !memcmp(&sig[i * W], &sig[j * W], W * sizeof(unsigned))) j++;
-		const std::string key((const char *)&sig[i * W], W * sizeof(unsigned));
-		auto it = cls_of.find(key);
-		size_t id;
-		if (it == cls_of.end()) {
-			id = csig.size();
-			cls_of.emplace(key, id);
-			csig.emplace_back(sig.begin() + i * W, sig.begin() + (i + 1) * W);
-			cls_chunks.emplace_back();
-		} else id = it->second;
-		for (size_t t = i; t < j; t += clen) {
-			Chunk c; c.t0 = t; c.count = (unsigned)std::min<size_t>(clen, j - t); c.row = 0;
-			cls_chunks[id].push_back(c);
+	// end of stage s: one past the last trace that belongs to a group of stage <= s in any column
+	std::vector<size_t> T(nstage, 0);
+	for (size_t i = 0; i < mtr; i++)
+		for (unsigned c = 0; c < W; c++) {
+			const unsigned g = sig[i * W + c];
+			if (g != SIG_DELETED) { const unsigned sg = std::min(g, KM - 1) / gps; T[sg] = std::max(T[sg], i + 1); }
 		}
-		i = j;
-	}
-	// stage of a class; classes deleted from every column are never streamed
-	const unsigned nstage = (KM + gps - 1) / gps;
-	std::vector<unsigned> stage(csig.size());
-	std::vector<std::vector<unsigned>> by_stage(nstage);
-	for (size_t id = 0; id < csig.size(); id++) {
-		unsigned g = SIG_DELETED;
-		for (unsigned c = 0; c < W; c++) g = std::min(g, csig[id][c]);
-		if (g == SIG_DELETED) { stage[id] = ~0u; continue; }
-		stage[id] = std::min(g, KM - 1) / gps;
-		by_stage[stage[id]].push_back((unsigned)id);
-	}
-	std::vector<unsigned> new_id(csig.size(), ~0u);
-	mp.chunks.clear(); mp.row_first.clear(); mp.cls0.assign(nstage + 1, 0);
-	unsigned n = 0;
-	for (unsigned sgi = 0; sgi < nstage; sgi++) {
-		mp.cls0[sgi] = n;
-		for (unsigned id : by_stage[sgi]) {
-			new_id[id] = n;
-			mp.row_first.push_back((unsigned)mp.chunks.size());
-			for (Chunk c : cls_chunks[id]) { c.row = n; mp.chunks.push_back(c); }
-			n++;
+	for (unsigned sg = 1; sg < nstage; sg++) T[sg] = std::max(T[sg], T[sg - 1]);
+	T[nstage - 1] = mtr; // (traces past the last group of every column change nothing; they ride along)
+	// runs, cut at signature changes and stage ends
+	mp.runs.clear();
+	std::vector<unsigned> run_stage;
+	{
+		unsigned sg = 0;
+		for (size_t i = 0; i < mtr;) {
+			while (sg + 1 < nstage && i >= T[sg]) sg++;
+			size_t j = i + 1;
+			while (j < mtr && j < T[sg] && !memcmp(&sig[i * W], &sig[j * W], W * sizeof(unsigned))) j++;
+			Chunk c; c.t0 = i; c.count = (unsigned)(j - i); c.row = 0;
+			if (c.count != j - i) { j = i + 0xFFFFFFF0ull; c.count = 0xFFFFFFF0u; } // (a run longer than 2^32 traces is cut)
+			mp.runs.push_back(c);
+			run_stage.push_back(sg);
+			i = j;
 		}
 	}
-	mp.cls0[nstage] = n;
-	mp.row_first.push_back((unsigned)mp.chunks.size());
-	mp.ncls = n;
-	// combine lists, rows group-major
+	const unsigned nr = (unsigned)mp.runs.size();
+	// segments: a stage's runs in ~256 / (column blocks) pieces of similar trace counts, each walked by its own workgroups
+	static int seg_wgs = -1; // workgroups the streaming side aims at per stage (sweeps: TSPWS_JK_SEGWG)
+	if (seg_wgs < 0) { const char *e = getenv("TSPWS_JK_SEGWG"); seg_wgs = e ? std::max(1, atoi(e)) : 256; }
+	const unsigned bx = (unsigned)((N + 1023) / 1024), want_seg = std::max(1u, (unsigned)seg_wgs / std::max(1u, bx));
+	mp.seg_first.clear(); mp.stage_seg0.assign(nstage + 1, 0);
+	std::vector<unsigned> seg_of(nr, 0), seg_last;      // segment (global numbering) of a run; last run of a segment
+	std::vector<unsigned> seg_stage_first(nstage + 1, 0); // first global segment of a stage
+	{
+		unsigned r = 0;
+		for (unsigned sg = 0; sg < nstage; sg++) {
+			mp.stage_seg0[sg] = (unsigned)mp.seg_first.size();
+			seg_stage_first[sg] = (unsigned)seg_last.size();
+			unsigned r1 = r;
+			size_t traces = 0;
+			while (r1 < nr && run_stage[r1] == sg) { traces += mp.runs[r1].count; r1++; }
+			const unsigned nruns = r1 - r, nseg = std::min(want_seg, nruns);
+			size_t done = 0;
+			unsigned k = 0;
+			for (unsigned q = r; q < r1; q++) {
+				// run q opens segment k when the traces before it reach k / nseg of the stage
+				if (k < nseg && (q == r || done * nseg >= (size_t)k * traces)) {
+					if (q != r) seg_last.push_back(q - 1);
+					mp.seg_first.push_back(q);
+					k++;
+				}
+				seg_of[q] = (unsigned)(seg_stage_first[sg] + k - 1);
+				done += mp.runs[q].count;
+			}
+			if (nruns) seg_last.push_back(r1 - 1);
+			mp.seg_first.push_back(r1);
+			r = r1;
+		}
+		mp.stage_seg0[nstage] = (unsigned)mp.seg_first.size();
+		seg_stage_first[nstage] = (unsigned)seg_last.size();
+	}
+	// prefix sum at the start of a stage = sum of the final snapshots of the segments of the last non-empty stage before it
+	mp.carry.clear(); mp.carry_ptr.assign(nstage + 1, 0);
+	{
+		std::vector<unsigned> cur;
+		for (unsigned sg = 0; sg < nstage; sg++) {
+			mp.carry_ptr[sg] = (unsigned)mp.carry.size();
+			mp.carry.insert(mp.carry.end(), cur.begin(), cur.end());
+			if (seg_stage_first[sg + 1] > seg_stage_first[sg]) {
+				cur.clear();
+				for (unsigned q = seg_stage_first[sg]; q < seg_stage_first[sg + 1]; q++) cur.push_back(seg_last[q]);
+			}
+		}
+		mp.carry_ptr[nstage] = (unsigned)mp.carry.size();
+	}
+	// G(k) = sum of all traces before run k, as a signed sum of snapshots: snap[k - 1] + the final snapshots of the earlier segments
+	// of the same stage (segment 0 of a stage starts from the carried prefix: its snapshots are global)
+	auto add_G = [&](std::vector<std::pair<unsigned, int>> &terms, unsigned k, int sign) {
+		if (!k) return;
+		const unsigned r = k - 1, sg = run_stage[r];
+		terms.emplace_back(r, sign);
+		for (unsigned q = seg_stage_first[sg]; q < seg_of[r]; q++) terms.emplace_back(seg_last[q], sign);
+	};
+	// rows: for every column and group the maximal stretches [a, b) of consecutive runs that belong to it: sum of G(b) - G(a)
 	const unsigned nrow = KM * W;
-	std::vector<std::vector<unsigned>> lists(nrow);
-	for (size_t id = 0; id < csig.size(); id++) {
-		if (new_id[id] == ~0u) continue;
-		for (unsigned c = 0; c < W; c++) if (csig[id][c] != SIG_DELETED) lists[(size_t)std::min(csig[id][c], KM - 1) * W + c].push_back(new_id[id]);
+	std::vector<std::vector<std::pair<unsigned, int>>> lists(nrow);
+	for (unsigned c = 0; c < W; c++) {
+		unsigned a = 0, cur = SIG_DELETED;
+		for (unsigned r = 0; r <= nr; r++) {
+			const unsigned g = r < nr ? sig[mp.runs[r].t0 * W + c] : SIG_DELETED;
+			if (g == cur) continue;
+			if (cur != SIG_DELETED) { auto &L = lists[mp.row_of(std::min(cur, KM - 1), c)]; add_G(L, r, +1); add_G(L, a, -1); }
+			cur = g; a = r;
+		}
 	}
-	mp.tab.assign((size_t)nrow + 1, 0);
+	mp.trow_ptr.assign((size_t)nrow + 1, 0); mp.tidx.clear(); mp.tcoef.clear();
 	for (unsigned r = 0; r < nrow; r++) {
-		mp.tab[r] = (unsigned)(mp.tab.size() - (nrow + 1));
-		std::sort(lists[r].begin(), lists[r].end()); // class order = trace order of first appearance within a stage: a fixed, data-independent order
-		mp.tab.insert(mp.tab.end(), lists[r].begin(), lists[r].end());
+		mp.trow_ptr[r] = (unsigned)mp.tidx.size();
+		auto &L = lists[r];
+		std::sort(L.begin(), L.end());
+		for (size_t i = 0; i < L.size();) { // merge equal snapshots, drop what cancels
+			size_t j = i; int cf = 0;
+			while (j < L.size() && L[j].first == L[i].first) cf += L[j++].second;
+			if (cf) { mp.tidx.push_back(L[i].first); mp.tcoef.push_back((float)cf); }
+			i = j;
+		}
 	}
-	mp.tab[nrow] = (unsigned)(mp.tab.size() - (nrow + 1));
+	mp.trow_ptr[nrow] = (unsigned)mp.tidx.size();
+	mp.rowmap.assign((size_t)W * KM, 0);
+	for (unsigned c = 0; c < W; c++) for (unsigned g = 0; g < KM; g++) mp.rowmap[(size_t)c * KM + g] = mp.row_of(g, c);
 	mp.Mv.assign(W, 0.0);
 	for (unsigned c = 0; c < C; c++) mp.Mv[c] = (double)mp.Kc[c];
 	if (with_main) mp.Mv[C] = (double)(unsigned)mtr;
-	mp.mtr = mtr; mp.C = C; mp.KM = KM; mp.clen = clen; mp.gps = gps; mp.with_main = with_main; mp.W = W; mp.nstage = nstage;
+	mp.mtr = mtr; mp.N = N; mp.C = C; mp.with_main = with_main; mp.nstage = nstage;
 	mp.sel.assign(h_sel, h_sel + (size_t)C * mtr);
 	mp.gen = next_masked_gen();
 	mp.valid = true;
 	return mp;
 }
 
-static unsigned masked_walk()
+// groups per stage: TSPWS_JK_GPS, else ceil(KM / stages) with TSPWS_JK_STAGES (default 2) stages
+static unsigned masked_gps(unsigned KM)
 {
-	static int v = -1;
-	if (v < 0) { const char *e = getenv("TSPWS_JK_WALK"); v = e ? std::max(0, atoi(e)) : 256; }
-	return (unsigned)v;
-}
-
-static unsigned masked_gps()
-{
-	static int v = -1;
-	if (v < 0) { const char *e = getenv("TSPWS_JK_GPS"); v = e ? std::max(1, atoi(e)) : 1; }
-	return (unsigned)v;
+	static int gps = -1, nst = -1;
+	if (gps < 0) { const char *e = getenv("TSPWS_JK_GPS"); gps = e ? std::max(0, atoi(e)) : 0; }
+	if (nst < 0) { const char *e = getenv("TSPWS_JK_STAGES"); nst = e ? std::max(1, atoi(e)) : 2; }
+	if (gps > 0) return std::min((unsigned)gps, KM);
+	return std::max(1u, (KM + (unsigned)nst - 1) / (unsigned)nst);
 }
 
 // 1: the pipelined call is possible for this plan / shape (per-trace coefficients of all KM W rows fit the scratch budget)
@@ -426,25 +504,34 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	hipStream_t st = S_(s);
 	const unsigned KM = p->Kmax;
 	const size_t N = pl->N, nc = pl->ncoef;
-	const MaskedPlan &mp = masked_plan(N, mtr, h_sel, C, KM, with_stack, masked_gps());
+	const MaskedPlan &mp = masked_plan(N, mtr, h_sel, C, KM, with_stack, masked_gps(KM));
 	const unsigned W = mp.W, nrow = KM * W;
 	int rc;
 	void *v;
-	// device blocks: class rows, group-major partial-stack rows, per-trace coefficients, stacks + weighted sets + reconstructions
-	if ((rc = scratch(pl, SCR_CLS, std::max<size_t>((size_t)mp.ncls * N, 1) * sizeof(double), &v))) return rc;
-	double *d_cls = (double *)v;
+	// device blocks: partial-stack rows, split partials, slice planes, stacks + weighted sets + reconstructions (the snapshots of
+	// the streaming side live in the chunk block)
+	const bool fuse = tspws_fused_forward(pl);
 	if ((rc = scratch(pl, SCR_JKP, ((size_t)nrow * N + W) * sizeof(double), &v))) return rc;
 	double *d_rows = (double *)v;
 	if ((rc = scratch(pl, SCR_PART, (size_t)nrow * pl->npart * sizeof(double2), &v))) return rc;
 	double2 *part = (double2 *)v;
+	double2 *planes = nullptr; // [stage][column][ST | PS]
+	if (fuse) { if ((rc = scratch(pl, SCR_FZ, (size_t)mp.nstage * W * 2 * nc * sizeof(double2), &v))) return rc; planes = (double2 *)v; }
 	const unsigned nrec = W + (with_stack ? 1u : 0u); // reconstructions: OUT of every column (+ ST of the plain stack)
 	if ((rc = scratch(pl, SCR_JKOUT, ((size_t)(nrec + 2 * W) * 2 * nc + (size_t)nrec * N) * sizeof(double), &v))) return rc;
 	double *OUT = (double *)v, *STr = OUT + (size_t)nrec * 2 * nc, *xr = STr + (size_t)W * 4 * nc;
-	const size_t tab_bytes = mp.tab.size() * sizeof(unsigned), tab_al = (tab_bytes + 7) & ~(size_t)7;
-	if ((rc = scratch(pl, SCR_JKTAB, tab_al + W * sizeof(double), &v))) return rc;
-	unsigned *d_rp = (unsigned *)v, *d_cols = d_rp + nrow + 1;
-	double *d_Mv = (double *)((char *)v + tab_al);
-	if ((rc = scratch(pl, SCR_CHUNK, 16, &v))) return rc; // (grown by the launches)
+	// table block: runs (16-byte records) | trace counts | term pointers | term snapshots | term coefficients | row map | segments | carries
+	const size_t n_runs = mp.runs.size(), n_tp = mp.trow_ptr.size(), n_t = mp.tidx.size(), n_map = mp.rowmap.size(), n_seg = mp.seg_first.size(),
+	             n_car = mp.carry.size();
+	const size_t o_mv = n_runs * sizeof(Chunk), o_tp = o_mv + W * sizeof(double), o_ti = o_tp + n_tp * 4, o_tc = o_ti + n_t * 4, o_map = o_tc + n_t * 4,
+	             o_seg = o_map + n_map * 4, o_car = o_seg + n_seg * 4, tab_bytes = o_car + std::max<size_t>(n_car, 1) * 4;
+	if ((rc = scratch(pl, SCR_JKTAB, tab_bytes, &v))) return rc;
+	char *tb = (char *)v;
+	const Chunk *d_runs = (const Chunk *)tb;
+	double *d_Mv = (double *)(tb + o_mv);
+	const unsigned *d_tp = (const unsigned *)(tb + o_tp), *d_ti = (const unsigned *)(tb + o_ti), *d_map = (const unsigned *)(tb + o_map),
+	               *d_seg = (const unsigned *)(tb + o_seg), *d_car = (const unsigned *)(tb + o_car);
+	const float *d_tc = (const float *)(tb + o_tc);
 	if (!pl->xf) {
 		int lo = 0, hi = 0;
 		HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi)); // (lo = least urgent)
@@ -456,35 +543,52 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 		HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
 		pl->stage_ev.push_back(e);
 	}
-	// tables: only when the blocks do not hold this selection's already
-	if (pl->jk_gen != mp.gen || !pl->scr[SCR_TAB]) {
-		if ((rc = tspws_chunks_upload(pl, mp.chunks, mp.row_first, mp.ncls, st, false))) return rc; // (resets jk_gen)
-		HIP_TRY(hipMemcpyAsync(d_rp, mp.tab.data(), tab_bytes, hipMemcpyHostToDevice, st));
-		HIP_TRY(hipMemcpyAsync(d_Mv, mp.Mv.data(), W * sizeof(double), hipMemcpyHostToDevice, st));
+	// tables: only when the block does not hold this selection's already
+	if (pl->jk_gen != mp.gen) {
+		pl->jk_gen = 0;
+		if (n_runs) HIP_TRY(hipMemcpyAsync(tb, mp.runs.data(), n_runs * sizeof(Chunk), hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(tb + o_mv, mp.Mv.data(), W * sizeof(double), hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(tb + o_tp, mp.trow_ptr.data(), n_tp * 4, hipMemcpyHostToDevice, st));
+		if (n_t) {
+			HIP_TRY(hipMemcpyAsync(tb + o_ti, mp.tidx.data(), n_t * 4, hipMemcpyHostToDevice, st));
+			HIP_TRY(hipMemcpyAsync(tb + o_tc, mp.tcoef.data(), n_t * 4, hipMemcpyHostToDevice, st));
+		}
+		HIP_TRY(hipMemcpyAsync(tb + o_map, mp.rowmap.data(), n_map * 4, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(tb + o_seg, mp.seg_first.data(), n_seg * 4, hipMemcpyHostToDevice, st));
+		if (n_car) HIP_TRY(hipMemcpyAsync(tb + o_car, mp.carry.data(), n_car * 4, hipMemcpyHostToDevice, st));
 		pl->jk_gen = mp.gen;
 	}
 	const unsigned nbx = (unsigned)((N + 255) / 256);
 	for (unsigned sg = 0; sg < mp.nstage; sg++) {
-		// HBM-bound half of the stage on the caller's stream: class sums of the stage's traces, then its rows
-		if ((rc = tspws_chunks_launch(pl, d_x, ld, N, mp.chunks, mp.row_first, mp.ncls, d_cls, N, st, mp.cls0[sg], mp.cls0[sg + 1], masked_walk()))) return rc;
-		const unsigned r0 = sg * mp.gps * W, r1 = std::min(KM, (sg + 1) * mp.gps) * W;
-		hipLaunchKernelGGL(k_combine_classes, dim3(nbx, r1 - r0), dim3(256), 0, st, (const double *)d_cls, N, (const unsigned *)(d_rp + r0), (const unsigned *)d_cols,
-		                   d_rows + (size_t)r0 * N, N);
+		// HBM-bound half of the stage on the caller's stream: running sums over the stage's traces (snapshots after every run),
+		// then its rows as signed sums of snapshots
+		const unsigned k0 = mp.stage_seg0[sg], nseg = mp.stage_seg0[sg + 1] - k0 - 1;
+		double *d_snap; size_t ldpc;
+		if ((rc = tspws_prefix_launch(pl, d_x, ld, N, d_runs, d_seg + k0, nseg, n_runs, d_car + mp.carry_ptr[sg], mp.carry_ptr[sg + 1] - mp.carry_ptr[sg], &d_snap, &ldpc, st)))
+			return rc;
+		const unsigned g0 = sg * mp.gps, ng = std::min(mp.gps, KM - g0), r0 = g0 * W, r1 = r0 + ng * W;
+		tspws_combine_terms_launch(d_snap, ldpc, d_tp + r0, d_ti, d_tc, r1 - r0, d_rows + (size_t)r0 * N, N, st);
 		HIP_TRY(hipEventRecord(pl->stage_ev[sg], st));
-		// FP64-bound half on the second stream: forward transforms of the stage's rows into per-trace coefficients
+		// FP64-bound half on the second stream: the stage's rows, one slice of ng rows per column
 		HIP_TRY(hipStreamWaitEvent(pl->xf, pl->stage_ev[sg], 0));
-		if ((rc = tspws_forward_parts_f64(pl, d_rows + (size_t)r0 * N, r1 - r0, N, part + (size_t)r0 * pl->npart, pl->xf, nullptr, ScaleRange()))) return rc;
+		FuseOut fz;
+		if (fuse) { fz.accST = planes + (size_t)sg * W * 2 * nc; fz.accPS = fz.accST + nc; fz.stride = 2 * nc; fz.tps = ng; }
+		if ((rc = tspws_forward_parts_f64(pl, d_rows + (size_t)r0 * N, r1 - r0, N, part + (size_t)r0 * pl->npart, pl->xf, fuse ? &fz : nullptr, ScaleRange()))) return rc;
 	}
 	HIP_TRY(hipEventRecord(pl->stage_ev[mp.nstage], pl->xf));
 	// time-domain linear stacks of the replicas (:799-811) while the last transforms run
-	if (C) hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, N, (size_t)W * N);
+	if (C) hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, W, mp.gps);
 	HIP_TRY(hipStreamWaitEvent(st, pl->stage_ev[mp.nstage], 0));
-	// stacks of every column from its KM transformed rows, in group order, weights by the same launch (K = KM, M = the column's traces)
+	// stacks of every column: its plane pairs in stage order + its split partials in group order; weights by the same launch
+	// (K = KM, M = the column's traces)
 	WeightArgs wa;
 	wa.OUT = (double2 *)OUT; wa.out_stride = nc; wa.mode = tspws_weight_mode(p->wu, p->unbiased, KM); wa.K = (double)KM; wa.wu = p->wu; wa.Mv = d_Mv;
 	wa.planes_batch = with_stack ? (int)C : -2; // only the plain stack's ST is reconstructed (ls); the replicas need their weighted coefficients only
-	tspws_launch_accumulate(pl, (const double2 *)part, KM, (double2 *)STr, (double2 *)STr + nc, 1, nullptr, 0, st, W, pl->npart, 2 * nc, nullptr, &wa, ScaleRange(),
-	                        (size_t)W * pl->npart);
+	AccExtra ex;
+	ex.rowmap = d_map; ex.y_fz = 2 * nc;
+	FuseOut fa;
+	if (fuse) { fa.accST = planes; fa.accPS = planes + nc; fa.stride = (size_t)W * 2 * nc; fa.applied = true; }
+	tspws_launch_accumulate(pl, (const double2 *)part, KM, (double2 *)STr, (double2 *)STr + nc, 1, fuse ? &fa : nullptr, mp.nstage, st, W, 0, 2 * nc, nullptr, &wa, ScaleRange(), &ex);
 	if (with_stack) HIP_TRY(hipMemcpyAsync(OUT + (size_t)W * 2 * nc, STr + (size_t)C * 4 * nc, nc * sizeof(double2), hipMemcpyDeviceToDevice, st)); // ST of the plain stack: the last set
 	if ((rc = tspws_hip_inverse(pl, OUT, nrec, xr, s))) return rc;
 	if (C) tspws_epilogue_rows(d_ts_out, xr, N, C, st);

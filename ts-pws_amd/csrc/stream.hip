@@ -128,86 +128,82 @@ __global__ void __launch_bounds__(256) k_partial(const float *__restrict__ x, si
 	}
 }
 
-// The same sums by a FIXED number of workgroups that walk the (chunk, column block) items of the launch, column blocks of a
-// chunk first.  For passes that share the GPU with another kernel (the pipelined masked replicas, resample.hip: the forward
-// transforms of finished groups run beside the streaming of the next ones): an ordinary launch of thousands of short-lived
-// workgroups takes every wave slot and register it can get, and the resident set of the transform kernel (two 80-KB
-// workgroups per CU, 432 of the 512 VGPRs of a SIMD) shrinks whenever one of its workgroups retires -- the transforms ran
-// 2x slower beside such a launch.  One or two walking workgroups per CU hold a fixed 40-80 VGPRs per SIMD for the whole pass.
-template <bool VEC4>
-__global__ void __launch_bounds__(256) k_partial_walk(const float *__restrict__ x, size_t ld, size_t N, const Chunk *__restrict__ chunks,
-                                                      unsigned nchunks, unsigned bx, double *__restrict__ pc, size_t ldpc)
-{
-	const unsigned nitems = nchunks * bx;
-#ifdef WALK_PRIO
-	__builtin_amdgcn_s_setprio(WALK_PRIO);
+// Running sums instead of chunk sums (masked replicas, resample.hip): segment `seg` of the launch walks ITS runs of traces in
+// trace order without ever resetting its accumulators and stores a snapshot after every run -- snap[r] = sum of the segment's
+// traces up to the end of run r (segment 0 starts from the sum of the `ncarry` rows carry[.]: the total of everything before the
+// launch, so its snapshots are prefix sums of the whole ensemble).  A sum over any run of consecutive traces is then a difference
+// of two snapshots (plus a segment base), whatever the number of runs in between: k_combine_terms.  Long sequential walks like the
+// plain pass's (one workgroup per column block and segment), no chunk rows to reduce.
+// grid = bx column blocks x segments; runs of segment s: [seg_first[s], seg_first[s + 1]).
+#ifndef PREFIX_STORE
+#define PREFIX_STORE 0
 #endif
+template <bool VEC4>
+__global__ void __launch_bounds__(256) k_prefix_walk(const float *__restrict__ x, size_t ld, size_t N, const Chunk *__restrict__ runs,
+                                                     const unsigned *__restrict__ seg_first, unsigned bx, double *__restrict__ snap, size_t ldpc,
+                                                     const unsigned *__restrict__ carry, unsigned ncarry)
+{
+	const unsigned seg = blockIdx.x / bx, cb = blockIdx.x - seg * bx;
+	unsigned ri = seg_first[seg];
+	const unsigned rend = seg_first[seg + 1];
+	const size_t col = ((size_t)cb * 256 + threadIdx.x) * 4;
+	if (ri >= rend || col >= N) return;
+	const unsigned rem = (N - col) < 4 ? (unsigned)(N - col) : 4u;
+	double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+	if (seg == 0)
+		for (unsigned k = 0; k < ncarry; k++) {
+			const double *c = snap + (size_t)carry[k] * ldpc + col;
+			a0 += c[0];
+			if (rem > 1) a1 += c[1];
+			if (rem > 2) a2 += c[2];
+			if (rem > 3) a3 += c[3];
+		}
 	if (VEC4) {
-		// The items of this workgroup as ONE sequence of 8-trace batches with two batches in flight: the loads of the next batch
-		// (of the same item or of the next one) are issued before the current batch is added, and a short last batch of a chunk
-		// is a batch like any other (rows past the end re-read the last row and are not added) -- the class chunks of masked
-		// replicas are ~30 traces long, and one load at a time for the remainder cost as many round trips as the full batches.
+		// the plain pass's loop (eight independent 16-byte non-temporal loads in flight, then their additions), run after run; the
+		// last, short batch of a run is a batch like the others (rows past the end re-read the last row and are not added)
 		typedef float v4f __attribute__((ext_vector_type(4)));
-		unsigned item = blockIdx.x;
-		if (item >= nitems) return;
-		const unsigned lane4 = threadIdx.x * 4;
-		auto locate = [&](unsigned it, Chunk &ck, size_t &col) {
-			const unsigned ci = it / bx, cb = it - ci * bx;
-			ck = chunks[ci];
-			col = (size_t)cb * 1024 + lane4;
-			return ci;
-		};
-		Chunk ck; size_t col;
-		unsigned ci = locate(item, ck, col);
-		unsigned t = 0;
-		v4f va[8], vb[8];
-		auto issue = [&](v4f (&v)[8], const Chunk &c, size_t cl, unsigned t0) {
-			const float *src = x + c.t0 * ld + (cl < N ? cl : 0);
-			const unsigned last = c.count - 1u;
+		for (; ri < rend; ri++) {
+			const Chunk ck = runs[ri];
+			const float *src = x + ck.t0 * ld + col;
+			unsigned t = 0;
+			for (; t + 8 <= ck.count; t += 8) {
+				v4f v[8];
 #pragma unroll
-			for (int j = 0; j < 8; j++) {
-				const unsigned r = t0 + (unsigned)j < c.count ? t0 + (unsigned)j : last; // (wave-uniform)
-				v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)r * ld));
-			}
-		};
-		issue(va, ck, col, 0);
-		double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-		for (;;) {
-			// where the batch after this one comes from
-			Chunk nck = ck; size_t ncol = col; unsigned nci = ci, nt = t + 8, nitem = item;
-			bool more = true;
-			if (nt >= ck.count) {
-				nitem = item + gridDim.x;
-				if (nitem < nitems) { nci = locate(nitem, nck, ncol); nt = 0; } else more = false;
-			}
-			if (more) issue(vb, nck, ncol, nt);
-			const unsigned nv = ck.count - t < 8u ? ck.count - t : 8u;
+				for (int j = 0; j < 8; j++) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)(t + j) * ld));
 #pragma unroll
-			for (int j = 0; j < 8; j++)
-				if ((unsigned)j < nv) { a0 += (double)va[j].x; a1 += (double)va[j].y; a2 += (double)va[j].z; a3 += (double)va[j].w; }
-			if (nt == 0 || !more) { // the chunk is complete: its row
-				if (col < N) {
-					double *dst = pc + (size_t)ci * ldpc + col;
-					*(double2 *)dst = make_double2(a0, a1);
-					*(double2 *)(dst + 2) = make_double2(a2, a3);
-				}
-				a0 = a1 = a2 = a3 = 0;
+				for (int j = 0; j < 8; j++) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
 			}
-			if (!more) break;
+			if (t < ck.count) {
+				const unsigned nv = ck.count - t, last = ck.count - 1u;
+				v4f v[8];
 #pragma unroll
-			for (int j = 0; j < 8; j++) va[j] = vb[j];
-			ck = nck; col = ncol; ci = nci; t = nt; item = nitem;
+				for (int j = 0; j < 8; j++) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)(t + (unsigned)j < ck.count ? t + (unsigned)j : last) * ld));
+#pragma unroll
+				for (int j = 0; j < 8; j++)
+					if ((unsigned)j < nv) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
+			}
+#if PREFIX_STORE == 3
+			double *dst = snap + (size_t)(ri + 1 == rend ? ri : (ri & 1u)) * ldpc + col; // timing ablation: the stores hit two rows only (L2 absorbs them)
+#else
+			double *dst = snap + (size_t)ri * ldpc + col;
+#endif
+#if PREFIX_STORE == 2
+			if (ri + 1 == rend) { *(double2 *)dst = make_double2(a0, a1); *(double2 *)(dst + 2) = make_double2(a2, a3); } // timing ablation
+#elif PREFIX_STORE == 1
+			typedef double v2d __attribute__((ext_vector_type(2)));
+			v2d s0 = {a0, a1}, s1 = {a2, a3};
+			__builtin_nontemporal_store(s0, (v2d *)dst);
+			__builtin_nontemporal_store(s1, (v2d *)(dst + 2));
+#else
+			*(double2 *)dst = make_double2(a0, a1);
+			*(double2 *)(dst + 2) = make_double2(a2, a3);
+#endif
 		}
 		return;
 	}
-	for (unsigned item = blockIdx.x; item < nitems; item += gridDim.x) {
-		const unsigned ci = item / bx, cb = item - ci * bx;
-		const Chunk ck = chunks[ci];
-		const size_t col = ((size_t)cb * 256 + threadIdx.x) * 4;
-		if (col >= N) continue;
+	for (; ri < rend; ri++) {
+		const Chunk ck = runs[ri];
 		const float *src = x + ck.t0 * ld + col;
-		double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-		const unsigned rem = (N - col) < 4 ? (unsigned)(N - col) : 4u;
 		for (unsigned t = 0; t < ck.count; t++) {
 			const float *r = src + (size_t)t * ld;
 			a0 += (double)r[0];
@@ -215,11 +211,50 @@ __global__ void __launch_bounds__(256) k_partial_walk(const float *__restrict__ 
 			if (rem > 2) a2 += (double)r[2];
 			if (rem > 3) a3 += (double)r[3];
 		}
-		double *dst = pc + (size_t)ci * ldpc + col;
+		double *dst = snap + (size_t)ri * ldpc + col;
 		dst[0] = a0;
 		if (rem > 1) dst[1] = a1;
 		if (rem > 2) dst[2] = a2;
 		if (rem > 3) dst[3] = a3;
+	}
+}
+
+// P[row][n] = sum_j coef[j] snap[idx[j]][n] over the row's terms [row_ptr[row], row_ptr[row + 1]) -- in list order; no terms: 0
+__global__ void __launch_bounds__(256) k_combine_terms(const double *__restrict__ snap, size_t ldpc, const unsigned *__restrict__ row_ptr,
+                                                       const unsigned *__restrict__ idx, const float *__restrict__ coef, double *__restrict__ P, size_t N)
+{
+	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (n >= N) return;
+	const unsigned row = blockIdx.y;
+	double acc = 0;
+	for (unsigned j = row_ptr[row]; j < row_ptr[row + 1]; j++) acc = fma((double)coef[j], snap[(size_t)idx[j] * ldpc + n], acc);
+	P[(size_t)row * N + n] = acc;
+}
+
+// host side of the two kernels above: launches on device-resident tables (the caller uploaded them)
+int tspws_prefix_launch(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, const Chunk *d_runs, const unsigned *d_seg_first, unsigned nseg,
+                        size_t nruns_total, const unsigned *d_carry, unsigned ncarry, double **d_snap, size_t *ldpc_out, hipStream_t st)
+{
+	const size_t ldpc = (N + 3) & ~(size_t)3;
+	void *v = nullptr;
+	int rc;
+	if ((rc = scratch(p, SCR_CHUNK, std::max<size_t>(nruns_total * ldpc * sizeof(double), 16), &v))) return rc;
+	*d_snap = (double *)v; *ldpc_out = ldpc;
+	if (!nseg) return 0;
+	const unsigned bx = (unsigned)((N + 1023) / 1024);
+	const bool vec = (N % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x & 15) == 0);
+	if (vec) hipLaunchKernelGGL(k_prefix_walk<true>, dim3(bx * nseg), dim3(256), 0, st, d_x, ld, N, d_runs, d_seg_first, bx, (double *)v, ldpc, d_carry, ncarry);
+	else hipLaunchKernelGGL(k_prefix_walk<false>, dim3(bx * nseg), dim3(256), 0, st, d_x, ld, N, d_runs, d_seg_first, bx, (double *)v, ldpc, d_carry, ncarry);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+void tspws_combine_terms_launch(const double *d_snap, size_t ldpc, const unsigned *d_row_ptr, const unsigned *d_idx, const float *d_coef, unsigned nrows,
+                                double *d_P, size_t N, hipStream_t st)
+{
+	for (unsigned r0 = 0; r0 < nrows; r0 += 65535) {
+		const unsigned ny = std::min(nrows - r0, 65535u);
+		hipLaunchKernelGGL(k_combine_terms, dim3((unsigned)((N + 255) / 256), ny), dim3(256), 0, st, d_snap, ldpc, d_row_ptr + r0, d_idx, d_coef, d_P + (size_t)r0 * N, N);
 	}
 }
 
@@ -289,7 +324,7 @@ int tspws_chunks_upload(tspws_hip_plan *p, const std::vector<Chunk> &chunks, con
 // into the plan's table block (the host copies give the launch geometry).
 int tspws_chunks_launch(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, const std::vector<Chunk> &chunks,
                         const std::vector<unsigned> &row_first, unsigned rows, double *d_P, size_t ldP, hipStream_t st,
-                        unsigned row_begin, unsigned row_end, unsigned walk)
+                        unsigned row_begin, unsigned row_end)
 {
 	row_end = std::min(row_end, rows);
 	const size_t nck = chunks.size();
@@ -304,22 +339,6 @@ int tspws_chunks_launch(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N
 	const unsigned bx = (unsigned)((N + 1023) / 1024);
 	const bool vec = (N % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x & 15) == 0);
 	const size_t ck0 = row_first[row_begin], ck1 = row_first[row_end]; // chunks are sorted by destination row
-	if (walk && ck1 - ck0 <= 0xFFFFFFFFull / std::max(1u, bx)) {
-		// a fixed number of walking workgroups (see k_partial_walk), chunk rows then reduced per destination as below
-		p->last_stream_launches = 1;
-		const unsigned nck_l = (unsigned)(ck1 - ck0);
-		if (nck_l) {
-			const unsigned grid = (unsigned)std::min<size_t>((size_t)nck_l * bx, walk);
-			if (vec) hipLaunchKernelGGL(k_partial_walk<true>, dim3(grid), dim3(256), 0, st, d_x, ld, N, (const Chunk *)(d_chunks + ck0), nck_l, bx, (double *)d_pc + ck0 * ldpc, ldpc);
-			else hipLaunchKernelGGL(k_partial_walk<false>, dim3(grid), dim3(256), 0, st, d_x, ld, N, (const Chunk *)(d_chunks + ck0), nck_l, bx, (double *)d_pc + ck0 * ldpc, ldpc);
-		}
-		for (unsigned r0 = row_begin; r0 < row_end; r0 += 65535) {
-			const unsigned ny = std::min(row_end - r0, 65535u);
-			hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((N + 255) / 256), ny), dim3(256), 0, st, (const double *)d_pc, ldpc, d_rf + r0, d_P + (size_t)r0 * ldP, ldP, N);
-		}
-		HIP_TRY(hipGetLastError());
-		return 0;
-	}
 	// every destination row fed by exactly ONE chunk: the streaming kernel writes the rows themselves, no chunk reduction
 	bool direct = ck1 - ck0 == (size_t)(row_end - row_begin) && ck1 - ck0 <= 65535 && (!vec || ldP % 2 == 0);
 	for (unsigned r = row_begin; r < row_end && direct; r++) direct = row_first[r + 1] - row_first[r] == 1;

@@ -112,6 +112,13 @@ struct WeightArgs {
 	int planes_batch = -1;    // -1: every stack's ST / PS planes are written; -2: none (only OUT is wanted); b >= 0: those of stack b only
 };
 
+// optional geometry of tspws_launch_accumulate for stacks whose transformed traces / slice planes are interleaved in memory
+struct AccExtra {
+	size_t trace_stride = 0;          // distance of consecutive transformed traces in `part` (0: npart)
+	size_t y_fz = 0;                  // slice planes of stack b start b * y_fz further
+	const unsigned *rowmap = nullptr; // device table [nbatch][nb]: transformed trace t of stack b is trace rowmap[b nb + t] of `part`
+};
+
 enum { SCR_Y = 0, SCR_PART, SCR_XT, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_JKTAB, SCR_N };
 
 struct OctDesc; // inverse work items (inv_poly.h)
@@ -277,7 +284,7 @@ int  tspws_stacks_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, size_t l
 // k_accumulate_parts for nb transformed traces (nbatch independent stacks side by side: y_part / y_stack apart)
 void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb, double2 *ST, double2 *PS, int zero_first, const FuseOut *fz,
                              unsigned nslices, hipStream_t st, unsigned nbatch, size_t y_part, size_t y_stack, const TlTable *tl, const WeightArgs *wa,
-                             ScaleRange rg, size_t trace_stride = 0); // trace_stride: distance of consecutive transformed traces of a stack in `part` (0: npart)
+                             ScaleRange rg, const AccExtra *ex = nullptr);
 bool tspws_fused_forward(const tspws_hip_plan *p);        // the few-trace forward kernel stacks some scales in registers
 bool tspws_many_trace_path(const tspws_hip_plan *p, size_t ntr); // a batch this size goes to the trace-lane kernel
 size_t tspws_part_budget_bytes();
@@ -302,7 +309,12 @@ int  tspws_chunks_upload(tspws_hip_plan *p, const std::vector<Chunk> &chunks, co
                          bool cached);
 int  tspws_chunks_launch(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, const std::vector<Chunk> &chunks,
                          const std::vector<unsigned> &row_first, unsigned rows, double *d_P, size_t ldP, hipStream_t st,
-                         unsigned row_begin = 0, unsigned row_end = ~0u, unsigned walk = 0); // walk: a fixed number of walking workgroups (k_partial_walk)
+                         unsigned row_begin = 0, unsigned row_end = ~0u);
+// running sums with snapshots after every run of traces + rows as signed sums of snapshots (masked replicas): see k_prefix_walk
+int  tspws_prefix_launch(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, const Chunk *d_runs, const unsigned *d_seg_first, unsigned nseg,
+                         size_t nruns_total, const unsigned *d_carry, unsigned ncarry, double **d_snap, size_t *ldpc, hipStream_t st);
+void tspws_combine_terms_launch(const double *d_snap, size_t ldpc, const unsigned *d_row_ptr, const unsigned *d_idx, const float *d_coef, unsigned nrows,
+                                double *d_P, size_t N, hipStream_t st);
 unsigned tspws_chunk_len_for(size_t N, size_t mtr);
 // stack.hip
 bool tspws_is_two_stage(const t_tsPWS *p, size_t mtr_global);
