@@ -305,6 +305,25 @@ def test_jackknife_vs_oracle_many_traces(lib):
     assert z["rc"] == 0 and not z["jk_ts"].any() and z["tsPWS"].any()
 
 
+@pytest.mark.parametrize("env", [dict(), dict(TSPWS_JK_DIRECT="0"), dict(TSPWS_JK_STAGES="1"), dict(TSPWS_JK_STAGES="5"), dict(TSPWS_JK_PIPELINE="0")])
+def test_masked_replica_engines_agree(env):
+    """The streaming side of the masked replicas has three forms: rows straight from the walk (a running sum per column, <= 16
+    columns), running sums with snapshots + signed sums of snapshots (any number of columns), and the class sums of the serial
+    call (TSPWS_JK_PIPELINE=0); the transforms run in 1 .. Kmax stages.  Every combination against the oracle's tspws_main:
+    10 replicas + the plain stack (direct walk by default), 21 replicas (n = 7, d = 2: 22 columns, the snapshot form), a replica
+    that loses a whole group's worth of traces, two-stage random subsampling (masks from rand(): same engine).  Each case in a
+    fresh process: the switches are read once per process."""
+    import subprocess
+    import sys as _sys
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "masked_engines.py")], capture_output=True, text=True,
+                       timeout=900, env=e)
+    line = [l for l in r.stdout.splitlines() if l.startswith("MASKED_ENGINES")]
+    assert line, r.stdout[-3000:] + r.stderr[-3000:]
+    assert float(line[0].split()[1]) < TOL32, line[0]
+
+
 # ------------------------------------------------------- device-resident / sharded path
 @pytest.mark.parametrize("kw", [dict(Kmax=10, unbiased=1), dict(), dict(type=-3, Kmax=4)])
 def test_device_path_and_shards(lib, torch, kw):

@@ -318,6 +318,13 @@ struct MaskedPlan {
 	std::vector<unsigned> trow_ptr;     // rows as signed sums of snapshots: [KM W + 1] pointers, rows in stage / column / group order
 	std::vector<unsigned> tidx;
 	std::vector<float> tcoef;
+	// few columns (W <= tspws_rows_walk_wmax()): the rows straight from the walk -- per run the columns it belongs to and the columns
+	// whose group ends with it (+ the rows those sums become)
+	// two halves: half h walks the runs with index = h (mod 2) and stores its share of every row
+	bool direct = false, unwritten = false; // unwritten: a half never stores some row (no run of its own in that group): the half blocks are cleared first
+	std::vector<RunDesc> rdesc[2];      // the half's runs, stage after stage
+	std::vector<unsigned> half_run0[2]; // per stage: the half's first run in rdesc[h] (nstage + 1)
+	std::vector<unsigned> flush_rows;   // flush destinations of both halves (RunDesc::frow points here)
 	std::vector<unsigned> rowmap;       // [W][KM]: row of (column, group)
 	std::vector<double> Mv;             // trace count per column (replicas: selected traces; plain stack: mtr)
 	unsigned row_of(unsigned g, unsigned c) const
@@ -385,6 +392,38 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 		}
 	}
 	const unsigned nr = (unsigned)mp.runs.size();
+	mp.direct = W <= tspws_rows_walk_wmax() && W <= 32;
+	mp.flush_rows.clear(); mp.unwritten = false;
+	for (int h = 0; h < 2; h++) { mp.rdesc[h].clear(); mp.half_run0[h].assign(nstage + 1, 0); }
+	if (mp.direct) {
+		std::vector<char> written((size_t)2 * KM * W, 0);
+		for (int h = 0; h < 2; h++) {
+			unsigned sg_done = 0;
+			for (unsigned r = (unsigned)h; r < nr; r += 2) {
+				while (sg_done <= run_stage[r]) mp.half_run0[h][sg_done++] = (unsigned)mp.rdesc[h].size(); // (first run of every stage up to this one)
+				RunDesc d;
+				memset(&d, 0, sizeof d);
+				d.t0 = mp.runs[r].t0; d.count = mp.runs[r].count; d.frow = (unsigned)mp.flush_rows.size();
+				const unsigned *sr = &sig[mp.runs[r].t0 * W];
+				for (unsigned c = 0; c < W; c++) {
+					if (sr[c] == SIG_DELETED) continue;
+					d.member |= 1u << c;
+					// column c's group ends -- for this half -- with this run when the half's next run that belongs to c has another group
+					unsigned q = r + 2;
+					while (q < nr && sig[mp.runs[q].t0 * W + c] == SIG_DELETED) q += 2;
+					if (q >= nr || sig[mp.runs[q].t0 * W + c] != sr[c]) {
+						d.flush |= 1u << c;
+						const unsigned row = mp.row_of(std::min(sr[c], KM - 1), c);
+						mp.flush_rows.push_back(row);
+						written[(size_t)h * KM * W + row] = 1;
+					}
+				}
+				mp.rdesc[h].push_back(d);
+			}
+			while (sg_done <= nstage) mp.half_run0[h][sg_done++] = (unsigned)mp.rdesc[h].size();
+		}
+		for (char w : written) if (!w) mp.unwritten = true;
+	}
 	// segments: a stage's runs in ~256 / (column blocks) pieces of similar trace counts, each walked by its own workgroups
 	static int seg_wgs = -1; // workgroups the streaming side aims at per stage (sweeps: TSPWS_JK_SEGWG)
 	if (seg_wgs < 0) { const char *e = getenv("TSPWS_JK_SEGWG"); seg_wgs = e ? std::max(1, atoi(e)) : 256; }
@@ -522,12 +561,19 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	double *OUT = (double *)v, *STr = OUT + (size_t)nrec * 2 * nc, *xr = STr + (size_t)W * 4 * nc;
 	// table block: runs (16-byte records) | trace counts | term pointers | term snapshots | term coefficients | row map | segments | carries
 	const size_t n_runs = mp.runs.size(), n_tp = mp.trow_ptr.size(), n_t = mp.tidx.size(), n_map = mp.rowmap.size(), n_seg = mp.seg_first.size(),
-	             n_car = mp.carry.size();
-	const size_t o_mv = n_runs * sizeof(Chunk), o_tp = o_mv + W * sizeof(double), o_ti = o_tp + n_tp * 4, o_tc = o_ti + n_t * 4, o_map = o_tc + n_t * 4,
-	             o_seg = o_map + n_map * 4, o_car = o_seg + n_seg * 4, tab_bytes = o_car + std::max<size_t>(n_car, 1) * 4;
+	             n_car = mp.carry.size(), n_rd0 = mp.rdesc[0].size(), n_rd1 = mp.rdesc[1].size(), n_rd = n_rd0 + n_rd1, n_fr = mp.flush_rows.size();
+	const size_t o_mv = n_runs * sizeof(Chunk), o_rd = o_mv + W * sizeof(double), o_tp = o_rd + n_rd * sizeof(RunDesc), o_ti = o_tp + n_tp * 4, o_tc = o_ti + n_t * 4,
+	             o_map = o_tc + n_t * 4, o_seg = o_map + n_map * 4, o_car = o_seg + n_seg * 4, o_fr = o_car + n_car * 4, tab_bytes = o_fr + std::max<size_t>(n_fr, 1) * 4;
 	if ((rc = scratch(pl, SCR_JKTAB, tab_bytes, &v))) return rc;
 	char *tb = (char *)v;
 	const Chunk *d_runs = (const Chunk *)tb;
+	const RunDesc *d_rd = (const RunDesc *)(tb + o_rd);
+	const unsigned *d_fr = (const unsigned *)(tb + o_fr);
+	double *d_half = nullptr, *d_carryblk = nullptr; // direct walk: the halves' rows [2][nrow][N], their live per-column sums between stages [2][W][N]
+	if (mp.direct) {
+		if ((rc = scratch(pl, SCR_CLS, ((size_t)2 * nrow + 2 * W) * N * sizeof(double), &v))) return rc;
+		d_half = (double *)v; d_carryblk = d_half + (size_t)2 * nrow * N;
+	}
 	double *d_Mv = (double *)(tb + o_mv);
 	const unsigned *d_tp = (const unsigned *)(tb + o_tp), *d_ti = (const unsigned *)(tb + o_ti), *d_map = (const unsigned *)(tb + o_map),
 	               *d_seg = (const unsigned *)(tb + o_seg), *d_car = (const unsigned *)(tb + o_car);
@@ -556,18 +602,35 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 		HIP_TRY(hipMemcpyAsync(tb + o_map, mp.rowmap.data(), n_map * 4, hipMemcpyHostToDevice, st));
 		HIP_TRY(hipMemcpyAsync(tb + o_seg, mp.seg_first.data(), n_seg * 4, hipMemcpyHostToDevice, st));
 		if (n_car) HIP_TRY(hipMemcpyAsync(tb + o_car, mp.carry.data(), n_car * 4, hipMemcpyHostToDevice, st));
+		if (n_rd0) HIP_TRY(hipMemcpyAsync(tb + o_rd, mp.rdesc[0].data(), n_rd0 * sizeof(RunDesc), hipMemcpyHostToDevice, st));
+		if (n_rd1) HIP_TRY(hipMemcpyAsync(tb + o_rd + n_rd0 * sizeof(RunDesc), mp.rdesc[1].data(), n_rd1 * sizeof(RunDesc), hipMemcpyHostToDevice, st));
+		if (n_fr) HIP_TRY(hipMemcpyAsync(tb + o_fr, mp.flush_rows.data(), n_fr * 4, hipMemcpyHostToDevice, st));
 		pl->jk_gen = mp.gen;
 	}
 	const unsigned nbx = (unsigned)((N + 255) / 256);
+	bool have_carry = false;
+	static int no_direct = -1; // TSPWS_JK_DIRECT=0: the snapshot form also for few columns (tests, A/B)
+	if (no_direct < 0) { const char *e = getenv("TSPWS_JK_DIRECT"); no_direct = (e && *e == '0') ? 1 : 0; }
 	for (unsigned sg = 0; sg < mp.nstage; sg++) {
 		// HBM-bound half of the stage on the caller's stream: running sums over the stage's traces (snapshots after every run),
 		// then its rows as signed sums of snapshots
 		const unsigned k0 = mp.stage_seg0[sg], nseg = mp.stage_seg0[sg + 1] - k0 - 1;
-		double *d_snap; size_t ldpc;
-		if ((rc = tspws_prefix_launch(pl, d_x, ld, N, d_runs, d_seg + k0, nseg, n_runs, d_car + mp.carry_ptr[sg], mp.carry_ptr[sg + 1] - mp.carry_ptr[sg], &d_snap, &ldpc, st)))
+		double *d_snap = nullptr; size_t ldpc = 0;
+		if (mp.direct && !no_direct) {
+			// few columns: the rows themselves from the walk (a running sum per column in registers, two halves of the runs; k_rows_walk)
+			if (sg == 0 && mp.unwritten) HIP_TRY(hipMemsetAsync(d_half, 0, (size_t)2 * nrow * N * sizeof(double), st));
+			const unsigned a0 = mp.half_run0[0][sg], a1 = mp.half_run0[0][sg + 1], b0 = mp.half_run0[1][sg], b1 = mp.half_run0[1][sg + 1];
+			if (a1 > a0 || b1 > b0) {
+				if ((rc = tspws_rows_walk_launch(d_x, ld, N, d_rd + a0, d_rd + n_rd0 + b0, a1 - a0, b1 - b0, W, d_fr, d_half, (size_t)nrow * N, d_carryblk, (size_t)W * N,
+				                                 have_carry ? 1 : 0, sg + 1 < mp.nstage ? 1 : 0, st))) return rc;
+				have_carry = true;
+			}
+		} else if ((rc = tspws_prefix_launch(pl, d_x, ld, N, d_runs, d_seg + k0, nseg, n_runs, d_car + mp.carry_ptr[sg], mp.carry_ptr[sg + 1] - mp.carry_ptr[sg], &d_snap,
+		                                     &ldpc, st)))
 			return rc;
 		const unsigned g0 = sg * mp.gps, ng = std::min(mp.gps, KM - g0), r0 = g0 * W, r1 = r0 + ng * W;
-		tspws_combine_terms_launch(d_snap, ldpc, d_tp + r0, d_ti, d_tc, r1 - r0, d_rows + (size_t)r0 * N, N, st);
+		if (mp.direct && !no_direct) tspws_add_halves_launch(d_half + (size_t)r0 * N, d_half + ((size_t)nrow + r0) * N, d_rows + (size_t)r0 * N, (size_t)(r1 - r0) * N, st);
+		else tspws_combine_terms_launch(d_snap, ldpc, d_tp + r0, d_ti, d_tc, r1 - r0, d_rows + (size_t)r0 * N, N, st);
 		HIP_TRY(hipEventRecord(pl->stage_ev[sg], st));
 		// FP64-bound half on the second stream: the stage's rows, one slice of ng rows per column
 		HIP_TRY(hipStreamWaitEvent(pl->xf, pl->stage_ev[sg], 0));

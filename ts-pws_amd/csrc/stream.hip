@@ -219,6 +219,130 @@ __global__ void __launch_bounds__(256) k_prefix_walk(const float *__restrict__ x
 	}
 }
 
+// Few columns (<= ROWS_WMAX: the jackknife of cfg4 has 10 replicas + the plain stack): the rows THEMSELVES from the walk.  A
+// workgroup owns 1024 samples of every trace of ITS runs and keeps one running sum per column in registers; after every run of
+// traces (one signature) the run's sum is added to the columns the run belongs to (`member`, a bit per column -- uniform
+// branches, once per ~30 traces, not once per trace: the round-3 kernel that added every trace to every column was VALU-bound
+// at 2.4 ms), and a column whose group ends there stores its sum as that group's row and starts over (`flush`).  No snapshots
+// (their 326 MB of writes cost the prefix walk 0.25 ms), no combining pass over ~10 snapshots per row.
+// Two workgroups per column block (grid.y = half): half h walks the runs with index = h (mod 2) -- 128 column blocks alone would
+// leave half the CUs without a stream (1.05 ms for the plain pass at 128 workgroups) -- into its own row block; k_add_halves
+// adds the two.  Both halves flush a column at the same point of the run sequence (the flush of run r sits on run r - 1 in the
+// other half's list).  Stages: the live sums of a half travel through its carry block (W rows) from one launch to the next.
+#define ROWS_WMAX 16
+template <bool VEC4>
+__global__ void __launch_bounds__(256) k_rows_walk(const float *__restrict__ x, size_t ld, size_t N, const RunDesc *__restrict__ runs0,
+                                                   const RunDesc *__restrict__ runs1, unsigned n0, unsigned n1, unsigned W,
+                                                   const unsigned *__restrict__ flush_rows, double *__restrict__ rows, size_t half_stride,
+                                                   double *__restrict__ carry, size_t carry_stride, int carry_in, int carry_out)
+{
+	const unsigned h = blockIdx.y;
+	const RunDesc *runs = h ? runs1 : runs0;
+	const unsigned nr = h ? n1 : n0;
+	rows += (size_t)h * half_stride; carry += (size_t)h * carry_stride;
+	const size_t col = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+	if (col >= N) return;
+	const unsigned rem = (N - col) < 4 ? (unsigned)(N - col) : 4u;
+	double P[ROWS_WMAX][4];
+#pragma unroll
+	for (int c = 0; c < ROWS_WMAX; c++) {
+#pragma unroll
+		for (int k = 0; k < 4; k++) P[c][k] = 0;
+		if (carry_in && (unsigned)c < W) {
+			const double *s = carry + (size_t)c * N + col;
+#pragma unroll
+			for (int k = 0; k < 4; k++) if ((unsigned)k < rem) P[c][k] = s[k];
+		}
+	}
+	typedef float v4f __attribute__((ext_vector_type(4)));
+	for (unsigned ri = 0; ri < nr; ri++) {
+		const RunDesc rd = runs[ri];
+		const float *src = x + rd.t0 * ld + col;
+		double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+		if (VEC4) { // the plain pass's loop: eight independent 16-byte non-temporal loads in flight, then their additions
+			unsigned t = 0;
+			for (; t + 8 <= rd.count; t += 8) {
+				v4f v[8];
+#pragma unroll
+				for (int j = 0; j < 8; j++) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)(t + j) * ld));
+#pragma unroll
+				for (int j = 0; j < 8; j++) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
+			}
+			if (t < rd.count) { // the remainder as one batch: rows past the end re-read the last row and are not added
+				const unsigned nv = rd.count - t, last = rd.count - 1u;
+				v4f v[8];
+#pragma unroll
+				for (int j = 0; j < 8; j++) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)(t + (unsigned)j < rd.count ? t + (unsigned)j : last) * ld));
+#pragma unroll
+				for (int j = 0; j < 8; j++)
+					if ((unsigned)j < nv) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
+			}
+		} else {
+			for (unsigned t = 0; t < rd.count; t++) {
+				const float *r = src + (size_t)t * ld;
+				a0 += (double)r[0];
+				if (rem > 1) a1 += (double)r[1];
+				if (rem > 2) a2 += (double)r[2];
+				if (rem > 3) a3 += (double)r[3];
+			}
+		}
+		unsigned fr = rd.frow;
+#pragma unroll
+		for (int c = 0; c < ROWS_WMAX; c++) {
+			if ((rd.member >> c) & 1u) { P[c][0] += a0; P[c][1] += a1; P[c][2] += a2; P[c][3] += a3; } // (wave-uniform)
+			if ((rd.flush >> c) & 1u) {
+				double *dst = rows + (size_t)flush_rows[fr++] * N + col;
+				if (VEC4) { *(double2 *)dst = make_double2(P[c][0], P[c][1]); *(double2 *)(dst + 2) = make_double2(P[c][2], P[c][3]); }
+				else {
+#pragma unroll
+					for (int k = 0; k < 4; k++) if ((unsigned)k < rem) dst[k] = P[c][k];
+				}
+#pragma unroll
+				for (int k = 0; k < 4; k++) P[c][k] = 0;
+			}
+		}
+	}
+	if (carry_out) {
+#pragma unroll
+		for (int c = 0; c < ROWS_WMAX; c++)
+			if ((unsigned)c < W) {
+				double *d = carry + (size_t)c * N + col;
+#pragma unroll
+				for (int k = 0; k < 4; k++) if ((unsigned)k < rem) d[k] = P[c][k];
+			}
+	}
+}
+
+// out[i] = a[i] + b[i]  (the two halves of a stage's rows)
+__global__ void __launch_bounds__(256) k_add_halves(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out, size_t n)
+{
+	const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+	if (i + 1 < n) { const double2 u = *(const double2 *)(a + i), v = *(const double2 *)(b + i); *(double2 *)(out + i) = make_double2(u.x + v.x, u.y + v.y); }
+	else if (i < n) out[i] = a[i] + b[i];
+}
+
+// one stage of the direct walk: runs [q0[h], q1[h]) of half h's list; the halves' rows go to d_half + h * half_stride
+int tspws_rows_walk_launch(const float *d_x, size_t ld, size_t N, const RunDesc *d_runs0, const RunDesc *d_runs1, unsigned n0, unsigned n1, unsigned W,
+                           const unsigned *d_flush_rows, double *d_half, size_t half_stride, double *d_carry, size_t carry_stride, int carry_in,
+                           int carry_out, hipStream_t st)
+{
+	if (W > ROWS_WMAX) return fail(TSPWS_E_ARG, "rows_walk: too many columns");
+	const unsigned grid = (unsigned)((N + 1023) / 1024);
+	const bool vec = (N % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x & 15) == 0);
+	if (vec) hipLaunchKernelGGL(k_rows_walk<true>, dim3(grid, 2), dim3(256), 0, st, d_x, ld, N, d_runs0, d_runs1, n0, n1, W, d_flush_rows, d_half, half_stride, d_carry,
+	                            carry_stride, carry_in, carry_out);
+	else hipLaunchKernelGGL(k_rows_walk<false>, dim3(grid, 2), dim3(256), 0, st, d_x, ld, N, d_runs0, d_runs1, n0, n1, W, d_flush_rows, d_half, half_stride, d_carry,
+	                        carry_stride, carry_in, carry_out);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+void tspws_add_halves_launch(const double *a, const double *b, double *out, size_t n, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_add_halves, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, st, a, b, out, n);
+}
+unsigned tspws_rows_walk_wmax() { return ROWS_WMAX; }
+
 // P[row][n] = sum_j coef[j] snap[idx[j]][n] over the row's terms [row_ptr[row], row_ptr[row + 1]) -- in list order; no terms: 0
 __global__ void __launch_bounds__(256) k_combine_terms(const double *__restrict__ snap, size_t ldpc, const unsigned *__restrict__ row_ptr,
                                                        const unsigned *__restrict__ idx, const float *__restrict__ coef, double *__restrict__ P, size_t N)
