@@ -42,6 +42,9 @@ check(dict(Kmax=7, unbiased=1, jackknife_n=3, jackknife_d=1), X[:61], times[:61]
 t2 = times.copy()
 t2[50:450] = 1262304000 + 86400 * 200
 check(dict(Kmax=8, jackknife_n=5, jackknife_d=1), X, np.sort(t2))
+# a replica with fewer traces than groups (3 traces, 8 groups): most of its groups are empty -- rows nobody stores
+t3 = np.concatenate([np.full(17, 1262304000 + 86400 * 10), np.full(3, 1262304000 + 86400 * 300)]).astype(np.int64)
+check(dict(Kmax=8, jackknife_n=2, jackknife_d=1), X[:20], t3)
 # N not a multiple of 4: the scalar form of the walk
 check(dict(Kmax=4, jackknife_n=4, jackknife_d=1), abi.synth_traces(90, 1501, seed=5), times[:90])
 # two-stage random subsampling runs on the same engine (masks from libc rand(): same seed on both sides)

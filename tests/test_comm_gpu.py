@@ -207,3 +207,21 @@ def test_torch_nccl_backend_reduces_the_plan_buffers(lib, torch):
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
+
+
+def test_device_list_call_fails_after_the_prologue_like_the_reference(lib, monkeypatch):
+    """A frame that cannot be built (J resolves to 0) fails with 4 AFTER fold / mean removal have rewritten the traces
+    (/root/reference/src/ts_pws1f_lib.c:71-88, :159-169, :199-204); the several-device call must leave the same traces behind as the
+    single-device call and the oracle."""
+    kw = dict(type=-3, s0=4.823433067845736, fmin=0.04796741189352445, wu=1.5, Kmax=12, lrm=1)
+    X = abi.synth_traces(9, 1000, seed=3) + np.float32(0.25)
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), X)
+    assert want["rc"] == 4 and want["params"].J == 0
+    monkeypatch.setenv("TSPWS_DEVICES", "0,0")
+    try:
+        got = abi.run_main(lib.tspws_main, abi.default_params(**kw), X)
+        assert got["rc"] == 4
+        assert abi.relerr(got["sigall"], want["sigall"]) < 1e-6 and not np.array_equal(got["sigall"], X)
+        assert not got["ls"].any() and not got["tsPWS"].any()
+    finally:
+        lib.tspws_main_release()
