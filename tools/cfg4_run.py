@@ -28,6 +28,10 @@ if os.environ.get("TSPWS_FWD_CLASSES"):  # -DFL_ABLATE=1 builds: switch classes 
     lib.tspws_hip_fwd_ablate()
 
 
+if os.environ.get("TSPWS_INV_CLASSES"):  # likewise for the octave classes of k_inv_poly
+    lib.tspws_hip_inv_ablate()
+
+
 def jk():
     # the stack and its ten replicas from ONE pass over the traces
     pl.stack_jackknife(X, sel)

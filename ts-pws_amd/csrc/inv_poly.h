@@ -39,6 +39,18 @@
 __device__ unsigned inv_class_mask = 0x7fu;   // debug builds: bit c = the octaves of lanes-per-phase class log2(DL) = c run (6: D >= 64); TSPWS_INV_CLASSES
 #endif
 
+// LDS-staged form for the finely decimated octaves (D < 64; round 4).  There a wave's lanes are (output group, phase) and the
+// coefficient windows of adjacent groups start R = 8 coefficients apart: a per-lane 16-byte load touches up to 64 different
+// cache lines per wave (D = 1), and with two coefficient sets + the tap that is ~144 address-path cycles per tap step against
+// 128 FMA cycles on each of the four SIMDs -- the batched reconstructions of the jackknife (cfg4: 12 at once) ran at 27 % of the
+// FP64 pipe.  Here each wave copies the coefficient window of a block of INV_QB tap steps into its own slab of LDS with coalesced
+// loads (row e at e + e / 8: the sliding windows of the lanes then fall on distinct banks) and the steps read it from there.
+// Same additions in the same order as the per-lane form: bit-identical outputs.
+#define INV_QB 32                               /* tap steps per staged block */
+#define INV_WROWS (64 * INV_R + INV_QB + 16)    /* rows of a wave's window: <= 512 outputs + the block's steps + the sliding window + shifts */
+#define INV_WPAD(e) ((e) + ((e) >> 3))
+#define INV_SLAB (INV_WROWS + INV_WROWS / 8 + 2)
+
 struct OctDesc {
 	unsigned s0, nv;        // first scale, voices
 	unsigned D, Ns;
@@ -51,7 +63,7 @@ struct OctDesc {
 
 // GEN = the three-frame form for octaves whose D does not divide N (its own instantiation: the masked loads and 64-bit
 // index arithmetic would otherwise cost the common case registers and time; the host launches the two classes separately)
-template <int NREC, bool GEN>
+template <int NREC, bool GEN, bool LDSW = false>
 __global__ void __launch_bounds__(256) k_inv_poly(const double2 *__restrict__ Y, size_t ncoef, unsigned N, const ScaleDesc *__restrict__ sc,
                                                   const OctDesc *__restrict__ oc, unsigned noct, const double2 *__restrict__ wd,
                                                   double *__restrict__ obuf, size_t slot_stride, unsigned total_waves, size_t y_coef,
@@ -85,7 +97,75 @@ __global__ void __launch_bounds__(256) k_inv_poly(const double2 *__restrict__ Y,
 #pragma unroll
 		for (int r = 0; r < R; r++) acc[c][r] = 0;
 
-	if constexpr (GEN) {
+	if constexpr (LDSW) {
+		// (this instantiation is launched for the waves of the octaves with D <= INV_LDS_MAXD whose D divides N only)
+		__shared__ __attribute__((aligned(16))) double2 slab_all[4][NREC][INV_SLAB];
+		double2 (*slab)[INV_SLAB] = slab_all[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+		const unsigned GW = 64u >> o.logDL;
+		for (unsigned v = 0; v < o.nv; v++) {
+			const ScaleDesc d = sc[o.s0 + v];
+			const double2 *ws = wd + d.tap_off;
+			const double2 *ys = Y + d.coef_off;
+			// n - cd = a D + rho for n = n0 + (gR + r) D
+			const long long t = (long long)n0c - d.cd;
+			long long a = t >= 0 ? t / D : -((-t + D - 1) / D);
+			const unsigned rho = (unsigned)(t - a * (long long)D);
+			const unsigned mu = rho ? D - rho : 0;
+			a += (long long)g * R + (rho ? 1 : 0);
+			// the wave's window starts at the coefficient of its first group's phase 0 (the smallest index any lane uses)
+			const long long tb = -(long long)d.cd;
+			const long long ab = (tb >= 0 ? tb / D : -((-tb + D - 1) / D)) + (long long)(gb * GW) * R;
+			const unsigned off = (unsigned)(a - ab);   // <= GW R + 1
+			const double gD = d.gain * (double)D;
+			unsigned l = mu;
+			for (unsigned q0 = 0; q0 < d.Q; q0 += INV_QB) {
+				const unsigned nq = d.Q - q0 < (unsigned)INV_QB ? d.Q - q0 : (unsigned)INV_QB;
+				const unsigned nq8 = (nq + R - 1) / R * R;
+				const unsigned need = GW * R + 2 + nq8 + R; // rows the block's steps can touch
+				long long sm = (ab + (long long)q0) % (long long)Ns;
+				if (sm < 0) sm += Ns;
+				const unsigned smu = (unsigned)sm;
+				const bool one_wrap = Ns >= need; // (the window wraps at most once: one conditional subtraction instead of a software division per row)
+				// (the previous block's reads of this slab are complete: LDS operations of a wave execute in order)
+				for (unsigned e = lane; e < need; e += 64) {
+					unsigned row = smu + e;
+					if (one_wrap) { if (row >= Ns) row -= Ns; } else row %= Ns;
+#pragma unroll
+					for (int c = 0; c < NREC; c++) slab[c][INV_WPAD(e)] = ys[(size_t)c * ncoef + row];
+				}
+				double2 yw[NREC][R];
+#pragma unroll
+				for (int j = 0; j < R - 1; j++) {
+#pragma unroll
+					for (int c = 0; c < NREC; c++) yw[c][j] = slab[c][INV_WPAD(off + (unsigned)j)];
+				}
+				for (unsigned qq = 0; qq < nq8; qq += R) {
+					// the block's R taps first (independent loads; taps of steps past the block / past the filter are exact zeros and add
+					// nothing), then its window rows, then straight-line FMAs
+					double2 tp[R];
+#pragma unroll
+					for (int u = 0; u < R; u++) {
+						const unsigned lu = l + (unsigned)u * D;
+						const bool on = qq + (unsigned)u < nq && lu < d.L;
+						tp[u] = ws[on ? lu : 0u];
+						tp[u].x = on ? tp[u].x * gD : 0.0; tp[u].y = on ? tp[u].y * gD : 0.0;
+					}
+#pragma unroll
+					for (int u = 0; u < R; u++) {
+						const unsigned e = off + qq + (unsigned)u + (unsigned)(R - 1);
+#pragma unroll
+						for (int c = 0; c < NREC; c++) yw[c][(u + R - 1) % R] = slab[c][INV_WPAD(e)];
+#pragma unroll
+						for (int c = 0; c < NREC; c++)
+#pragma unroll
+							for (int r = 0; r < R; r++)
+								acc[c][r] = fma(tp[u].x, yw[c][(u + r) % R].x, fma(tp[u].y, yw[c][(u + r) % R].y, acc[c][r]));
+					}
+					l += (unsigned)R * D; // (a partial last block leaves l past its steps: the next voice starts over)
+				}
+			}
+		}
+	} else if constexpr (GEN) {
 		// D does not divide N (cdotx.c:313-337: the zero-stuffed grid restarts at the circular seam).  With the raw position
 		// P = n - cd + l in (-N, 2N), frame f = floor(P / N) and in-frame position p = P - f N, a tap is on the grid iff
 		// D | p and then meets coefficient p / D.  Per frame this is the ordinary polyphase correlation for the shifted

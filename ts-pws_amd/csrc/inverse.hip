@@ -124,6 +124,15 @@ __global__ void __launch_bounds__(256) k_inverse_generic(const double2 *__restri
 
 #include "inv_poly.h"
 
+// octaves up to this decimation take the LDS-staged instantiation (TSPWS_INV_LDS_MAXD, default 1: the full-rate scales of the
+// Mexican hat / `uni` frames, whose per-lane windows touch 64 cache lines per wave-load; 0: none)
+static unsigned inv_lds_maxd()
+{
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("TSPWS_INV_LDS_MAXD"); v = e ? std::max(0, atoi(e)) : 1; }
+	return (unsigned)v;
+}
+
 // work list of the polyphase inverse: one item group per run of consecutive scales with the same D
 int tspws_build_inverse(tspws_hip_plan *p)
 {
@@ -148,12 +157,15 @@ int tspws_build_inverse(tspws_hip_plan *p)
 	}
 	// octaves whose decimation divides N first: the two classes are launched separately (k_inv_poly<., GEN>)
 	std::stable_sort(oc.begin(), oc.end(), [](const OctDesc &x, const OctDesc &y) { return x.gen < y.gen; });
-	p->inv_waves_fast = 0;
+	p->inv_waves_fast = 0; p->inv_waves_lds = 0;
 	for (size_t i = 0; i < oc.size(); i++) {
 		oc[i].wave_off = woff; oc[i].slot = (unsigned)i;
 		woff += oc[i].MC * oc[i].ngw;
 		if (!oc[i].gen) p->inv_waves_fast = woff;
+		// the finely decimated octaves (D < 64) come first in scale order: their waves take the LDS-staged instantiation
+		if (!oc[i].gen && oc[i].D <= inv_lds_maxd() && p->inv_waves_lds == oc[i].wave_off) p->inv_waves_lds = woff;
 	}
+	if (const char *e = getenv("TSPWS_INV_LDS")) if (*e == '0') p->inv_waves_lds = 0; // (A/B: the per-lane form for every octave)
 	p->inv_waves = woff; p->inv_noct = (unsigned)oc.size();
 	p->oc_s0.clear(); p->oc_nv.clear(); p->oc_wave_off.clear(); p->oc_nwaves.clear(); p->oc_gen.clear();
 	for (const OctDesc &o : oc) {
@@ -205,15 +217,36 @@ static int inverse_launch(tspws_hip_plan *p, const double2 *Y, double *x, hipStr
 	int rc = scratch(p, SCR_OBUF, (size_t)nb * nslots * slot * sizeof(double), &v);
 	if (rc) return rc;
 	double *obuf = (double *)v;
-	if (p->inv_waves_fast)
-		hipLaunchKernelGGL((k_inv_poly<NREC, false>), dim3((p->inv_waves_fast + 3) / 4, nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->d_oc, p->inv_noct,
-		                   p->d_wd, obuf, slot, p->inv_waves_fast, (size_t)NREC * p->ncoef, (size_t)nslots * slot, 0u);
+	// the LDS-staged octaves (D = 1: two 80-KB workgroups per CU) run BESIDE the others (latency-bound, eight waves per SIMD) on the
+	// plan's side stream: one after the other they took 64 + 153 us for cfg4's twelve reconstructions, the single per-lane launch 262
+	// (batched reconstructions only: a single pair is 206 vs 197 us that way -- the fork / join and two waves per SIMD cost more than
+	// the one octave's coalescing gains)
+	const unsigned lds_w = nb >= 2 ? p->inv_waves_lds : 0u;
+	hipStream_t sl = st;
+	const bool beside = lds_w && p->inv_waves_fast > lds_w;
+	if (beside) {
+		const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+		if (!p->side) HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+		if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, evf));
+		if (!p->ev_join) HIP_TRY(hipEventCreateWithFlags(&p->ev_join, evf));
+		HIP_TRY(hipEventRecord(p->ev_fork, st));
+		HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+		sl = p->side;
+	}
+	if (lds_w)
+		hipLaunchKernelGGL((k_inv_poly<NREC, false, true>), dim3((lds_w + 3) / 4, nb), dim3(256), 0, sl, Y, p->ncoef, p->N, p->d_sc, p->d_oc, p->inv_noct,
+		                   p->d_wd, obuf, slot, lds_w, (size_t)NREC * p->ncoef, (size_t)nslots * slot, 0u);
+	if (beside) HIP_TRY(hipEventRecord(p->ev_join, sl));
+	if (p->inv_waves_fast > lds_w)
+		hipLaunchKernelGGL((k_inv_poly<NREC, false>), dim3((p->inv_waves_fast - lds_w + 3) / 4, nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->d_oc, p->inv_noct,
+		                   p->d_wd, obuf, slot, p->inv_waves_fast, (size_t)NREC * p->ncoef, (size_t)nslots * slot, lds_w);
 	if (p->inv_waves > p->inv_waves_fast)
 		hipLaunchKernelGGL((k_inv_poly<NREC, true>), dim3((p->inv_waves - p->inv_waves_fast + 3) / 4, nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc,
 		                   p->d_oc, p->inv_noct, p->d_wd, obuf, slot, p->inv_waves, (size_t)NREC * p->ncoef, (size_t)nslots * slot, p->inv_waves_fast);
 	if (p->inv_ngeneric)
 		hipLaunchKernelGGL(k_inverse_generic<NREC>, dim3(nbx, nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->S, p->d_wd,
 		                   obuf + (size_t)p->inv_noct * slot, 1, (size_t)NREC * p->ncoef, (size_t)nslots * slot);
+	if (beside) HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
 	if (NREC == 2 && nb == 1 && (f_ts || f_ls))
 		if (hipEvent_t e1 = p->le.call_end) { // the call's end event rides on its last launch (tspws_hip_stack)
 			p->le.call_end = nullptr;
