@@ -271,7 +271,7 @@ def run(args):
         par = f"schedule=single, trace-sharded x{world}: ONE fp64 all-reduce of P[K][N] between the shard-local half and the redundant finish stage"
     res = {
         "metric": baseline_metric(),
-        "value": mtr_global * N * args.steps / dt,
+        "value": mtr_local * world * N * args.steps / dt,   # the samples all ranks processed (a one-GPU shard of a larger ensemble counts its own traces only)
         "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
