@@ -283,7 +283,9 @@ static int finish_replicas(tspws_hip_plan *pl, const t_tsPWS *p, double *d_P, co
 //             [a, b) of consecutive runs that belong to it: sum of G(b) - G(a), G(k) = snapshot before run k (+ the final
 //             snapshots of the earlier segments of its stage): ~10 signed snapshots per row (k_combine_terms) instead of a
 //             chunk reduction + ~15 class rows per row -- 1.30 -> 1.17 ms for the streaming side of cfg4 (the 326 MB of snapshot
-//             writes cost 0.25 ms of the 1.02-ms walk: with the stores aimed at two rows only it takes 0.78 ms);
+//             writes cost 0.25 ms of the 1.02-ms walk: with the stores aimed at two rows only it takes 0.78 ms).  With <= 16
+//             columns the walk keeps a running sum per column in registers and stores the rows themselves (k_rows_walk +
+//             k_seg_fix, stream.hip): 0.93 ms, no snapshots, no combining pass;
 //   rows   are STAGE-major and, inside a stage, column-major: row(g, c) = g0 W + c ng + (g - g0)  (W = C [+ 1 for the plain
 //             stack], g0 / ng = first group / groups of the stage), so the rows of a stage are one run and the ng rows of a
 //             column in it are consecutive: the stage's forward launch is the FUSED kernel with one slice per column -- the
@@ -320,11 +322,12 @@ struct MaskedPlan {
 	std::vector<float> tcoef;
 	// few columns (W <= tspws_rows_walk_wmax()): the rows straight from the walk -- per run the columns it belongs to and the columns
 	// whose group ends with it (+ the rows those sums become)
-	// two halves: half h walks the runs with index = h (mod 2) and stores its share of every row
-	bool direct = false, unwritten = false; // unwritten: a half never stores some row (no run of its own in that group): the half blocks are cleared first
-	std::vector<RunDesc> rdesc[2];      // the half's runs, stage after stage
-	std::vector<unsigned> half_run0[2]; // per stage: the half's first run in rdesc[h] (nstage + 1)
-	std::vector<unsigned> flush_rows;   // flush destinations of both halves (RunDesc::frow points here)
+	bool direct = false, unwritten = false; // unwritten: some row is never stored (an empty group): the row block is cleared first
+	std::vector<RunDesc> rdesc;         // the runs with their column bits
+	std::vector<unsigned> stage_run0;   // per stage: its first run (nstage + 1)
+	std::vector<unsigned> stage_mid;    // per stage: first run of its second segment (== the next stage's first run: one segment)
+	std::vector<unsigned> fix_row;      // [nstage][W]: the first row column c stores in the stage's second segment (~0u: none)
+	std::vector<unsigned> flush_rows;   // flush destinations (RunDesc::frow points here)
 	std::vector<unsigned> rowmap;       // [W][KM]: row of (column, group)
 	std::vector<double> Mv;             // trace count per column (replicas: selected traces; plain stack: mtr)
 	unsigned row_of(unsigned g, unsigned c) const
@@ -392,37 +395,50 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 		}
 	}
 	const unsigned nr = (unsigned)mp.runs.size();
+	mp.stage_run0.assign(nstage + 1, nr);
+	for (unsigned r = nr; r-- > 0;) mp.stage_run0[run_stage[r]] = r;
+	for (unsigned sg = nstage; sg-- > 0;) if (mp.stage_run0[sg] > mp.stage_run0[sg + 1]) mp.stage_run0[sg] = mp.stage_run0[sg + 1]; // (empty stages)
 	mp.direct = W <= tspws_rows_walk_wmax() && W <= 32;
-	mp.flush_rows.clear(); mp.unwritten = false;
-	for (int h = 0; h < 2; h++) { mp.rdesc[h].clear(); mp.half_run0[h].assign(nstage + 1, 0); }
+	mp.rdesc.clear(); mp.flush_rows.clear(); mp.unwritten = false;
 	if (mp.direct) {
-		std::vector<char> written((size_t)2 * KM * W, 0);
-		for (int h = 0; h < 2; h++) {
-			unsigned sg_done = 0;
-			for (unsigned r = (unsigned)h; r < nr; r += 2) {
-				while (sg_done <= run_stage[r]) mp.half_run0[h][sg_done++] = (unsigned)mp.rdesc[h].size(); // (first run of every stage up to this one)
-				RunDesc d;
-				memset(&d, 0, sizeof d);
-				d.t0 = mp.runs[r].t0; d.count = mp.runs[r].count; d.frow = (unsigned)mp.flush_rows.size();
-				const unsigned *sr = &sig[mp.runs[r].t0 * W];
-				for (unsigned c = 0; c < W; c++) {
-					if (sr[c] == SIG_DELETED) continue;
-					d.member |= 1u << c;
-					// column c's group ends -- for this half -- with this run when the half's next run that belongs to c has another group
-					unsigned q = r + 2;
-					while (q < nr && sig[mp.runs[q].t0 * W + c] == SIG_DELETED) q += 2;
-					if (q >= nr || sig[mp.runs[q].t0 * W + c] != sr[c]) {
-						d.flush |= 1u << c;
-						const unsigned row = mp.row_of(std::min(sr[c], KM - 1), c);
-						mp.flush_rows.push_back(row);
-						written[(size_t)h * KM * W + row] = 1;
-					}
+		std::vector<char> written((size_t)KM * W, 0);
+		mp.rdesc.resize(nr);
+		for (unsigned r = 0; r < nr; r++) {
+			RunDesc d;
+			memset(&d, 0, sizeof d);
+			d.t0 = mp.runs[r].t0; d.count = mp.runs[r].count; d.frow = (unsigned)mp.flush_rows.size();
+			const unsigned *sr = &sig[mp.runs[r].t0 * W];
+			for (unsigned c = 0; c < W; c++) {
+				if (sr[c] == SIG_DELETED) continue;
+				d.member |= 1u << c;
+				// column c's group ends with this run when the next run that belongs to c has another group (or there is none)
+				unsigned q = r + 1;
+				while (q < nr && sig[mp.runs[q].t0 * W + c] == SIG_DELETED) q++;
+				if (q == nr || sig[mp.runs[q].t0 * W + c] != sr[c]) {
+					d.flush |= 1u << c;
+					const unsigned row = mp.row_of(std::min(sr[c], KM - 1), c);
+					mp.flush_rows.push_back(row);
+					written[row] = 1;
 				}
-				mp.rdesc[h].push_back(d);
 			}
-			while (sg_done <= nstage) mp.half_run0[h][sg_done++] = (unsigned)mp.rdesc[h].size();
+			mp.rdesc[r] = d;
 		}
 		for (char w : written) if (!w) mp.unwritten = true;
+		// two segments of similar trace counts per stage, and what the second one's first stores lack
+		mp.stage_mid.assign(nstage, 0); mp.fix_row.assign((size_t)nstage * W, ~0u);
+		for (unsigned sg = 0; sg < nstage; sg++) {
+			const unsigned q0 = mp.stage_run0[sg], q1 = mp.stage_run0[sg + 1];
+			size_t traces = 0, done = 0;
+			for (unsigned r = q0; r < q1; r++) traces += mp.runs[r].count;
+			unsigned qm = q1;
+			for (unsigned r = q0; r < q1; r++) { if (r > q0 && 2 * done >= traces) { qm = r; break; } done += mp.runs[r].count; }
+			mp.stage_mid[sg] = qm;
+			for (unsigned r = qm; r < q1; r++) {
+				unsigned fr = mp.rdesc[r].frow;
+				for (unsigned c = 0; c < W; c++)
+					if ((mp.rdesc[r].flush >> c) & 1u) { if (mp.fix_row[(size_t)sg * W + c] == ~0u) mp.fix_row[(size_t)sg * W + c] = mp.flush_rows[fr]; fr++; }
+			}
+		}
 	}
 	// segments: a stage's runs in ~256 / (column blocks) pieces of similar trace counts, each walked by its own workgroups
 	static int seg_wgs = -1; // workgroups the streaming side aims at per stage (sweeps: TSPWS_JK_SEGWG)
@@ -561,19 +577,16 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	double *OUT = (double *)v, *STr = OUT + (size_t)nrec * 2 * nc, *xr = STr + (size_t)W * 4 * nc;
 	// table block: runs (16-byte records) | trace counts | term pointers | term snapshots | term coefficients | row map | segments | carries
 	const size_t n_runs = mp.runs.size(), n_tp = mp.trow_ptr.size(), n_t = mp.tidx.size(), n_map = mp.rowmap.size(), n_seg = mp.seg_first.size(),
-	             n_car = mp.carry.size(), n_rd0 = mp.rdesc[0].size(), n_rd1 = mp.rdesc[1].size(), n_rd = n_rd0 + n_rd1, n_fr = mp.flush_rows.size();
+	             n_car = mp.carry.size(), n_rd = mp.rdesc.size(), n_fr = mp.flush_rows.size(), n_fx = mp.fix_row.size();
 	const size_t o_mv = n_runs * sizeof(Chunk), o_rd = o_mv + W * sizeof(double), o_tp = o_rd + n_rd * sizeof(RunDesc), o_ti = o_tp + n_tp * 4, o_tc = o_ti + n_t * 4,
-	             o_map = o_tc + n_t * 4, o_seg = o_map + n_map * 4, o_car = o_seg + n_seg * 4, o_fr = o_car + n_car * 4, tab_bytes = o_fr + std::max<size_t>(n_fr, 1) * 4;
+	             o_map = o_tc + n_t * 4, o_seg = o_map + n_map * 4, o_car = o_seg + n_seg * 4, o_fr = o_car + n_car * 4, o_fx = o_fr + n_fr * 4, tab_bytes = o_fx + std::max<size_t>(n_fx, 1) * 4;
 	if ((rc = scratch(pl, SCR_JKTAB, tab_bytes, &v))) return rc;
 	char *tb = (char *)v;
 	const Chunk *d_runs = (const Chunk *)tb;
 	const RunDesc *d_rd = (const RunDesc *)(tb + o_rd);
-	const unsigned *d_fr = (const unsigned *)(tb + o_fr);
-	double *d_half = nullptr, *d_carryblk = nullptr; // direct walk: the halves' rows [2][nrow][N], their live per-column sums between stages [2][W][N]
-	if (mp.direct) {
-		if ((rc = scratch(pl, SCR_CLS, ((size_t)2 * nrow + 2 * W) * N * sizeof(double), &v))) return rc;
-		d_half = (double *)v; d_carryblk = d_half + (size_t)2 * nrow * N;
-	}
+	const unsigned *d_fr = (const unsigned *)(tb + o_fr), *d_fx = (const unsigned *)(tb + o_fx);
+	double *d_carryblk = nullptr; // direct walk: [tail of segment A | end of segment B | carry into the next stage], W rows each
+	if (mp.direct) { if ((rc = scratch(pl, SCR_CLS, (size_t)3 * W * N * sizeof(double), &v))) return rc; d_carryblk = (double *)v; }
 	double *d_Mv = (double *)(tb + o_mv);
 	const unsigned *d_tp = (const unsigned *)(tb + o_tp), *d_ti = (const unsigned *)(tb + o_ti), *d_map = (const unsigned *)(tb + o_map),
 	               *d_seg = (const unsigned *)(tb + o_seg), *d_car = (const unsigned *)(tb + o_car);
@@ -602,9 +615,9 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 		HIP_TRY(hipMemcpyAsync(tb + o_map, mp.rowmap.data(), n_map * 4, hipMemcpyHostToDevice, st));
 		HIP_TRY(hipMemcpyAsync(tb + o_seg, mp.seg_first.data(), n_seg * 4, hipMemcpyHostToDevice, st));
 		if (n_car) HIP_TRY(hipMemcpyAsync(tb + o_car, mp.carry.data(), n_car * 4, hipMemcpyHostToDevice, st));
-		if (n_rd0) HIP_TRY(hipMemcpyAsync(tb + o_rd, mp.rdesc[0].data(), n_rd0 * sizeof(RunDesc), hipMemcpyHostToDevice, st));
-		if (n_rd1) HIP_TRY(hipMemcpyAsync(tb + o_rd + n_rd0 * sizeof(RunDesc), mp.rdesc[1].data(), n_rd1 * sizeof(RunDesc), hipMemcpyHostToDevice, st));
+		if (n_rd) HIP_TRY(hipMemcpyAsync(tb + o_rd, mp.rdesc.data(), n_rd * sizeof(RunDesc), hipMemcpyHostToDevice, st));
 		if (n_fr) HIP_TRY(hipMemcpyAsync(tb + o_fr, mp.flush_rows.data(), n_fr * 4, hipMemcpyHostToDevice, st));
+		if (n_fx) HIP_TRY(hipMemcpyAsync(tb + o_fx, mp.fix_row.data(), n_fx * 4, hipMemcpyHostToDevice, st));
 		pl->jk_gen = mp.gen;
 	}
 	const unsigned nbx = (unsigned)((N + 255) / 256);
@@ -617,20 +630,19 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 		const unsigned k0 = mp.stage_seg0[sg], nseg = mp.stage_seg0[sg + 1] - k0 - 1;
 		double *d_snap = nullptr; size_t ldpc = 0;
 		if (mp.direct && !no_direct) {
-			// few columns: the rows themselves from the walk (a running sum per column in registers, two halves of the runs; k_rows_walk)
-			if (sg == 0 && mp.unwritten) HIP_TRY(hipMemsetAsync(d_half, 0, (size_t)2 * nrow * N * sizeof(double), st));
-			const unsigned a0 = mp.half_run0[0][sg], a1 = mp.half_run0[0][sg + 1], b0 = mp.half_run0[1][sg], b1 = mp.half_run0[1][sg + 1];
-			if (a1 > a0 || b1 > b0) {
-				if ((rc = tspws_rows_walk_launch(d_x, ld, N, d_rd + a0, d_rd + n_rd0 + b0, a1 - a0, b1 - b0, W, d_fr, d_half, (size_t)nrow * N, d_carryblk, (size_t)W * N,
-				                                 have_carry ? 1 : 0, sg + 1 < mp.nstage ? 1 : 0, st))) return rc;
+			// few columns: the rows themselves from the walk (a running sum per column in registers; k_rows_walk)
+			if (sg == 0 && mp.unwritten) HIP_TRY(hipMemsetAsync(d_rows, 0, (size_t)nrow * N * sizeof(double), st));
+			const unsigned q0 = mp.stage_run0[sg], q1 = mp.stage_run0[sg + 1];
+			if (q1 > q0) {
+				if ((rc = tspws_rows_walk_launch(d_x, ld, N, d_rd, q0, mp.stage_mid[sg], q1, W, d_fr, d_fx + (size_t)sg * W, d_rows, d_carryblk, have_carry ? 1 : 0,
+				                                 sg + 1 < mp.nstage ? 1 : 0, st))) return rc;
 				have_carry = true;
 			}
 		} else if ((rc = tspws_prefix_launch(pl, d_x, ld, N, d_runs, d_seg + k0, nseg, n_runs, d_car + mp.carry_ptr[sg], mp.carry_ptr[sg + 1] - mp.carry_ptr[sg], &d_snap,
 		                                     &ldpc, st)))
 			return rc;
 		const unsigned g0 = sg * mp.gps, ng = std::min(mp.gps, KM - g0), r0 = g0 * W, r1 = r0 + ng * W;
-		if (mp.direct && !no_direct) tspws_add_halves_launch(d_half + (size_t)r0 * N, d_half + ((size_t)nrow + r0) * N, d_rows + (size_t)r0 * N, (size_t)(r1 - r0) * N, st);
-		else tspws_combine_terms_launch(d_snap, ldpc, d_tp + r0, d_ti, d_tc, r1 - r0, d_rows + (size_t)r0 * N, N, st);
+		if (!(mp.direct && !no_direct)) tspws_combine_terms_launch(d_snap, ldpc, d_tp + r0, d_ti, d_tc, r1 - r0, d_rows + (size_t)r0 * N, N, st);
 		HIP_TRY(hipEventRecord(pl->stage_ev[sg], st));
 		// FP64-bound half on the second stream: the stage's rows, one slice of ng rows per column
 		HIP_TRY(hipStreamWaitEvent(pl->xf, pl->stage_ev[sg], 0));

@@ -220,26 +220,26 @@ __global__ void __launch_bounds__(256) k_prefix_walk(const float *__restrict__ x
 }
 
 // Few columns (<= ROWS_WMAX: the jackknife of cfg4 has 10 replicas + the plain stack): the rows THEMSELVES from the walk.  A
-// workgroup owns 1024 samples of every trace of ITS runs and keeps one running sum per column in registers; after every run of
-// traces (one signature) the run's sum is added to the columns the run belongs to (`member`, a bit per column -- uniform
-// branches, once per ~30 traces, not once per trace: the round-3 kernel that added every trace to every column was VALU-bound
-// at 2.4 ms), and a column whose group ends there stores its sum as that group's row and starts over (`flush`).  No snapshots
-// (their 326 MB of writes cost the prefix walk 0.25 ms), no combining pass over ~10 snapshots per row.
-// Two workgroups per column block (grid.y = half): half h walks the runs with index = h (mod 2) -- 128 column blocks alone would
-// leave half the CUs without a stream (1.05 ms for the plain pass at 128 workgroups) -- into its own row block; k_add_halves
-// adds the two.  Both halves flush a column at the same point of the run sequence (the flush of run r sits on run r - 1 in the
-// other half's list).  Stages: the live sums of a half travel through its carry block (W rows) from one launch to the next.
+// workgroup owns 1024 samples of every trace of ITS segment of the stage and keeps one running sum per column in registers; after
+// every run of traces (one signature) the run's sum is added to the columns the run belongs to (`member`, a bit per column --
+// uniform branches, once per ~30 traces, not once per trace: the round-3 kernel that added every trace to every column was
+// VALU-bound at 2.4 ms), and a column whose group ends there stores its sum as that group's row and starts over (`flush`).  No
+// snapshots (their 326 MB of writes cost the prefix walk 0.25 ms), no combining pass over ~10 snapshots per row.
+// Two workgroups per column block (grid.y): 128 alone would leave half the CUs without a stream (1.05 ms for the plain pass at 128
+// workgroups), and narrower workgroups lose (512 samples: 1.08-1.19 ms -- a workgroup that reads 4 KB of every row keeps one
+// channel stream to itself).  The stage's runs are cut in two SEGMENTS of similar trace counts: segment A starts from the sums the
+// previous stage left (carry), segment B from zero -- the first row a column stores in B lacks what A had collected for it
+// (`tail`), and k_seg_fix adds it (or, for a column that stores nothing in B, hands tail + B's sum on to the next stage): W rows of
+// fix-up per stage instead of a second set of rows and a pass that adds the two (alternate runs in two halves: 0.97 + 0.05 ms).
 #define ROWS_WMAX 16
 template <bool VEC4>
-__global__ void __launch_bounds__(256) k_rows_walk(const float *__restrict__ x, size_t ld, size_t N, const RunDesc *__restrict__ runs0,
-                                                   const RunDesc *__restrict__ runs1, unsigned n0, unsigned n1, unsigned W,
-                                                   const unsigned *__restrict__ flush_rows, double *__restrict__ rows, size_t half_stride,
-                                                   double *__restrict__ carry, size_t carry_stride, int carry_in, int carry_out)
+__global__ void __launch_bounds__(256) k_rows_walk(const float *__restrict__ x, size_t ld, size_t N, const RunDesc *__restrict__ runs, unsigned qa0,
+                                                   unsigned qm, unsigned qb1, unsigned W, const unsigned *__restrict__ flush_rows,
+                                                   double *__restrict__ rows, const double *__restrict__ carry_in, double *__restrict__ endA,
+                                                   double *__restrict__ endB)
 {
-	const unsigned h = blockIdx.y;
-	const RunDesc *runs = h ? runs1 : runs0;
-	const unsigned nr = h ? n1 : n0;
-	rows += (size_t)h * half_stride; carry += (size_t)h * carry_stride;
+	const unsigned seg = blockIdx.y;
+	const unsigned r0 = seg ? qm : qa0, r1 = seg ? qb1 : qm;
 	const size_t col = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
 	if (col >= N) return;
 	const unsigned rem = (N - col) < 4 ? (unsigned)(N - col) : 4u;
@@ -248,14 +248,14 @@ __global__ void __launch_bounds__(256) k_rows_walk(const float *__restrict__ x, 
 	for (int c = 0; c < ROWS_WMAX; c++) {
 #pragma unroll
 		for (int k = 0; k < 4; k++) P[c][k] = 0;
-		if (carry_in && (unsigned)c < W) {
-			const double *s = carry + (size_t)c * N + col;
+		if (!seg && carry_in && (unsigned)c < W) {
+			const double *s = carry_in + (size_t)c * N + col;
 #pragma unroll
 			for (int k = 0; k < 4; k++) if ((unsigned)k < rem) P[c][k] = s[k];
 		}
 	}
 	typedef float v4f __attribute__((ext_vector_type(4)));
-	for (unsigned ri = 0; ri < nr; ri++) {
+	for (unsigned ri = r0; ri < r1; ri++) {
 		const RunDesc rd = runs[ri];
 		const float *src = x + rd.t0 * ld + col;
 		double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -302,44 +302,51 @@ __global__ void __launch_bounds__(256) k_rows_walk(const float *__restrict__ x, 
 			}
 		}
 	}
-	if (carry_out) {
+	double *end = seg ? endB : endA; // the live sums of the segment
+	if (end) {
 #pragma unroll
 		for (int c = 0; c < ROWS_WMAX; c++)
 			if ((unsigned)c < W) {
-				double *d = carry + (size_t)c * N + col;
+				double *d = end + (size_t)c * N + col;
 #pragma unroll
 				for (int k = 0; k < 4; k++) if ((unsigned)k < rem) d[k] = P[c][k];
 			}
 	}
 }
 
-// out[i] = a[i] + b[i]  (the two halves of a stage's rows)
-__global__ void __launch_bounds__(256) k_add_halves(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out, size_t n)
+// after a stage walked in two segments: column c (blockIdx.y) -- the first row it stored in segment B gets what segment A had
+// collected for it (fix_row[c]), or, if it stored nothing in B, the next stage inherits tail + B's sum
+__global__ void __launch_bounds__(256) k_seg_fix(const double *__restrict__ tailA, const double *__restrict__ endB, const unsigned *__restrict__ fix_row,
+                                                 double *__restrict__ rows, double *__restrict__ carry, size_t N)
 {
-	const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
-	if (i + 1 < n) { const double2 u = *(const double2 *)(a + i), v = *(const double2 *)(b + i); *(double2 *)(out + i) = make_double2(u.x + v.x, u.y + v.y); }
-	else if (i < n) out[i] = a[i] + b[i];
+	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (n >= N) return;
+	const unsigned c = blockIdx.y, fr = fix_row[c];
+	const double t = tailA[(size_t)c * N + n], e = endB[(size_t)c * N + n];
+	if (fr != ~0u) { rows[(size_t)fr * N + n] = t + rows[(size_t)fr * N + n]; carry[(size_t)c * N + n] = e; }
+	else carry[(size_t)c * N + n] = t + e;
 }
 
-// one stage of the direct walk: runs [q0[h], q1[h]) of half h's list; the halves' rows go to d_half + h * half_stride
-int tspws_rows_walk_launch(const float *d_x, size_t ld, size_t N, const RunDesc *d_runs0, const RunDesc *d_runs1, unsigned n0, unsigned n1, unsigned W,
-                           const unsigned *d_flush_rows, double *d_half, size_t half_stride, double *d_carry, size_t carry_stride, int carry_in,
-                           int carry_out, hipStream_t st)
+// one stage of the direct walk: runs [q0, q1), cut at qm into two segments (qm == q1: one segment); d_blk = [tail | endB | carry], W rows
+// each; carry_in / carry_out: the stage starts from / leaves the carry rows
+int tspws_rows_walk_launch(const float *d_x, size_t ld, size_t N, const RunDesc *d_runs, unsigned q0, unsigned qm, unsigned q1, unsigned W,
+                           const unsigned *d_flush_rows, const unsigned *d_fix_row, double *d_rows, double *d_blk, int carry_in, int carry_out, hipStream_t st)
 {
 	if (W > ROWS_WMAX) return fail(TSPWS_E_ARG, "rows_walk: too many columns");
 	const unsigned grid = (unsigned)((N + 1023) / 1024);
 	const bool vec = (N % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x & 15) == 0);
-	if (vec) hipLaunchKernelGGL(k_rows_walk<true>, dim3(grid, 2), dim3(256), 0, st, d_x, ld, N, d_runs0, d_runs1, n0, n1, W, d_flush_rows, d_half, half_stride, d_carry,
-	                            carry_stride, carry_in, carry_out);
-	else hipLaunchKernelGGL(k_rows_walk<false>, dim3(grid, 2), dim3(256), 0, st, d_x, ld, N, d_runs0, d_runs1, n0, n1, W, d_flush_rows, d_half, half_stride, d_carry,
-	                        carry_stride, carry_in, carry_out);
+	double *tail = d_blk, *endB = d_blk + (size_t)W * N, *carry = d_blk + (size_t)2 * W * N;
+	const bool two = qm < q1 && qm > q0;
+	if (!two) qm = q1;
+	// one segment: its live sums are the carry; two: tail + endB, merged by k_seg_fix
+	double *endA = two ? tail : (carry_out ? carry : nullptr);
+	if (vec) hipLaunchKernelGGL(k_rows_walk<true>, dim3(grid, two ? 2 : 1), dim3(256), 0, st, d_x, ld, N, d_runs, q0, qm, q1, W, d_flush_rows, d_rows,
+	                            (const double *)(carry_in ? carry : nullptr), endA, endB);
+	else hipLaunchKernelGGL(k_rows_walk<false>, dim3(grid, two ? 2 : 1), dim3(256), 0, st, d_x, ld, N, d_runs, q0, qm, q1, W, d_flush_rows, d_rows,
+	                        (const double *)(carry_in ? carry : nullptr), endA, endB);
+	if (two) hipLaunchKernelGGL(k_seg_fix, dim3((unsigned)((N + 255) / 256), W), dim3(256), 0, st, (const double *)tail, (const double *)endB, d_fix_row, d_rows, carry, N);
 	HIP_TRY(hipGetLastError());
 	return 0;
-}
-
-void tspws_add_halves_launch(const double *a, const double *b, double *out, size_t n, hipStream_t st)
-{
-	hipLaunchKernelGGL(k_add_halves, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, st, a, b, out, n);
 }
 unsigned tspws_rows_walk_wmax() { return ROWS_WMAX; }
 

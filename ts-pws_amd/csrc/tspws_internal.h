@@ -324,11 +324,9 @@ int  tspws_prefix_launch(tspws_hip_plan *p, const float *d_x, size_t ld, size_t 
                          size_t nruns_total, const unsigned *d_carry, unsigned ncarry, double **d_snap, size_t *ldpc, hipStream_t st);
 void tspws_combine_terms_launch(const double *d_snap, size_t ldpc, const unsigned *d_row_ptr, const unsigned *d_idx, const float *d_coef, unsigned nrows,
                                 double *d_P, size_t N, hipStream_t st);
-// few columns: the rows themselves from one walk with a running sum per column, two halves of the runs side by side (k_rows_walk)
-int  tspws_rows_walk_launch(const float *d_x, size_t ld, size_t N, const RunDesc *d_runs0, const RunDesc *d_runs1, unsigned n0, unsigned n1, unsigned W,
-                            const unsigned *d_flush_rows, double *d_half, size_t half_stride, double *d_carry, size_t carry_stride, int carry_in,
-                            int carry_out, hipStream_t st);
-void tspws_add_halves_launch(const double *a, const double *b, double *out, size_t n, hipStream_t st);
+// few columns: the rows themselves from one walk with a running sum per column, a stage in two segments (k_rows_walk, k_seg_fix)
+int  tspws_rows_walk_launch(const float *d_x, size_t ld, size_t N, const RunDesc *d_runs, unsigned q0, unsigned qm, unsigned q1, unsigned W,
+                            const unsigned *d_flush_rows, const unsigned *d_fix_row, double *d_rows, double *d_blk, int carry_in, int carry_out, hipStream_t st);
 unsigned tspws_rows_walk_wmax();
 unsigned tspws_chunk_len_for(size_t N, size_t mtr);
 // stack.hip
