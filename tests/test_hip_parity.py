@@ -305,7 +305,7 @@ def test_jackknife_vs_oracle_many_traces(lib):
     assert z["rc"] == 0 and not z["jk_ts"].any() and z["tsPWS"].any()
 
 
-@pytest.mark.parametrize("env", [dict(), dict(TSPWS_JK_DIRECT="0"), dict(TSPWS_JK_STAGES="1"), dict(TSPWS_JK_STAGES="5"), dict(TSPWS_JK_PIPELINE="0")])
+@pytest.mark.parametrize("env", [dict(), dict(TSPWS_JK_DIRECT="0"), dict(TSPWS_JK_STAGES="1"), dict(TSPWS_JK_STAGES="5"), dict(TSPWS_JK_PIPELINE="0"), dict(TSPWS_JK_FINAL="0")])
 def test_masked_replica_engines_agree(env):
     """The streaming side of the masked replicas has three forms: rows straight from the walk (a running sum per column, <= 16
     columns), running sums with snapshots + signed sums of snapshots (any number of columns), and the class sums of the serial

@@ -339,8 +339,10 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 			const dim3 grid(lr.lds1 - lr.lds0, (nt + tps - 1) / tps);
 			double2 *aS = fuse ? fz->accST + (t0 / tps) * fz->stride : nullptr, *aP = fuse ? fz->accPS + (t0 / tps) * fz->stride : nullptr;
 			const size_t astr = fuse ? fz->stride : 0;
+			FuseFinal ff;
+			if (fuse && fz->fin.OUT && t0 == 0 && ntr <= per_launch) ff = fz->fin; // (slice indices of the final step are the launch's own: one launch)
 #define FL_LAUNCH(F, QT) hipLaunchKernelGGL((k_fwd_lds<TIn, F, QT>), grid, dim3(FL_NT), FL_LDS_BYTES_(QT), st, d_x + t0 * ld, ld, nt, tps, p->N, p->d_sc, p->S, \
-			                            p->d_w, d_part + t0 * p->npart, p->npart, aS, aP, astr, lr.lds0)
+			                            p->d_w, d_part + t0 * p->npart, p->npart, aS, aP, astr, lr.lds0, ff)
 			if (p->lds_qt == 32) { if (fuse) FL_LAUNCH(true, 32); else FL_LAUNCH(false, 32); }
 			else { if (fuse) FL_LAUNCH(true, 24); else FL_LAUNCH(false, 24); }
 #undef FL_LAUNCH
@@ -499,7 +501,7 @@ void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb
 	auto kern = (wa && wa->OUTP) ? k_accumulate_parts<true> : k_accumulate_parts<false>;
 	hipLaunchKernelGGL(kern, dim3(a1 - a0, nbatch), dim3(256), 0, st, part, trace_stride ? trace_stride : (tl ? tl->npart : p->npart),
 	                   (const ScaleDesc *)(tl ? tl->d_sc : p->d_sc), p->S, nb, ST, PS, zero_first,
-	                   on ? (direct ? 1 : 2) : 0, on ? (const double2 *)fz->accST : nullptr, on ? (const double2 *)fz->accPS : nullptr,
+	                   (ex && ex->fused_done) ? 3 : on ? (direct ? 1 : 2) : 0, on ? (const double2 *)fz->accST : nullptr, on ? (const double2 *)fz->accPS : nullptr,
 	                   on ? fz->stride : (size_t)0, nslices, y_part, y_stack, tl ? 1 : 0, wa ? *wa : w0, a0, ex ? ex->y_fz : (size_t)0,
 	                   ex ? ex->rowmap : (const unsigned *)nullptr);
 }

@@ -116,7 +116,7 @@ template <typename TIn, int LOGD, bool FUSE, int PASSES, int QT>
 __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const size_t ld, const unsigned ntr, const unsigned N, const ScaleDesc &d,
                                              const double2 *__restrict__ ws, double *__restrict__ pout0, const size_t npart,
                                              const unsigned chunk, const unsigned bb, double2 *tL, double *xL,
-                                             double2 *__restrict__ accST, double2 *__restrict__ accPS)
+                                             double2 *__restrict__ accST, double2 *__restrict__ accPS, const FuseFinal &ff, const unsigned slice)
 {
 	static_assert(QT % FL_R == 0 && QT % FL_WAVES == 0 && QT % FL_BATCH == 0, "QT: a multiple of the window length, the waves and the burst");
 	constexpr int R = FL_R;
@@ -528,7 +528,22 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 #pragma unroll
 				for (int i = 0; i < NACC; i++) {
 					const unsigned k = g * R + (first >> 1) + (unsigned)i;
-					if (k < d.Ns) { accST[d.coef_off + k] = fst[p][i]; accPS[d.coef_off + k] = fps[p][i]; }
+					if (k < d.Ns) {
+						const size_t ci = d.coef_off + k;
+						if (ff.OUT) { // complete the column's stacks here: earlier stages first (stage order), then this slice; weights on the spot
+							double2 st = fst[p][i], ps = fps[p][i];
+							if (ff.nprev) {
+								double2 s0 = make_double2(0.0, 0.0), p0 = make_double2(0.0, 0.0);
+								for (unsigned q = 0; q < ff.nprev; q++) {
+									const double2 a = ff.pST[q * ff.pair_stride + slice * ff.slice_stride + ci], b = ff.pPS[q * ff.pair_stride + slice * ff.slice_stride + ci];
+									s0.x += a.x; s0.y += a.y; p0.x += b.x; p0.y += b.y;
+								}
+								st.x = s0.x + st.x; st.y = s0.y + st.y; ps.x = p0.x + ps.x; ps.y = p0.y + ps.y;
+							}
+							ff.OUT[slice * ff.out_stride + ci] = weight_value(st, ps, ff.mode, ff.K, ff.Mv[slice], ff.wu);
+							if ((int)slice == ff.keep_slice) ff.keepST[ci] = st;
+						} else { accST[ci] = fst[p][i]; accPS[ci] = fps[p][i]; }
+					}
 				}
 			}
 		}
@@ -554,7 +569,7 @@ template <typename TIn, bool FUSE, int QT>
 __device__ __forceinline__ void fwd_lds_workgroup(const unsigned bid, const unsigned slice, char *smem, const TIn *__restrict__ x, size_t ld,
                                                   unsigned ntr, unsigned tps, unsigned N, const ScaleDesc *__restrict__ sc, unsigned S,
                                                   const double2 *__restrict__ w, double2 *__restrict__ part, size_t npart,
-                                                  double2 *__restrict__ accST, double2 *__restrict__ accPS, size_t acc_stride)
+                                                  double2 *__restrict__ accST, double2 *__restrict__ accPS, size_t acc_stride, const FuseFinal &ff)
 {
 	double2 *tL = (double2 *)smem;
 	double *xL = (double *)(smem + FL_TAPS_BYTES_(QT));
@@ -576,14 +591,14 @@ __device__ __forceinline__ void fwd_lds_workgroup(const unsigned bid, const unsi
 #if FL_ABLATE
 	if (!((fl_class_mask >> (d.D >= 64 ? 6u : d.logDL)) & 1u)) return;
 #endif
-	if (d.D >= 64) { fwd_lds_body<TIn, 6, FUSE, FL_PASSES, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); return; }
+	if (d.D >= 64) { fwd_lds_body<TIn, 6, FUSE, FL_PASSES, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP, ff, slice); return; }
 	switch (d.logDL) {
-	case 0: fwd_lds_body<TIn, 0, FUSE, FL_PASSES_FINE, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break; // D = 1 (Mexican hat, uni): 8 coefficients per lane
-	case 1: fwd_lds_body<TIn, 1, FUSE, FL_PASSES_FINE, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
-	case 2: fwd_lds_body<TIn, 2, FUSE, FL_PASSES_FINE, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
-	case 3: fwd_lds_body<TIn, 3, FUSE, FL_PASSES, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
-	case 4: fwd_lds_body<TIn, 4, FUSE, FL_PASSES, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
-	default: fwd_lds_body<TIn, 5, FUSE, FL_PASSES, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP); break;
+	case 0: fwd_lds_body<TIn, 0, FUSE, FL_PASSES_FINE, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP, ff, slice); break; // D = 1 (Mexican hat, uni): 8 coefficients per lane
+	case 1: fwd_lds_body<TIn, 1, FUSE, FL_PASSES_FINE, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP, ff, slice); break;
+	case 2: fwd_lds_body<TIn, 2, FUSE, FL_PASSES_FINE, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP, ff, slice); break;
+	case 3: fwd_lds_body<TIn, 3, FUSE, FL_PASSES, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP, ff, slice); break;
+	case 4: fwd_lds_body<TIn, 4, FUSE, FL_PASSES, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP, ff, slice); break;
+	default: fwd_lds_body<TIn, 5, FUSE, FL_PASSES, QT>(x0, ld, nt, N, d, ws, pout0, npart, chunk, bb, tL, xL, aS, aP, ff, slice); break;
 	}
 }
 
@@ -598,7 +613,7 @@ template <typename TIn, bool FUSE, int QT>
 __global__ void __launch_bounds__(FL_NT, 2) FL_VGPR_ATTR k_fwd_lds(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned tps, unsigned N,
                                                  const ScaleDesc *__restrict__ sc, unsigned S, const double2 *__restrict__ w,
                                                  double2 *__restrict__ part, size_t npart, double2 *__restrict__ accST,
-                                                 double2 *__restrict__ accPS, size_t acc_stride, unsigned bid0)
+                                                 double2 *__restrict__ accPS, size_t acc_stride, unsigned bid0, FuseFinal ff)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	// Workgroups are dispatched in blockIdx order and a launch is a few rounds of ~46 us workgroups, so the LAST round sets
@@ -606,5 +621,5 @@ __global__ void __launch_bounds__(FL_NT, 2) FL_VGPR_ATTR k_fwd_lds(const TIn *__
 	// the launch with short workgroups.
 	// bid0: first workgroup of the launch in the plan's list (a launch may cover a sub-range of the scales: sharded finish)
 	const unsigned bid = bid0 + (gridDim.x - 1u - blockIdx.x);
-	fwd_lds_workgroup<TIn, FUSE, QT>(bid, blockIdx.y, smem, x, ld, ntr, tps, N, sc, S, w, part, npart, accST, accPS, acc_stride);
+	fwd_lds_workgroup<TIn, FUSE, QT>(bid, blockIdx.y, smem, x, ld, ntr, tps, N, sc, S, w, part, npart, accST, accPS, acc_stride, ff);
 }

@@ -447,8 +447,8 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 #endif
 	if (fused && sc[lo].fuse_ok) {
 		// the forward kernel already stacked this scale: fused == 1, straight into ST / PS (nothing left to do);
-		// fused == 2, one plane pair per trace slice, added here in slice order
-		if (fused == 1 && !wa.OUT) return;
+		// fused == 2, one plane pair per trace slice, added here in slice order; fused == 3: it also completed and weighted them
+		if (fused == 3 || (fused == 1 && !wa.OUT)) return;
 		const unsigned k = (bx - sc[lo].acc2_off) * 256u + threadIdx.x;
 		if (k >= Ns) return;
 		const size_t i = sc[lo].coef_off + k;

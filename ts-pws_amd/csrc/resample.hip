@@ -275,7 +275,8 @@ static int finish_replicas(tspws_hip_plan *pl, const t_tsPWS *p, double *d_P, co
 // g = floor(k Kmax / K)), so once the traces up to the end of group g of EVERY column (replica / plain stack) have been
 // streamed, row g of all columns is final: its forward transforms (the FP64-bound half of the call: 110 transforms at cfg4)
 // run on a second stream while the next groups are streamed (the HBM-bound half).
-//   stage s = groups [s gps, (s + 1) gps) of every column (two stages by default), its traces = [T(s - 1), T(s)) with T(s) = the
+//   stage s = groups [s gps, (s + 1) gps) of every column (ONE stage by default: what the two sides cost each other eats what the
+//             overlap gains, see below), its traces = [T(s - 1), T(s)) with T(s) = the
 //             end of the last trace that belongs to a group of stage <= s in any column;
 //   streaming side: RUNNING sums.  The traces are cut into runs of one signature (= the group of the trace in every column);
 //             a segment of a stage walks its runs in trace order without resetting its accumulators and stores a snapshot after
@@ -534,12 +535,12 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 	return mp;
 }
 
-// groups per stage: TSPWS_JK_GPS, else ceil(KM / stages) with TSPWS_JK_STAGES (default 2) stages
+// groups per stage: TSPWS_JK_GPS, else ceil(KM / stages) with TSPWS_JK_STAGES stages (default 1: no overlap -- see the table of stage counts above)
 static unsigned masked_gps(unsigned KM)
 {
 	static int gps = -1, nst = -1;
 	if (gps < 0) { const char *e = getenv("TSPWS_JK_GPS"); gps = e ? std::max(0, atoi(e)) : 0; }
-	if (nst < 0) { const char *e = getenv("TSPWS_JK_STAGES"); nst = e ? std::max(1, atoi(e)) : 2; }
+	if (nst < 0) { const char *e = getenv("TSPWS_JK_STAGES"); nst = e ? std::max(1, atoi(e)) : 1; }
 	if (gps > 0) return std::min((unsigned)gps, KM);
 	return std::max(1u, (KM + (unsigned)nst - 1) / (unsigned)nst);
 }
@@ -622,6 +623,11 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	}
 	const unsigned nbx = (unsigned)((N + 255) / 256);
 	bool have_carry = false;
+	// the last stage's forward kernel completes the stacks itself (TSPWS_JK_FINAL: 0 never, 1 always; default: with ONE stage only -- with
+	// earlier stages' plane pairs to add in front the time just moves from the accumulation into the kernel's epilogue)
+	static int fin_env = -2;
+	if (fin_env == -2) { const char *e = getenv("TSPWS_JK_FINAL"); fin_env = e ? atoi(e) : -1; }
+	const bool fin_in_kernel = fin_env < 0 ? mp.nstage == 1 : fin_env != 0;
 	static int no_direct = -1; // TSPWS_JK_DIRECT=0: the snapshot form also for few columns (tests, A/B)
 	if (no_direct < 0) { const char *e = getenv("TSPWS_JK_DIRECT"); no_direct = (e && *e == '0') ? 1 : 0; }
 	for (unsigned sg = 0; sg < mp.nstage; sg++) {
@@ -648,6 +654,14 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 		HIP_TRY(hipStreamWaitEvent(pl->xf, pl->stage_ev[sg], 0));
 		FuseOut fz;
 		if (fuse) { fz.accST = planes + (size_t)sg * W * 2 * nc; fz.accPS = fz.accST + nc; fz.stride = 2 * nc; fz.tps = ng; }
+		if (fuse && fin_in_kernel && sg + 1 == mp.nstage) {
+			// the last stage completes the columns' stacks in the forward kernel itself: earlier stages' plane pairs in front, weights on
+			// the spot -- no pass over the fused scales (98 % of the coefficients) afterwards
+			FuseFinal &f = fz.fin;
+			f.pST = planes; f.pPS = planes + nc; f.pair_stride = (size_t)W * 2 * nc; f.slice_stride = 2 * nc; f.nprev = sg;
+			f.OUT = (double2 *)OUT; f.out_stride = nc; f.Mv = d_Mv; f.mode = tspws_weight_mode(p->wu, p->unbiased, KM); f.K = (double)KM; f.wu = p->wu;
+			f.keep_slice = with_stack ? (int)C : -1; f.keepST = (double2 *)OUT + (size_t)W * nc;
+		}
 		if ((rc = tspws_forward_parts_f64(pl, d_rows + (size_t)r0 * N, r1 - r0, N, part + (size_t)r0 * pl->npart, pl->xf, fuse ? &fz : nullptr, ScaleRange()))) return rc;
 	}
 	HIP_TRY(hipEventRecord(pl->stage_ev[mp.nstage], pl->xf));
@@ -663,8 +677,20 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	ex.rowmap = d_map; ex.y_fz = 2 * nc;
 	FuseOut fa;
 	if (fuse) { fa.accST = planes; fa.accPS = planes + nc; fa.stride = (size_t)W * 2 * nc; fa.applied = true; }
-	tspws_launch_accumulate(pl, (const double2 *)part, KM, (double2 *)STr, (double2 *)STr + nc, 1, fuse ? &fa : nullptr, mp.nstage, st, W, 0, 2 * nc, nullptr, &wa, ScaleRange(), &ex);
-	if (with_stack) HIP_TRY(hipMemcpyAsync(OUT + (size_t)W * 2 * nc, STr + (size_t)C * 4 * nc, nc * sizeof(double2), hipMemcpyDeviceToDevice, st)); // ST of the plain stack: the last set
+	if (fuse && fin_in_kernel) {
+		// only the scales with phase splits are left; the plain stack's ST goes straight to its set behind the weighted ones (batch C: ST + C y_stack)
+		ex.fused_done = true;
+		double2 *ST_arg = with_stack ? (double2 *)OUT + (size_t)W * nc - (size_t)C * 2 * nc : (double2 *)STr;
+		// (the launch covers the scales behind the last fused one only: the split scales are the far-decimated ones at the end of the list)
+		unsigned s_first = pl->S;
+		while (s_first > 0 && !pl->sc[s_first - 1].fuse_ok) s_first--;
+		ScaleRange rg; rg.s0 = s_first; rg.s1 = pl->S;
+		if (s_first == 0) rg = ScaleRange(); // (no fused scale at all: everything)
+		if (s_first < pl->S) tspws_launch_accumulate(pl, (const double2 *)part, KM, ST_arg, (double2 *)STr + nc, 1, &fa, mp.nstage, st, W, 0, 2 * nc, nullptr, &wa, rg, &ex);
+	} else {
+		tspws_launch_accumulate(pl, (const double2 *)part, KM, (double2 *)STr, (double2 *)STr + nc, 1, fuse ? &fa : nullptr, mp.nstage, st, W, 0, 2 * nc, nullptr, &wa, ScaleRange(), &ex);
+		if (with_stack) HIP_TRY(hipMemcpyAsync(OUT + (size_t)W * 2 * nc, STr + (size_t)C * 4 * nc, nc * sizeof(double2), hipMemcpyDeviceToDevice, st)); // ST of the plain stack: the last set
+	}
 	if ((rc = tspws_hip_inverse(pl, OUT, nrec, xr, s))) return rc;
 	if (C) tspws_epilogue_rows(d_ts_out, xr, N, C, st);
 	if (with_stack && (rc = tspws_hip_epilogue(d_ls, d_ts, xr + (size_t)(C + 1) * N, xr + (size_t)C * N, N, (unsigned)mtr, s))) return rc;

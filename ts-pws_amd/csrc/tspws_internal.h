@@ -95,11 +95,28 @@ struct ScaleRange {
 
 // Output of the fused forward + phase-stack kernel: slice j of the launch (traces [j*tps, (j+1)*tps)) leaves the linear and
 // phase stacks of every fuse_ok scale in accST / accPS + j*stride ([ncoef] planes).
+// Optional last step of the fused kernel (the staged masked replicas, resample.hip): the slice's stacks are COMPLETED there -- the plane
+// pairs of the `nprev` earlier stages of the same column are added in front (stage order), the weighted coefficient goes straight to
+// OUT (with the column's trace count Mv[slice]) and no pass of k_accumulate_parts over the fused scales (98 % of the coefficients) is
+// needed; the slice `keep_slice` also keeps its linear stack (the plain stack's ST is reconstructed for ls).
+struct FuseFinal {
+	const double2 *pST = nullptr, *pPS = nullptr; // plane pairs of stage 0: slice j at + j * slice_stride, stage q at + q * pair_stride
+	size_t pair_stride = 0, slice_stride = 0;
+	unsigned nprev = 0;
+	double2 *OUT = nullptr;                       // nullptr: off
+	size_t out_stride = 0;
+	const double *Mv = nullptr;
+	int mode = 0, keep_slice = -1;
+	double2 *keepST = nullptr;                    // [ncoef] set that receives the linear stack of slice keep_slice
+	double K = 0, wu = 0;
+};
+
 struct FuseOut {
 	double2 *accST = nullptr, *accPS = nullptr;
 	size_t stride = 0;
 	unsigned tps = 1;
 	bool applied = false; // set by the forward launch when the fused kernel ran
+	FuseFinal fin;        // (default: off)
 };
 
 // Phase weighting of one coefficient (tspws_biased :909-943, tspws_unbiased :965-984).
@@ -125,6 +142,7 @@ struct AccExtra {
 	size_t trace_stride = 0;          // distance of consecutive transformed traces in `part` (0: npart)
 	size_t y_fz = 0;                  // slice planes of stack b start b * y_fz further
 	const unsigned *rowmap = nullptr; // device table [nbatch][nb]: transformed trace t of stack b is trace rowmap[b nb + t] of `part`
+	bool fused_done = false;          // the fused forward kernel completed (and weighted) the stacks of its scales itself: only the others are left
 };
 
 enum { SCR_Y = 0, SCR_PART, SCR_XT, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_JKTAB, SCR_N };
