@@ -44,4 +44,14 @@ t0 = time.perf_counter()
 for _ in range(3):
     jk()
 torch.cuda.synchronize()
-print("cfg4 ms/call", (time.perf_counter() - t0) / 3 * 1e3)
+same = (time.perf_counter() - t0) / 3 * 1e3
+# a different selection every call (the host rebuilds its run lists and uploads them)
+times_b = times + 86400 * 5
+sel_b = np.zeros((Cn, mtr), np.int8)
+assert lib.tspws_jackknife_plan(sel_b.ctypes.data, times_b.ctypes.data, mtr, 1, 10, Cn) == 0
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(4):
+    pl.stack_jackknife(X, sel_b if i % 2 == 0 else sel)
+torch.cuda.synchronize()
+print("cfg4 ms/call", same, "changed selection", (time.perf_counter() - t0) / 4 * 1e3)

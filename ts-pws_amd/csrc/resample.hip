@@ -307,7 +307,7 @@ struct MaskedPlan {
 	// key
 	size_t mtr = 0, N = 0;
 	unsigned C = 0, KM = 0, gps = 0;
-	bool with_main = false, valid = false;
+	bool with_main = false, valid = false, allow_direct = true;
 	std::vector<char> sel;
 	// products
 	unsigned long long gen = 0;
@@ -331,6 +331,8 @@ struct MaskedPlan {
 	std::vector<unsigned> flush_rows;   // flush destinations (RunDesc::frow points here)
 	std::vector<unsigned> rowmap;       // [W][KM]: row of (column, group)
 	std::vector<double> Mv;             // trace count per column (replicas: selected traces; plain stack: mtr)
+	std::vector<char> blob;             // all device tables in one block, offsets below
+	size_t o_mv = 0, o_rd = 0, o_tp = 0, o_ti = 0, o_tc = 0, o_map = 0, o_seg = 0, o_car = 0, o_fr = 0, o_fx = 0;
 	unsigned row_of(unsigned g, unsigned c) const
 	{
 		const unsigned g0 = g / gps * gps, ng = std::min(gps, KM - g0);
@@ -344,10 +346,10 @@ static unsigned long long next_masked_gen()
 	return ++g;
 }
 
-static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, unsigned C, unsigned KM, bool with_main, unsigned gps)
+static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, unsigned C, unsigned KM, bool with_main, unsigned gps, bool allow_direct)
 {
 	static thread_local MaskedPlan mp;
-	if (mp.valid && mp.mtr == mtr && mp.N == N && mp.C == C && mp.KM == KM && mp.gps == gps && mp.with_main == with_main &&
+	if (mp.valid && mp.mtr == mtr && mp.N == N && mp.C == C && mp.KM == KM && mp.gps == gps && mp.with_main == with_main && mp.allow_direct == allow_direct &&
 	    mp.sel.size() == (size_t)C * mtr && !memcmp(mp.sel.data(), h_sel, (size_t)C * mtr)) return mp;
 	mp.valid = false;
 	const unsigned W = C + (with_main ? 1u : 0u);
@@ -399,7 +401,7 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 	mp.stage_run0.assign(nstage + 1, nr);
 	for (unsigned r = nr; r-- > 0;) mp.stage_run0[run_stage[r]] = r;
 	for (unsigned sg = nstage; sg-- > 0;) if (mp.stage_run0[sg] > mp.stage_run0[sg + 1]) mp.stage_run0[sg] = mp.stage_run0[sg + 1]; // (empty stages)
-	mp.direct = W <= tspws_rows_walk_wmax() && W <= 32;
+	mp.direct = allow_direct && W <= tspws_rows_walk_wmax() && W <= 32;
 	mp.rdesc.clear(); mp.flush_rows.clear(); mp.unwritten = false;
 	if (mp.direct) {
 		std::vector<char> written((size_t)KM * W, 0);
@@ -441,6 +443,9 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 			}
 		}
 	}
+	mp.seg_first.clear(); mp.stage_seg0.assign(nstage + 1, 0); mp.carry.clear(); mp.carry_ptr.assign(nstage + 1, 0);
+	mp.trow_ptr.assign((size_t)KM * W + 1, 0); mp.tidx.clear(); mp.tcoef.clear();
+	if (!mp.direct) { // the snapshot form: segments, carries, rows as signed sums of snapshots
 	// segments: a stage's runs in ~256 / (column blocks) pieces of similar trace counts, each walked by its own workgroups
 	static int seg_wgs = -1; // workgroups the streaming side aims at per stage (sweeps: TSPWS_JK_SEGWG)
 	if (seg_wgs < 0) { const char *e = getenv("TSPWS_JK_SEGWG"); seg_wgs = e ? std::max(1, atoi(e)) : 256; }
@@ -523,12 +528,34 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 		}
 	}
 	mp.trow_ptr[nrow] = (unsigned)mp.tidx.size();
+	} // (snapshot form)
 	mp.rowmap.assign((size_t)W * KM, 0);
 	for (unsigned c = 0; c < W; c++) for (unsigned g = 0; g < KM; g++) mp.rowmap[(size_t)c * KM + g] = mp.row_of(g, c);
 	mp.Mv.assign(W, 0.0);
 	for (unsigned c = 0; c < C; c++) mp.Mv[c] = (double)mp.Kc[c];
 	if (with_main) mp.Mv[C] = (double)(unsigned)mtr;
-	mp.mtr = mtr; mp.N = N; mp.C = C; mp.with_main = with_main; mp.nstage = nstage;
+	// one block for the device: runs (16-byte records) | trace counts | run descriptors | term pointers | term snapshots | term
+	// coefficients | row map | segments | carries | flush rows | fix rows -- ONE host-to-device copy per new selection
+	{
+		const size_t n_runs = mp.direct ? 0 : mp.runs.size(), n_tp = mp.trow_ptr.size(), n_t = mp.tidx.size(), n_map = mp.rowmap.size(), n_seg = mp.seg_first.size(),
+		             n_car = mp.carry.size(), n_rd = mp.rdesc.size(), n_fr = mp.flush_rows.size(), n_fx = mp.fix_row.size();
+		mp.o_mv = n_runs * sizeof(Chunk); mp.o_rd = mp.o_mv + W * sizeof(double); mp.o_tp = mp.o_rd + n_rd * sizeof(RunDesc); mp.o_ti = mp.o_tp + n_tp * 4;
+		mp.o_tc = mp.o_ti + n_t * 4; mp.o_map = mp.o_tc + n_t * 4; mp.o_seg = mp.o_map + n_map * 4; mp.o_car = mp.o_seg + n_seg * 4; mp.o_fr = mp.o_car + n_car * 4;
+		mp.o_fx = mp.o_fr + n_fr * 4;
+		mp.blob.assign(mp.o_fx + std::max<size_t>(n_fx, 1) * 4, 0);
+		char *b = mp.blob.data();
+		if (n_runs) memcpy(b, mp.runs.data(), n_runs * sizeof(Chunk));
+		memcpy(b + mp.o_mv, mp.Mv.data(), W * sizeof(double));
+		if (n_rd) memcpy(b + mp.o_rd, mp.rdesc.data(), n_rd * sizeof(RunDesc));
+		memcpy(b + mp.o_tp, mp.trow_ptr.data(), n_tp * 4);
+		if (n_t) { memcpy(b + mp.o_ti, mp.tidx.data(), n_t * 4); memcpy(b + mp.o_tc, mp.tcoef.data(), n_t * 4); }
+		memcpy(b + mp.o_map, mp.rowmap.data(), n_map * 4);
+		if (n_seg) memcpy(b + mp.o_seg, mp.seg_first.data(), n_seg * 4);
+		if (n_car) memcpy(b + mp.o_car, mp.carry.data(), n_car * 4);
+		if (n_fr) memcpy(b + mp.o_fr, mp.flush_rows.data(), n_fr * 4);
+		if (n_fx) memcpy(b + mp.o_fx, mp.fix_row.data(), n_fx * 4);
+	}
+	mp.mtr = mtr; mp.N = N; mp.C = C; mp.with_main = with_main; mp.nstage = nstage; mp.allow_direct = allow_direct;
 	mp.sel.assign(h_sel, h_sel + (size_t)C * mtr);
 	mp.gen = next_masked_gen();
 	mp.valid = true;
@@ -560,7 +587,9 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	hipStream_t st = S_(s);
 	const unsigned KM = p->Kmax;
 	const size_t N = pl->N, nc = pl->ncoef;
-	const MaskedPlan &mp = masked_plan(N, mtr, h_sel, C, KM, with_stack, masked_gps(KM));
+	static int no_direct_e = -1;
+	if (no_direct_e < 0) { const char *e = getenv("TSPWS_JK_DIRECT"); no_direct_e = (e && *e == '0') ? 1 : 0; }
+	const MaskedPlan &mp = masked_plan(N, mtr, h_sel, C, KM, with_stack, masked_gps(KM), !no_direct_e);
 	const unsigned W = mp.W, nrow = KM * W;
 	int rc;
 	void *v;
@@ -576,12 +605,11 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	const unsigned nrec = W + (with_stack ? 1u : 0u); // reconstructions: OUT of every column (+ ST of the plain stack)
 	if ((rc = scratch(pl, SCR_JKOUT, ((size_t)(nrec + 2 * W) * 2 * nc + (size_t)nrec * N) * sizeof(double), &v))) return rc;
 	double *OUT = (double *)v, *STr = OUT + (size_t)nrec * 2 * nc, *xr = STr + (size_t)W * 4 * nc;
-	// table block: runs (16-byte records) | trace counts | term pointers | term snapshots | term coefficients | row map | segments | carries
-	const size_t n_runs = mp.runs.size(), n_tp = mp.trow_ptr.size(), n_t = mp.tidx.size(), n_map = mp.rowmap.size(), n_seg = mp.seg_first.size(),
-	             n_car = mp.carry.size(), n_rd = mp.rdesc.size(), n_fr = mp.flush_rows.size(), n_fx = mp.fix_row.size();
-	const size_t o_mv = n_runs * sizeof(Chunk), o_rd = o_mv + W * sizeof(double), o_tp = o_rd + n_rd * sizeof(RunDesc), o_ti = o_tp + n_tp * 4, o_tc = o_ti + n_t * 4,
-	             o_map = o_tc + n_t * 4, o_seg = o_map + n_map * 4, o_car = o_seg + n_seg * 4, o_fr = o_car + n_car * 4, o_fx = o_fr + n_fr * 4, tab_bytes = o_fx + std::max<size_t>(n_fx, 1) * 4;
-	if ((rc = scratch(pl, SCR_JKTAB, tab_bytes, &v))) return rc;
+	static int no_direct = -1; // TSPWS_JK_DIRECT=0: the snapshot form also for few columns (tests, A/B)
+	if (no_direct < 0) { const char *e = getenv("TSPWS_JK_DIRECT"); no_direct = (e && *e == '0') ? 1 : 0; }
+	const size_t n_runs = mp.runs.size(), o_rd = mp.o_rd, o_mv = mp.o_mv, o_tp = mp.o_tp, o_ti = mp.o_ti, o_tc = mp.o_tc, o_map = mp.o_map, o_seg = mp.o_seg,
+	             o_car = mp.o_car, o_fr = mp.o_fr, o_fx = mp.o_fx;
+	if ((rc = scratch(pl, SCR_JKTAB, mp.blob.size(), &v))) return rc;
 	char *tb = (char *)v;
 	const Chunk *d_runs = (const Chunk *)tb;
 	const RunDesc *d_rd = (const RunDesc *)(tb + o_rd);
@@ -606,19 +634,7 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	// tables: only when the block does not hold this selection's already
 	if (pl->jk_gen != mp.gen) {
 		pl->jk_gen = 0;
-		if (n_runs) HIP_TRY(hipMemcpyAsync(tb, mp.runs.data(), n_runs * sizeof(Chunk), hipMemcpyHostToDevice, st));
-		HIP_TRY(hipMemcpyAsync(tb + o_mv, mp.Mv.data(), W * sizeof(double), hipMemcpyHostToDevice, st));
-		HIP_TRY(hipMemcpyAsync(tb + o_tp, mp.trow_ptr.data(), n_tp * 4, hipMemcpyHostToDevice, st));
-		if (n_t) {
-			HIP_TRY(hipMemcpyAsync(tb + o_ti, mp.tidx.data(), n_t * 4, hipMemcpyHostToDevice, st));
-			HIP_TRY(hipMemcpyAsync(tb + o_tc, mp.tcoef.data(), n_t * 4, hipMemcpyHostToDevice, st));
-		}
-		HIP_TRY(hipMemcpyAsync(tb + o_map, mp.rowmap.data(), n_map * 4, hipMemcpyHostToDevice, st));
-		HIP_TRY(hipMemcpyAsync(tb + o_seg, mp.seg_first.data(), n_seg * 4, hipMemcpyHostToDevice, st));
-		if (n_car) HIP_TRY(hipMemcpyAsync(tb + o_car, mp.carry.data(), n_car * 4, hipMemcpyHostToDevice, st));
-		if (n_rd) HIP_TRY(hipMemcpyAsync(tb + o_rd, mp.rdesc.data(), n_rd * sizeof(RunDesc), hipMemcpyHostToDevice, st));
-		if (n_fr) HIP_TRY(hipMemcpyAsync(tb + o_fr, mp.flush_rows.data(), n_fr * 4, hipMemcpyHostToDevice, st));
-		if (n_fx) HIP_TRY(hipMemcpyAsync(tb + o_fx, mp.fix_row.data(), n_fx * 4, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(tb, mp.blob.data(), mp.blob.size(), hipMemcpyHostToDevice, st));
 		pl->jk_gen = mp.gen;
 	}
 	const unsigned nbx = (unsigned)((N + 255) / 256);
@@ -628,8 +644,6 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	static int fin_env = -2;
 	if (fin_env == -2) { const char *e = getenv("TSPWS_JK_FINAL"); fin_env = e ? atoi(e) : -1; }
 	const bool fin_in_kernel = fin_env < 0 ? mp.nstage == 1 : fin_env != 0;
-	static int no_direct = -1; // TSPWS_JK_DIRECT=0: the snapshot form also for few columns (tests, A/B)
-	if (no_direct < 0) { const char *e = getenv("TSPWS_JK_DIRECT"); no_direct = (e && *e == '0') ? 1 : 0; }
 	for (unsigned sg = 0; sg < mp.nstage; sg++) {
 		// HBM-bound half of the stage on the caller's stream: running sums over the stage's traces (snapshots after every run),
 		// then its rows as signed sums of snapshots
