@@ -2,6 +2,7 @@
 // Reference citations are relative to /root/reference/src.
 #include "tspws_internal.h"
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <unordered_map>
 
@@ -352,33 +353,61 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 	if (mp.valid && mp.mtr == mtr && mp.N == N && mp.C == C && mp.KM == KM && mp.gps == gps && mp.with_main == with_main && mp.allow_direct == allow_direct &&
 	    mp.sel.size() == (size_t)C * mtr && !memcmp(mp.sel.data(), h_sel, (size_t)C * mtr)) return mp;
 	mp.valid = false;
+	struct HostTimer { // TSPWS_JK_HOSTTIME=1: what a new selection costs the host (printed per rebuild)
+		std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+		~HostTimer() { static const bool on = getenv("TSPWS_JK_HOSTTIME") != nullptr; if (on) printf("masked_plan: %.1f us of host work\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count()); }
+	} host_timer;
 	const unsigned W = C + (with_main ? 1u : 0u);
 	mp.KM = KM; mp.gps = gps; mp.W = W;
 	const unsigned nstage = (KM + gps - 1) / gps;
-	// signature of trace i: its group in every column (SIG_DELETED: not in that replica)
+	// Signature of trace i: its group in every column (SIG_DELETED: not in that replica), COLUMN-major: one sequential pass per
+	// column that also marks where a run ends (chg) and where each group of the column ends (for the stage ends).  The reference's
+	// floor((double)(k * KM) / (double)Kc) (:766) is the integer quotient (see class_sums), kept incrementally -- a 64-bit division
+	// per trace and column was a third of the 0.3 ms a new selection cost the host.
 	mp.Kc.assign(C, 0);
-	std::vector<unsigned> sig((size_t)mtr * W);
-	for (unsigned c = 0; c < C; c++) {
-		const char *row = h_sel + (size_t)c * mtr;
-		size_t n = 0;
-		for (size_t i = 0; i < mtr; i++) n += row[i] == 1;
-		mp.Kc[c] = n;
-		const size_t Kc = std::max<size_t>(n, 1);
-		size_t k = 0;
-		// (the reference's floor((double)(k * KM) / (double)Kc), :766, is the integer quotient: see class_sums)
-		for (size_t i = 0; i < mtr; i++) {
-			if (row[i] == 1) { sig[i * W + c] = (unsigned)((k * KM) / Kc); k++; }
-			else sig[i * W + c] = SIG_DELETED;
+	static thread_local std::vector<unsigned> sig;     // [W][mtr]
+	static thread_local std::vector<unsigned char> chg; // chg[i]: trace i starts a run
+	sig.resize((size_t)mtr * W);
+	chg.assign(mtr, 0);
+	if (mtr) chg[0] = 1;
+	std::vector<size_t> T(nstage, 0); // end of stage s: one past the last trace that belongs to a group of stage <= s in any column
+	for (unsigned c = 0; c < W; c++) {
+		unsigned *sc = sig.data() + (size_t)c * mtr;
+		unsigned prev = 0;
+		if (c < C) {
+			const char *row = h_sel + (size_t)c * mtr;
+			size_t n = 0;
+			for (size_t i = 0; i < mtr; i++) n += row[i] == 1;
+			mp.Kc[c] = n;
+			const size_t Kc = std::max<size_t>(n, 1);
+			size_t rem = 0;       // k KM - g Kc
+			unsigned g = 0;
+			for (size_t i = 0; i < mtr; i++) {
+				unsigned v = SIG_DELETED;
+				if (row[i] == 1) {
+					v = g;
+					{ size_t &te = T[std::min(g, KM - 1) / gps]; if (i + 1 > te) te = i + 1; }
+					rem += KM;
+					while (rem >= Kc) { rem -= Kc; g++; }
+				}
+				sc[i] = v;
+				if (i && v != prev) chg[i] = 1;
+				prev = v;
+			}
+		} else { // the plain stack: min(floor(i KM / mtr), KM - 1)
+			size_t rem = 0;
+			unsigned g = 0;
+			for (size_t i = 0; i < mtr; i++) {
+				const unsigned v = std::min(g, KM - 1);
+				{ size_t &te = T[v / gps]; if (i + 1 > te) te = i + 1; }
+				rem += KM;
+				while (rem >= mtr) { rem -= mtr; g++; }
+				sc[i] = v;
+				if (i && v != prev) chg[i] = 1;
+				prev = v;
+			}
 		}
 	}
-	if (with_main) for (size_t i = 0; i < mtr; i++) sig[i * W + C] = (unsigned)std::min<size_t>((i * KM) / mtr, KM - 1);
-	// end of stage s: one past the last trace that belongs to a group of stage <= s in any column
-	std::vector<size_t> T(nstage, 0);
-	for (size_t i = 0; i < mtr; i++)
-		for (unsigned c = 0; c < W; c++) {
-			const unsigned g = sig[i * W + c];
-			if (g != SIG_DELETED) { const unsigned sg = std::min(g, KM - 1) / gps; T[sg] = std::max(T[sg], i + 1); }
-		}
 	for (unsigned sg = 1; sg < nstage; sg++) T[sg] = std::max(T[sg], T[sg - 1]);
 	T[nstage - 1] = mtr; // (traces past the last group of every column change nothing; they ride along)
 	// runs, cut at signature changes and stage ends
@@ -389,7 +418,7 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 		for (size_t i = 0; i < mtr;) {
 			while (sg + 1 < nstage && i >= T[sg]) sg++;
 			size_t j = i + 1;
-			while (j < mtr && j < T[sg] && !memcmp(&sig[i * W], &sig[j * W], W * sizeof(unsigned))) j++;
+			while (j < mtr && j < T[sg] && !chg[j]) j++;
 			Chunk c; c.t0 = i; c.count = (unsigned)(j - i); c.row = 0;
 			if (c.count != j - i) { j = i + 0xFFFFFFF0ull; c.count = 0xFFFFFFF0u; } // (a run longer than 2^32 traces is cut)
 			mp.runs.push_back(c);
@@ -397,6 +426,7 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 			i = j;
 		}
 	}
+	auto SIG = [&](unsigned r, unsigned c) -> unsigned { return sig[(size_t)c * mtr + mp.runs[r].t0]; }; // group of run r in column c
 	const unsigned nr = (unsigned)mp.runs.size();
 	mp.stage_run0.assign(nstage + 1, nr);
 	for (unsigned r = nr; r-- > 0;) mp.stage_run0[run_stage[r]] = r;
@@ -406,25 +436,22 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 	if (mp.direct) {
 		std::vector<char> written((size_t)KM * W, 0);
 		mp.rdesc.resize(nr);
-		for (unsigned r = 0; r < nr; r++) {
-			RunDesc d;
-			memset(&d, 0, sizeof d);
-			d.t0 = mp.runs[r].t0; d.count = mp.runs[r].count; d.frow = (unsigned)mp.flush_rows.size();
-			const unsigned *sr = &sig[mp.runs[r].t0 * W];
-			for (unsigned c = 0; c < W; c++) {
-				if (sr[c] == SIG_DELETED) continue;
-				d.member |= 1u << c;
-				// column c's group ends with this run when the next run that belongs to c has another group (or there is none)
-				unsigned q = r + 1;
-				while (q < nr && sig[mp.runs[q].t0 * W + c] == SIG_DELETED) q++;
-				if (q == nr || sig[mp.runs[q].t0 * W + c] != sr[c]) {
-					d.flush |= 1u << c;
-					const unsigned row = mp.row_of(std::min(sr[c], KM - 1), c);
-					mp.flush_rows.push_back(row);
-					written[row] = 1;
-				}
+		for (unsigned r = 0; r < nr; r++) { RunDesc d; memset(&d, 0, sizeof d); d.t0 = mp.runs[r].t0; d.count = mp.runs[r].count; mp.rdesc[r] = d; }
+		// column by column, from the last run back: a run that belongs to the column ends the column's group when the next run that
+		// belongs to it has another group (or there is none)
+		for (unsigned c = 0; c < W; c++) {
+			unsigned next_g = SIG_DELETED;
+			for (unsigned r = nr; r-- > 0;) {
+				const unsigned g = SIG(r, c);
+				if (g == SIG_DELETED) continue;
+				mp.rdesc[r].member |= 1u << c;
+				if (g != next_g) { mp.rdesc[r].flush |= 1u << c; written[mp.row_of(std::min(g, KM - 1), c)] = 1; }
+				next_g = g;
 			}
-			mp.rdesc[r] = d;
+		}
+		for (unsigned r = 0; r < nr; r++) { // flush destinations in ascending column order
+			mp.rdesc[r].frow = (unsigned)mp.flush_rows.size();
+			for (unsigned c = 0; c < W; c++) if ((mp.rdesc[r].flush >> c) & 1u) mp.flush_rows.push_back(mp.row_of(std::min(SIG(r, c), KM - 1), c));
 		}
 		for (char w : written) if (!w) mp.unwritten = true;
 		// two segments of similar trace counts per stage, and what the second one's first stores lack
@@ -509,7 +536,7 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 	for (unsigned c = 0; c < W; c++) {
 		unsigned a = 0, cur = SIG_DELETED;
 		for (unsigned r = 0; r <= nr; r++) {
-			const unsigned g = r < nr ? sig[mp.runs[r].t0 * W + c] : SIG_DELETED;
+			const unsigned g = r < nr ? SIG(r, c) : SIG_DELETED;
 			if (g == cur) continue;
 			if (cur != SIG_DELETED) { auto &L = lists[mp.row_of(std::min(cur, KM - 1), c)]; add_G(L, r, +1); add_G(L, a, -1); }
 			cur = g; a = r;
