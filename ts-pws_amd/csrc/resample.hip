@@ -39,19 +39,6 @@ extern "C" int tspws_jackknife_plan(char *sel, const time_t *tm, size_t mtr, uns
 	return 0;
 }
 
-// P_c[g][n] = sum of class sums whose signature sends them to group g of replica c.
-// cls_of[(c*Kmax+g)] lists are given as CSR: row_ptr / cols.
-__global__ void __launch_bounds__(256) k_combine_classes(const double *__restrict__ cls, size_t ldc, const unsigned *__restrict__ row_ptr,
-                                                         const unsigned *__restrict__ cols, double *__restrict__ P, size_t N)
-{
-	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
-	if (n >= N) return;
-	const unsigned row = blockIdx.y;
-	double acc = 0;
-	for (unsigned j = row_ptr[row]; j < row_ptr[row + 1]; j++) acc += cls[(size_t)cols[j] * ldc + n];
-	P[(size_t)row * N + n] = acc;
-}
-
 // replica linear stack in the time domain, :799-811: (sum_g P[g]) * (1/K)
 // rows of replica c.  gps == 0: replica-major rows, P[(c Kmax + g) N]; gps > 0: the staged layout of the pipelined call,
 // row(g, c) = g0 W + c ng + (g - g0) with g0 = g / gps * gps, ng = min(gps, Kmax - g0)
@@ -74,147 +61,18 @@ __global__ void __launch_bounds__(256) k_jk_linear(const double *__restrict__ P,
 	out[n] = (float)(acc * invK);
 }
 
-// ONE pass over the traces for any number of masked two-stage replicas: traces with the same destination group in every
-// replica form a class (maximal runs of consecutive traces; equal signatures of separate runs share a class), the
-// streaming kernel sums every class once, and each (replica, group) partial stack is a sum of class sums.
-// with_main: the plain two-stage groups of ALL traces (ts_pws1f_lib.c:876) are one more signature column.
-// Sharded ensembles: d_x holds traces [first, first + mtr_local) of the mtr the selection refers to; signatures come from
-// the GLOBAL trace index (a trace's group in a replica is its rank among ALL selected traces, :766), the sums run over the
-// shard's traces only, so the rows of all shards add up to the rows of the whole ensemble.
-//
-// A ClassSums object belongs to ONE call: it owns the host tables whose uploads may still be in flight, so the call
-// synchronises its stream before the object goes out of scope (cs_done).
 static constexpr unsigned SIG_DELETED = ~0u; // (32-bit signatures: Kmax is an unsigned in t_tsPWS, any value is a legal group count)
-struct ClassSums {
-	unsigned C = 0, KM = 0, ncls = 0;
-	std::vector<std::vector<unsigned>> sig;         // per class: group in each replica (SIG_DELETED = deleted) [+ plain group]
-	std::vector<size_t> Kc;                         // traces per replica
-	std::vector<Chunk> chunks;
-	std::vector<unsigned> row_first;
-	std::vector<std::vector<unsigned>> tabs;        // CSR tables of the combine passes (row_ptr | cols), one per pass
-	size_t tab_used = 0;                            // unsigneds of SCR_JKTAB handed out so far
-};
 
+// (host tables handed to asynchronous copies: the call synchronises its stream before they can change)
 static int cs_done(hipStream_t st) { HIP_TRY(hipStreamSynchronize(st)); return 0; }
 
-static int class_sums(tspws_hip_plan *pl, ClassSums &cs, unsigned KM, const float *d_x, size_t ld, size_t mtr, const char *h_sel, unsigned C,
-                      bool with_main, hipStream_t st, size_t first, size_t mtr_local)
-{
-	if (first > mtr || mtr_local > mtr - first) return fail(TSPWS_E_ARG, "class sums: shard outside the ensemble");
-	const size_t lo = first, hi = first + mtr_local;
-	const size_t N = pl->N;
-	const unsigned W = C + (with_main ? 1u : 0u);
-	const unsigned clen = tspws_chunk_len_for(N, std::max<size_t>(mtr_local, 1));
-	// The classes depend on the selection and the shapes only.  A caller that stacks many ensembles with the same time stamps (the
-	// same days for every station pair) repeats them: the last call's classes are kept per host thread, keyed by CONTENT (the
-	// selection is compared byte for byte), so a hit skips ~0.2 ms of host work per call at 10 000 traces x 10 replicas.
-	struct Memo { size_t mtr = 0, first = 0, mtr_local = 0; unsigned C = 0, KM = 0, clen = 0; bool with_main = false, valid = false;
-	              std::vector<char> sel; ClassSums cs; };
-	static thread_local Memo memo;
-	const bool hit = memo.valid && memo.mtr == mtr && memo.first == first && memo.mtr_local == mtr_local && memo.C == C && memo.KM == KM &&
-	                 memo.clen == clen && memo.with_main == with_main && memo.sel.size() == (size_t)C * mtr && !memcmp(memo.sel.data(), h_sel, (size_t)C * mtr);
-	if (hit) { cs.sig = memo.cs.sig; cs.Kc = memo.cs.Kc; cs.chunks = memo.cs.chunks; cs.row_first = memo.cs.row_first; }
-	else {
-	// signature of trace i: group index in every replica (SIG_DELETED = deleted)
-	// (the reference's floor((double)(k * KM) / (double)Kc), :766, is the integer quotient: k * KM < 2^53 and a non-integer
-	// quotient is at least 1 / Kc away from the next integer, far more than a rounding of the division)
-	cs.Kc.assign(C, 0);
-	for (unsigned c = 0; c < C; c++) {
-		const char *row = h_sel + (size_t)c * mtr;
-		size_t n = 0;
-		for (size_t i = 0; i < mtr; i++) n += row[i] == 1;
-		cs.Kc[c] = n;
-	}
-	std::vector<unsigned> sig((size_t)mtr * W);
-	for (unsigned c = 0; c < C; c++) {
-		const char *row = h_sel + (size_t)c * mtr;
-		const size_t Kc = std::max<size_t>(cs.Kc[c], 1);
-		size_t k = 0;
-		for (size_t i = 0; i < mtr; i++) {
-			if (row[i] == 1) { sig[i * W + c] = (unsigned)((k * KM) / Kc); k++; }
-			else sig[i * W + c] = SIG_DELETED;
-		}
-	}
-	if (with_main) for (size_t i = 0; i < mtr; i++) sig[i * W + C] = (unsigned)std::min<size_t>((i * KM) / mtr, KM - 1);
-	cs.sig.clear(); cs.chunks.clear();
-	std::vector<std::vector<Chunk>> cls_chunks;
-	std::unordered_map<std::string, size_t> cls_of; // signature bytes -> class (classes numbered in order of first appearance)
-	for (size_t i = lo; i < hi;) {
-		size_t j = i + 1;
-		while (j < hi && !memcmp(&sig[i * W], &sig[j * W], W * sizeof(unsigned))) j++;
-		const std::string key((const char *)&sig[i * W], W * sizeof(unsigned));
-		auto it = cls_of.find(key);
-		size_t id;
-		if (it == cls_of.end()) {
-			id = cs.sig.size();
-			cls_of.emplace(key, id);
-			cs.sig.emplace_back(sig.begin() + i * W, sig.begin() + (i + 1) * W);
-			cls_chunks.emplace_back();
-		} else id = it->second;
-		for (size_t t = i; t < j; t += clen) {
-			Chunk c; c.t0 = t - lo; c.count = (unsigned)std::min<size_t>(clen, j - t); c.row = (unsigned)id; // t0: row of d_x
-			cls_chunks[id].push_back(c);
-		}
-		i = j;
-	}
-	const unsigned ncls_b = (unsigned)cs.sig.size();
-	cs.row_first.assign(ncls_b + 1, 0);
-	for (unsigned id = 0; id < ncls_b; id++) {
-		cs.row_first[id] = (unsigned)cs.chunks.size();
-		cs.chunks.insert(cs.chunks.end(), cls_chunks[id].begin(), cls_chunks[id].end());
-	}
-	cs.row_first[ncls_b] = (unsigned)cs.chunks.size();
-	memo.valid = false;
-	memo.mtr = mtr; memo.first = first; memo.mtr_local = mtr_local; memo.C = C; memo.KM = KM; memo.clen = clen; memo.with_main = with_main;
-	memo.sel.assign(h_sel, h_sel + (size_t)C * mtr);
-	memo.cs.sig = cs.sig; memo.cs.Kc = cs.Kc; memo.cs.chunks = cs.chunks; memo.cs.row_first = cs.row_first;
-	memo.valid = true;
-	} // (miss)
-	const unsigned ncls = (unsigned)cs.sig.size();
-	int rc;
-	void *v;
-	if ((rc = scratch(pl, SCR_CLS, std::max<size_t>((size_t)ncls * N, 1) * sizeof(double), &v))) return rc;
-	if (ncls && (rc = tspws_run_chunks(pl, d_x, ld, N, cs.chunks, cs.row_first, ncls, (double *)v, N, st, false))) return rc; // own table: not the cached one
-	// room for the CSR tables of every combine pass of this call (each pass gets its own piece of the block)
-	const size_t tab_max = 2 * ((size_t)W * KM + 2 + (size_t)W * ncls);
-	if ((rc = scratch(pl, SCR_JKTAB, tab_max * sizeof(unsigned), &v))) return rc;
-	cs.C = C; cs.KM = KM; cs.ncls = ncls; cs.tab_used = 0;
-	return 0;
-}
-
-// d_P[(col - col0) * KM + g][n] = sum of the class sums whose signature column `col` is g, for col in [col0, col1)
-static int combine_classes(tspws_hip_plan *pl, ClassSums &cs, unsigned col0, unsigned col1, double *d_P, hipStream_t st)
-{
-	const unsigned KM = cs.KM, nrow = (col1 - col0) * KM;
-	const size_t N = pl->N;
-	cs.tabs.emplace_back();
-	std::vector<unsigned> &tab = cs.tabs.back(); // [nrow + 1] row pointers, then the columns
-	tab.assign((size_t)nrow + 1, 0);
-	for (unsigned c = col0; c < col1; c++)
-		for (unsigned g = 0; g < KM; g++) {
-			tab[(size_t)(c - col0) * KM + g] = (unsigned)(tab.size() - (nrow + 1));
-			for (unsigned id = 0; id < cs.ncls; id++) if (cs.sig[id][c] == g) tab.push_back(id);
-		}
-	tab[nrow] = (unsigned)(tab.size() - (nrow + 1));
-	if ((cs.tab_used + tab.size()) * sizeof(unsigned) > pl->scr_bytes[SCR_JKTAB]) return fail(TSPWS_E_ARG, "combine_classes: table block too small");
-	pl->jk_gen = 0; // (the table block no longer holds a pipelined call's tables)
-	unsigned *d_rp = (unsigned *)pl->scr[SCR_JKTAB] + cs.tab_used, *d_cols = d_rp + nrow + 1;
-	cs.tab_used += tab.size();
-	HIP_TRY(hipMemcpyAsync(d_rp, tab.data(), tab.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
-	for (unsigned r0 = 0; r0 < nrow; r0 += 65535) {
-		const unsigned ny = std::min(nrow - r0, 65535u);
-		hipLaunchKernelGGL(k_combine_classes, dim3((unsigned)((N + 255) / 256), ny), dim3(256), 0, st, (const double *)pl->scr[SCR_CLS], N, d_rp + r0, d_cols,
-		                   d_P + (size_t)r0 * N, N);
-	}
-	HIP_TRY(hipGetLastError());
-	return 0;
-}
-
-// Rows of the masked replicas: d_P[c * KM + g][N] (SCR_JKP; the replicas' trace counts follow the rows).
+// Rows of the masked replicas: d_P[c * KM + g][N] (SCR_JKP; the replicas' trace counts follow the rows).  Always with room for one
+// more column -- the plain groups, which the one-pass walk leaves behind the replicas -- so that the block does not move between
+// the calls of one sharded jackknife.
 static int replica_rows_buffer(tspws_hip_plan *pl, unsigned KM, unsigned C, double **d_P)
 {
 	void *v;
-	int rc = scratch(pl, SCR_JKP, ((size_t)C * KM * pl->N + C) * sizeof(double), &v);
+	int rc = scratch(pl, SCR_JKP, ((size_t)(C + 1) * KM * pl->N + C + 1) * sizeof(double), &v);
 	if (rc) return rc;
 	*d_P = (double *)v;
 	return 0;
@@ -306,7 +164,7 @@ static int finish_replicas(tspws_hip_plan *pl, const t_tsPWS *p, double *d_P, co
 // ------------------------------------------------------------------------------------------
 struct MaskedPlan {
 	// key
-	size_t mtr = 0, N = 0;
+	size_t mtr = 0, N = 0, first = 0, mtr_local = 0;
 	unsigned C = 0, KM = 0, gps = 0;
 	bool with_main = false, valid = false, allow_direct = true;
 	std::vector<char> sel;
@@ -347,10 +205,13 @@ static unsigned long long next_masked_gen()
 	return ++g;
 }
 
-static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, unsigned C, unsigned KM, bool with_main, unsigned gps, bool allow_direct)
+// Trace shards: the signatures come from the WHOLE selection (a trace's group in a replica is its rank among all selected traces, :766),
+// the runs cover the shard's traces [first, first + mtr_local) only, with trace indices local to the shard.
+static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, unsigned C, unsigned KM, bool with_main, unsigned gps, bool allow_direct,
+                                     size_t first, size_t mtr_local)
 {
 	static thread_local MaskedPlan mp;
-	if (mp.valid && mp.mtr == mtr && mp.N == N && mp.C == C && mp.KM == KM && mp.gps == gps && mp.with_main == with_main && mp.allow_direct == allow_direct &&
+	if (mp.valid && mp.mtr == mtr && mp.N == N && mp.C == C && mp.KM == KM && mp.gps == gps && mp.with_main == with_main && mp.allow_direct == allow_direct && mp.first == first && mp.mtr_local == mtr_local &&
 	    mp.sel.size() == (size_t)C * mtr && !memcmp(mp.sel.data(), h_sel, (size_t)C * mtr)) return mp;
 	mp.valid = false;
 	struct HostTimer { // TSPWS_JK_HOSTTIME=1: what a new selection costs the host (printed per rebuild)
@@ -362,14 +223,15 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 	const unsigned nstage = (KM + gps - 1) / gps;
 	// Signature of trace i: its group in every column (SIG_DELETED: not in that replica), COLUMN-major: one sequential pass per
 	// column that also marks where a run ends (chg) and where each group of the column ends (for the stage ends).  The reference's
-	// floor((double)(k * KM) / (double)Kc) (:766) is the integer quotient (see class_sums), kept incrementally -- a 64-bit division
+	// floor((double)(k * KM) / (double)Kc) (:766) is the integer quotient (k KM < 2^53 and a non-integer quotient is at least 1 / Kc away from the next integer), kept incrementally -- a 64-bit division
 	// per trace and column was a third of the 0.3 ms a new selection cost the host.
 	mp.Kc.assign(C, 0);
 	static thread_local std::vector<unsigned> sig;     // [W][mtr]
 	static thread_local std::vector<unsigned char> chg; // chg[i]: trace i starts a run
 	sig.resize((size_t)mtr * W);
 	chg.assign(mtr, 0);
-	if (mtr) chg[0] = 1;
+	const size_t lo = first, hi = first + mtr_local; // the shard
+	if (lo < hi) chg[lo] = 1;
 	std::vector<size_t> T(nstage, 0); // end of stage s: one past the last trace that belongs to a group of stage <= s in any column
 	for (unsigned c = 0; c < W; c++) {
 		unsigned *sc = sig.data() + (size_t)c * mtr;
@@ -386,7 +248,7 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 				unsigned v = SIG_DELETED;
 				if (row[i] == 1) {
 					v = g;
-					{ size_t &te = T[std::min(g, KM - 1) / gps]; if (i + 1 > te) te = i + 1; }
+					if (i >= lo && i < hi) { size_t &te = T[std::min(g, KM - 1) / gps]; if (i - lo + 1 > te) te = i - lo + 1; }
 					rem += KM;
 					while (rem >= Kc) { rem -= Kc; g++; }
 				}
@@ -399,7 +261,7 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 			unsigned g = 0;
 			for (size_t i = 0; i < mtr; i++) {
 				const unsigned v = std::min(g, KM - 1);
-				{ size_t &te = T[v / gps]; if (i + 1 > te) te = i + 1; }
+				if (i >= lo && i < hi) { size_t &te = T[v / gps]; if (i - lo + 1 > te) te = i - lo + 1; }
 				rem += KM;
 				while (rem >= mtr) { rem -= mtr; g++; }
 				sc[i] = v;
@@ -409,16 +271,16 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 		}
 	}
 	for (unsigned sg = 1; sg < nstage; sg++) T[sg] = std::max(T[sg], T[sg - 1]);
-	T[nstage - 1] = mtr; // (traces past the last group of every column change nothing; they ride along)
-	// runs, cut at signature changes and stage ends
+	T[nstage - 1] = mtr_local; // (traces past the last group of every column change nothing; they ride along)
+	// runs of the shard (local trace indices), cut at signature changes and stage ends
 	mp.runs.clear();
 	std::vector<unsigned> run_stage;
 	{
 		unsigned sg = 0;
-		for (size_t i = 0; i < mtr;) {
+		for (size_t i = 0; i < mtr_local;) {
 			while (sg + 1 < nstage && i >= T[sg]) sg++;
 			size_t j = i + 1;
-			while (j < mtr && j < T[sg] && !chg[j]) j++;
+			while (j < mtr_local && j < T[sg] && !chg[lo + j]) j++;
 			Chunk c; c.t0 = i; c.count = (unsigned)(j - i); c.row = 0;
 			if (c.count != j - i) { j = i + 0xFFFFFFF0ull; c.count = 0xFFFFFFF0u; } // (a run longer than 2^32 traces is cut)
 			mp.runs.push_back(c);
@@ -426,7 +288,7 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 			i = j;
 		}
 	}
-	auto SIG = [&](unsigned r, unsigned c) -> unsigned { return sig[(size_t)c * mtr + mp.runs[r].t0]; }; // group of run r in column c
+	auto SIG = [&](unsigned r, unsigned c) -> unsigned { return sig[(size_t)c * mtr + lo + mp.runs[r].t0]; }; // group of run r in column c
 	const unsigned nr = (unsigned)mp.runs.size();
 	mp.stage_run0.assign(nstage + 1, nr);
 	for (unsigned r = nr; r-- > 0;) mp.stage_run0[run_stage[r]] = r;
@@ -582,7 +444,7 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 		if (n_fr) memcpy(b + mp.o_fr, mp.flush_rows.data(), n_fr * 4);
 		if (n_fx) memcpy(b + mp.o_fx, mp.fix_row.data(), n_fx * 4);
 	}
-	mp.mtr = mtr; mp.N = N; mp.C = C; mp.with_main = with_main; mp.nstage = nstage; mp.allow_direct = allow_direct;
+	mp.mtr = mtr; mp.N = N; mp.C = C; mp.with_main = with_main; mp.nstage = nstage; mp.allow_direct = allow_direct; mp.first = first; mp.mtr_local = mtr_local;
 	mp.sel.assign(h_sel, h_sel + (size_t)C * mtr);
 	mp.gen = next_masked_gen();
 	mp.valid = true;
@@ -608,15 +470,91 @@ static bool masked_pipeline_ok(const tspws_hip_plan *pl, unsigned KM, unsigned W
 	return (size_t)KM * W * pl->npart * sizeof(double2) <= tspws_part_budget_bytes();
 }
 
+// device side of a MaskedPlan: the table block (uploaded when the plan's block does not hold this selection's already) and, for the
+// direct walk, the [tail | end | carry] rows between its segments and stages
+struct MaskedDev {
+	char *tb = nullptr;
+	double *carryblk = nullptr;
+	bool have_carry = false;
+};
+
+static int masked_tables(tspws_hip_plan *pl, const MaskedPlan &mp, hipStream_t st, MaskedDev &dv)
+{
+	void *v;
+	int rc;
+	if ((rc = scratch(pl, SCR_JKTAB, mp.blob.size(), &v))) return rc;
+	dv.tb = (char *)v;
+	if (mp.direct) { if ((rc = scratch(pl, SCR_CLS, (size_t)3 * mp.W * mp.N * sizeof(double), &v))) return rc; dv.carryblk = (double *)v; }
+	if (pl->jk_gen != mp.gen) {
+		pl->jk_gen = 0;
+		HIP_TRY(hipMemcpyAsync(dv.tb, mp.blob.data(), mp.blob.size(), hipMemcpyHostToDevice, st));
+		pl->jk_gen = mp.gen;
+	}
+	dv.have_carry = false;
+	return 0;
+}
+
+// the streaming side of stage sg: the stage's rows [g0 W, (g0 + ng) W) of d_rows from the shard's traces
+static int masked_stream_stage(tspws_hip_plan *pl, const MaskedPlan &mp, MaskedDev &dv, const float *d_x, size_t ld, double *d_rows, unsigned sg, hipStream_t st)
+{
+	const size_t N = mp.N;
+	const unsigned W = mp.W, KM = mp.KM, nrow = KM * W;
+	const unsigned g0 = sg * mp.gps, ng = std::min(mp.gps, KM - g0), r0 = g0 * W, r1 = r0 + ng * W;
+	int rc;
+	if (mp.direct) {
+		// few columns: the rows themselves from the walk (a running sum per column in registers; k_rows_walk)
+		if (sg == 0 && mp.unwritten) HIP_TRY(hipMemsetAsync(d_rows, 0, (size_t)nrow * N * sizeof(double), st));
+		const unsigned q0 = mp.stage_run0[sg], q1 = mp.stage_run0[sg + 1];
+		if (q1 > q0) {
+			if ((rc = tspws_rows_walk_launch(d_x, ld, N, (const RunDesc *)(dv.tb + mp.o_rd), q0, mp.stage_mid[sg], q1, W, (const unsigned *)(dv.tb + mp.o_fr),
+			                                 (const unsigned *)(dv.tb + mp.o_fx) + (size_t)sg * W, d_rows, dv.carryblk, dv.have_carry ? 1 : 0, sg + 1 < mp.nstage ? 1 : 0, st)))
+				return rc;
+			dv.have_carry = true;
+		}
+		return 0;
+	}
+	// running sums over the stage's traces (snapshots after every run), then its rows as signed sums of snapshots
+	const unsigned k0 = mp.stage_seg0[sg], nseg = mp.stage_seg0[sg + 1] - k0 - 1;
+	double *d_snap = nullptr; size_t ldpc = 0;
+	if ((rc = tspws_prefix_launch(pl, d_x, ld, N, (const Chunk *)dv.tb, (const unsigned *)(dv.tb + mp.o_seg) + k0, nseg, mp.runs.size(),
+	                              (const unsigned *)(dv.tb + mp.o_car) + mp.carry_ptr[sg], mp.carry_ptr[sg + 1] - mp.carry_ptr[sg], &d_snap, &ldpc, st)))
+		return rc;
+	tspws_combine_terms_launch(d_snap, ldpc, (const unsigned *)(dv.tb + mp.o_tp) + r0, (const unsigned *)(dv.tb + mp.o_ti), (const float *)(dv.tb + mp.o_tc), r1 - r0,
+	                           d_rows + (size_t)r0 * N, N, st);
+	return 0;
+}
+
+static bool masked_allow_direct()
+{
+	static int no_direct = -1; // TSPWS_JK_DIRECT=0: the snapshot form also for few columns (tests, A/B)
+	if (no_direct < 0) { const char *e = getenv("TSPWS_JK_DIRECT"); no_direct = (e && *e == '0') ? 1 : 0; }
+	return !no_direct;
+}
+
+// The rows of every column from ONE pass over a shard, replica-major: d_rows[(c KM + g) N] for the replicas, the plain groups of
+// ALL traces (with_main, ts_pws1f_lib.c:876) as column C behind them -- one stage of KM groups, where row(g, c) = c KM + g.
+// Sharded ensembles: d_x holds traces [first, first + mtr_local) of the mtr the selection refers to; the rows of all shards add up
+// to the rows of the whole ensemble.  (The parts-budget fallback of the one-device call and the sharded jackknife.)
+static int masked_rows(tspws_hip_plan *pl, unsigned KM, const float *d_x, size_t ld, size_t mtr, const char *h_sel, unsigned C, bool with_main,
+                       size_t first, size_t mtr_local, hipStream_t st, double **d_rows, const MaskedPlan **plan)
+{
+	if (first > mtr || mtr_local > mtr - first) return fail(TSPWS_E_ARG, "masked rows: shard outside the ensemble");
+	const MaskedPlan &mp = masked_plan(pl->N, mtr, h_sel, C, KM, with_main, KM, masked_allow_direct(), first, mtr_local);
+	int rc;
+	if ((rc = replica_rows_buffer(pl, KM, C, d_rows))) return rc;
+	MaskedDev dv;
+	if ((rc = masked_tables(pl, mp, st, dv)) || (rc = masked_stream_stage(pl, mp, dv, d_x, ld, *d_rows, 0, st))) return rc;
+	*plan = &mp;
+	return 0;
+}
+
 static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, const float *d_x, size_t ld, size_t mtr, const char *h_sel, unsigned C,
                                       float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *s, bool with_stack, float *d_ls, float *d_ts)
 {
 	hipStream_t st = S_(s);
 	const unsigned KM = p->Kmax;
 	const size_t N = pl->N, nc = pl->ncoef;
-	static int no_direct_e = -1;
-	if (no_direct_e < 0) { const char *e = getenv("TSPWS_JK_DIRECT"); no_direct_e = (e && *e == '0') ? 1 : 0; }
-	const MaskedPlan &mp = masked_plan(N, mtr, h_sel, C, KM, with_stack, masked_gps(KM), !no_direct_e);
+	const MaskedPlan &mp = masked_plan(N, mtr, h_sel, C, KM, with_stack, masked_gps(KM), masked_allow_direct(), 0, mtr);
 	const unsigned W = mp.W, nrow = KM * W;
 	int rc;
 	void *v;
@@ -632,21 +570,10 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	const unsigned nrec = W + (with_stack ? 1u : 0u); // reconstructions: OUT of every column (+ ST of the plain stack)
 	if ((rc = scratch(pl, SCR_JKOUT, ((size_t)(nrec + 2 * W) * 2 * nc + (size_t)nrec * N) * sizeof(double), &v))) return rc;
 	double *OUT = (double *)v, *STr = OUT + (size_t)nrec * 2 * nc, *xr = STr + (size_t)W * 4 * nc;
-	static int no_direct = -1; // TSPWS_JK_DIRECT=0: the snapshot form also for few columns (tests, A/B)
-	if (no_direct < 0) { const char *e = getenv("TSPWS_JK_DIRECT"); no_direct = (e && *e == '0') ? 1 : 0; }
-	const size_t n_runs = mp.runs.size(), o_rd = mp.o_rd, o_mv = mp.o_mv, o_tp = mp.o_tp, o_ti = mp.o_ti, o_tc = mp.o_tc, o_map = mp.o_map, o_seg = mp.o_seg,
-	             o_car = mp.o_car, o_fr = mp.o_fr, o_fx = mp.o_fx;
-	if ((rc = scratch(pl, SCR_JKTAB, mp.blob.size(), &v))) return rc;
-	char *tb = (char *)v;
-	const Chunk *d_runs = (const Chunk *)tb;
-	const RunDesc *d_rd = (const RunDesc *)(tb + o_rd);
-	const unsigned *d_fr = (const unsigned *)(tb + o_fr), *d_fx = (const unsigned *)(tb + o_fx);
-	double *d_carryblk = nullptr; // direct walk: [tail of segment A | end of segment B | carry into the next stage], W rows each
-	if (mp.direct) { if ((rc = scratch(pl, SCR_CLS, (size_t)3 * W * N * sizeof(double), &v))) return rc; d_carryblk = (double *)v; }
-	double *d_Mv = (double *)(tb + o_mv);
-	const unsigned *d_tp = (const unsigned *)(tb + o_tp), *d_ti = (const unsigned *)(tb + o_ti), *d_map = (const unsigned *)(tb + o_map),
-	               *d_seg = (const unsigned *)(tb + o_seg), *d_car = (const unsigned *)(tb + o_car);
-	const float *d_tc = (const float *)(tb + o_tc);
+	MaskedDev dv;
+	if ((rc = masked_tables(pl, mp, st, dv))) return rc;
+	double *d_Mv = (double *)(dv.tb + mp.o_mv);
+	const unsigned *d_map = (const unsigned *)(dv.tb + mp.o_map);
 	if (!pl->xf) {
 		int lo = 0, hi = 0;
 		HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi)); // (lo = least urgent)
@@ -658,38 +585,16 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 		HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
 		pl->stage_ev.push_back(e);
 	}
-	// tables: only when the block does not hold this selection's already
-	if (pl->jk_gen != mp.gen) {
-		pl->jk_gen = 0;
-		HIP_TRY(hipMemcpyAsync(tb, mp.blob.data(), mp.blob.size(), hipMemcpyHostToDevice, st));
-		pl->jk_gen = mp.gen;
-	}
 	const unsigned nbx = (unsigned)((N + 255) / 256);
-	bool have_carry = false;
 	// the last stage's forward kernel completes the stacks itself (TSPWS_JK_FINAL: 0 never, 1 always; default: with ONE stage only -- with
 	// earlier stages' plane pairs to add in front the time just moves from the accumulation into the kernel's epilogue)
 	static int fin_env = -2;
 	if (fin_env == -2) { const char *e = getenv("TSPWS_JK_FINAL"); fin_env = e ? atoi(e) : -1; }
 	const bool fin_in_kernel = fin_env < 0 ? mp.nstage == 1 : fin_env != 0;
 	for (unsigned sg = 0; sg < mp.nstage; sg++) {
-		// HBM-bound half of the stage on the caller's stream: running sums over the stage's traces (snapshots after every run),
-		// then its rows as signed sums of snapshots
-		const unsigned k0 = mp.stage_seg0[sg], nseg = mp.stage_seg0[sg + 1] - k0 - 1;
-		double *d_snap = nullptr; size_t ldpc = 0;
-		if (mp.direct && !no_direct) {
-			// few columns: the rows themselves from the walk (a running sum per column in registers; k_rows_walk)
-			if (sg == 0 && mp.unwritten) HIP_TRY(hipMemsetAsync(d_rows, 0, (size_t)nrow * N * sizeof(double), st));
-			const unsigned q0 = mp.stage_run0[sg], q1 = mp.stage_run0[sg + 1];
-			if (q1 > q0) {
-				if ((rc = tspws_rows_walk_launch(d_x, ld, N, d_rd, q0, mp.stage_mid[sg], q1, W, d_fr, d_fx + (size_t)sg * W, d_rows, d_carryblk, have_carry ? 1 : 0,
-				                                 sg + 1 < mp.nstage ? 1 : 0, st))) return rc;
-				have_carry = true;
-			}
-		} else if ((rc = tspws_prefix_launch(pl, d_x, ld, N, d_runs, d_seg + k0, nseg, n_runs, d_car + mp.carry_ptr[sg], mp.carry_ptr[sg + 1] - mp.carry_ptr[sg], &d_snap,
-		                                     &ldpc, st)))
-			return rc;
+		// HBM-bound half of the stage on the caller's stream: its rows from its traces
+		if ((rc = masked_stream_stage(pl, mp, dv, d_x, ld, d_rows, sg, st))) return rc;
 		const unsigned g0 = sg * mp.gps, ng = std::min(mp.gps, KM - g0), r0 = g0 * W, r1 = r0 + ng * W;
-		if (!(mp.direct && !no_direct)) tspws_combine_terms_launch(d_snap, ldpc, d_tp + r0, d_ti, d_tc, r1 - r0, d_rows + (size_t)r0 * N, N, st);
 		HIP_TRY(hipEventRecord(pl->stage_ev[sg], st));
 		// FP64-bound half on the second stream: the stage's rows, one slice of ng rows per column
 		HIP_TRY(hipStreamWaitEvent(pl->xf, pl->stage_ev[sg], 0));
@@ -755,17 +660,18 @@ static int masked_two_stage(tspws_hip_plan *pl, const t_tsPWS *p, const float *d
 		if (rc) { (void)hipStreamSynchronize(pl->xf); (void)cs_done(st); }
 		return rc;
 	}
-	ClassSums cs;
-	if ((rc = class_sums(pl, cs, KM, d_x, ld, mtr, h_sel, C, with_stack, st, 0, mtr))) { (void)cs_done(st); return rc; }
+	// over the parts budget (or TSPWS_JK_PIPELINE=0): the same one-pass rows, then the replicas in batches that fit
 	double *d_P;
-	if ((rc = replica_rows_buffer(pl, KM, C, &d_P))) { (void)cs_done(st); return rc; }
+	const MaskedPlan *mp;
+	if ((rc = masked_rows(pl, KM, d_x, ld, mtr, h_sel, C, with_stack, 0, mtr, st, &d_P, &mp))) { (void)cs_done(st); return rc; }
 	if (with_stack) {
 		double *main_rows; size_t nd;
-		if ((rc = tspws_hip_reduce_buffer(pl, p, mtr, &main_rows, &nd)) || (rc = combine_classes(pl, cs, C, C + 1, main_rows, st)) ||
-		    (rc = tspws_hip_stack_finish(pl, p, mtr, d_ls, d_ts, s))) { (void)cs_done(st); return rc; }
+		if ((rc = tspws_hip_reduce_buffer(pl, p, mtr, &main_rows, &nd))) { (void)cs_done(st); return rc; }
+		HIP_TRY(hipMemcpyAsync(main_rows, d_P + (size_t)C * KM * pl->N, (size_t)KM * pl->N * sizeof(double), hipMemcpyDeviceToDevice, st));
+		if ((rc = tspws_hip_stack_finish(pl, p, mtr, d_ls, d_ts, s))) { (void)cs_done(st); return rc; }
 	}
-	if ((rc = combine_classes(pl, cs, 0, C, d_P, st))) { (void)cs_done(st); return rc; }
-	rc = finish_replicas(pl, p, d_P, cs.Kc, C, 0, C, d_ls_out, d_ts_out, h_mtr_out, s);
+	const std::vector<size_t> Kc = mp->Kc;
+	rc = finish_replicas(pl, p, d_P, Kc, C, 0, C, d_ls_out, d_ts_out, h_mtr_out, s);
 	(void)cs_done(st);
 	return rc;
 }
@@ -815,9 +721,9 @@ extern "C" int tspws_hip_jackknife_local(tspws_hip_plan *pl, const t_tsPWS *p, c
 	if ((rc = tspws_hip_reduce_buffer(pl, p, mtr_global, &main_rows, &nd))) return rc;
 	if ((rc = replica_rows_buffer(pl, KM, C, &d_P))) return rc;
 	// ONE pass over the shard for the plain groups and for every replica (empty shard: all rows zero)
-	ClassSums cs;
-	if ((rc = class_sums(pl, cs, KM, d_x, ld, mtr_global, h_sel, C, true, st, first, mtr_local)) ||
-	    (rc = combine_classes(pl, cs, C, C + 1, main_rows, st)) || (rc = combine_classes(pl, cs, 0, C, d_P, st))) { (void)cs_done(st); return rc; }
+	const MaskedPlan *mp;
+	if ((rc = masked_rows(pl, KM, d_x, ld, mtr_global, h_sel, C, true, first, mtr_local, st, &d_P, &mp))) { (void)cs_done(st); return rc; }
+	HIP_TRY(hipMemcpyAsync(main_rows, d_P + (size_t)C * KM * pl->N, (size_t)KM * pl->N * sizeof(double), hipMemcpyDeviceToDevice, st));
 	return cs_done(st);
 }
 
