@@ -243,31 +243,46 @@ __global__ void __launch_bounds__(TL_NT, 2) k_fwd_tl(const TIn *__restrict__ xT,
 						double xw[R];
 #pragma unroll
 						for (int j = 0; j < R - 1; j++) xw[j] = (double)xb[j * 64];
-						for (unsigned sb = 0; sb < QR; sb += R) { // QR is a multiple of 4
-#pragma unroll
-							for (int h = 0; h < 2; h++) {
-								if (h == 0 || sb + 4u < QR) {
-									double xn[4];
-									double2 tn[4];
-#pragma unroll
-									for (int u = 0; u < 4; u++) {
-										xn[u] = (double)xb[(h * 4 + u + R - 1) * 64];
-										tn[u] = tbv[h * 4 + u]; // same address in every lane: broadcast
-									}
-#pragma unroll
-									for (int u = 0; u < 4; u++) {
-										const int sidx = h * 4 + u;
-										xw[(sidx + R - 1) % R] = xn[u];
-#pragma unroll
-										for (int r = 0; r < R; r++) {
-											ar[v][r] = fma(xw[(sidx + r) % R], tn[u].x, ar[v][r]);
-											ai[v][r] = fma(xw[(sidx + r) % R], tn[u].y, ai[v][r]);
-										}
-									}
-								}
-							}
+						// Four tap steps at a time ("half turn" of the ring of R window registers): the LDS operands of a half turn are
+						// requested one half turn AHEAD (two operand sets, A and B), the x values stay RAW until their step -- the conversion
+						// is the move into the ring slot, placed (scheduling barriers) where the slot's old value has died.  As a hoisted
+						// conversion + copy, and with the second half of the loop body conditional, the compiler spent 14 register moves
+						// per 128 FMAs: 8 % of the kernel's VALU instructions (profiles/r04_valu_mix.txt).
+#define TL_READ(S, hh) do { \
+							_Pragma("unroll") for (int u = 0; u < 4; u++) { \
+								xr##S[u] = xb[((hh) * 4 + u + R - 1) * 64]; \
+								tn##S[u] = tbv[(hh) * 4 + u]; /* same address in every lane: broadcast */ \
+							} \
+						} while (0)
+#define TL_HALF(S, h) do { \
+							_Pragma("unroll") for (int u = 0; u < 4; u++) { \
+								const int sidx = (h) * 4 + u; \
+								__builtin_amdgcn_sched_barrier(0); \
+								xw[(sidx + R - 1) % R] = (double)xr##S[u]; \
+								_Pragma("unroll") for (int r = 0; r < R; r++) { \
+									ar[v][r] = fma(xw[(sidx + r) % R], tn##S[u].x, ar[v][r]); \
+									ai[v][r] = fma(xw[(sidx + r) % R], tn##S[u].y, ai[v][r]); \
+								} \
+							} \
+							__builtin_amdgcn_sched_barrier(0); \
+						} while (0)
+						// QR is a multiple of 4.  Whole turns of the ring (8 steps) in the loop, so that the window registers are where they
+						// were after every iteration; the odd half turn after it, where the window dies.  The last prefetch reads four rows /
+						// taps past the voice's (inside the stage buffers or, beyond the allocation, zeros): never used.
+						TIn xrA[4], xrB[4];
+						double2 tnA[4], tnB[4];
+						TL_READ(A, 0);
+						unsigned sb = 0;
+						for (; sb + R <= QR; sb += R) {
+							TL_READ(B, 1);
+							TL_HALF(A, 0);
+							TL_READ(A, 2);
+							TL_HALF(B, 1);
 							xb += R * 64; tbv += R;
 						}
+						if (sb < QR) TL_HALF(A, 0);
+#undef TL_READ
+#undef TL_HALF
 					}
 				}
 			}
