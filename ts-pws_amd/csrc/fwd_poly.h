@@ -230,7 +230,12 @@ __device__ __forceinline__ void valu_reduce_cplx64(const double (&v)[16], const 
 // One wave of the direct kernel: R outputs per thread (8, or 16 for the scales flagged r16: 64 phase lanes and at least 16
 // outputs -- one x value and one tap per 2 R FMAs and trace, i.e. half the operand bytes per FMA; the kernel is bound by
 // the L2 operand stream: without the tap loads the call is 10 us shorter), BS tap steps per load block.
-template <typename TIn, int B, int R, int BS>
+// BUF: the operands come through raw buffer loads -- resource = the trace / the scale's taps (uniform: SGPRs), ONE 32-bit byte offset
+// per lane and stream.  The circular wrap of a row is add / subtract / unsigned min on that offset, a tap past the filter end or of an
+// idle phase lane is an offset beyond the resource's range (the load returns zeros): 4 integer VALU ops per tap step instead of ~13
+// (64-bit address per trace, index select, compare, four selects that zero the tap) beside the step's 16 B FMAs -- every VALU op
+// competes with the 4-cycle FMAs (profiles/r04_valu_mix.txt: 63 % of this kernel's VALU instructions were FMAs on cfg2).
+template <typename TIn, int B, int R, int BS, bool BUF>
 __device__ __forceinline__ void fwd_poly_wave(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned N, const ScaleDesc &d,
                                               const double2 *__restrict__ w, double2 *__restrict__ part, size_t npart, const unsigned wl,
                                               const unsigned lane)
@@ -256,6 +261,19 @@ __device__ __forceinline__ void fwd_poly_wave(const TIn *__restrict__ x, size_t 
 		for (int r = 0; r < R; r++) { ar[b][r] = 0; ai[b][r] = 0; }
 
 	const unsigned Dw = d.D % N; // row advance, pre-reduced so one conditional subtraction re-wraps (D may exceed N on tiny traces)
+	__amdgpu_buffer_rsrc_t rx[B], rw;
+	const unsigned Nb = N * (unsigned)sizeof(TIn), Dwb = Dw * (unsigned)sizeof(TIn), D16 = d.D * 16u;
+	if constexpr (BUF) {
+#pragma unroll
+		for (int b = 0; b < B; b++) rx[b] = __builtin_amdgcn_make_buffer_rsrc((void *)xb[b], 0, Nb, 0x00020000);
+		rw = __builtin_amdgcn_make_buffer_rsrc((void *)ws, 0, d.L * 16u, 0x00020000);
+	}
+	auto ldx = [&](const int b, const unsigned row) -> double { // row: sample index, or its byte offset (BUF)
+		if constexpr (BUF) {
+			if constexpr (sizeof(TIn) == 8) return (double)__builtin_bit_cast(TIn, __builtin_amdgcn_raw_buffer_load_b64(rx[b], row, 0, 0));
+			else return (double)__builtin_bit_cast(TIn, __builtin_amdgcn_raw_buffer_load_b32(rx[b], row, 0, 0));
+		} else return (double)xb[b][row];
+	};
 	for (unsigned ci = 0; ci < d.cps; ci++) {
 		const unsigned chunk = split * d.cps + ci;
 		if (chunk >= d.MC) break;
@@ -264,14 +282,17 @@ __device__ __forceinline__ void fwd_poly_wave(const TIn *__restrict__ x, size_t 
 		const unsigned mm = mvalid ? m : 0; // idle phase lanes read valid addresses, contribute nothing
 		// row j of this thread is x[(k0 + j) D + m - c  (mod N)]; keep the wrapped index incrementally
 		unsigned row = wrap_index((long long)k0 * d.D + mm - d.c, N);
+		if constexpr (BUF) row *= (unsigned)sizeof(TIn);
 		double xw[B][R];
 #pragma unroll
 		for (int j = 0; j < R - 1; j++) {
 #pragma unroll
-			for (int b = 0; b < B; b++) xw[b][j] = (double)xb[b][row];
-			row += Dw; if (row >= N) row -= N;
+			for (int b = 0; b < B; b++) xw[b][j] = ldx(b, row);
+			if constexpr (BUF) { row += Dwb; row = min(row, row - Nb); }
+			else { row += Dw; if (row >= N) row -= N; }
 		}
 		unsigned l = mm;
+		unsigned tb = mvalid ? mm * 16u : 0x80000000u; // BUF: byte offset of the next tap (idle lanes: out of range for good)
 		for (unsigned q = 0; q < d.Q; q += R) {
 #pragma unroll
 			for (int h = 0; h < R / BS; h++) {
@@ -283,12 +304,19 @@ __device__ __forceinline__ void fwd_poly_wave(const TIn *__restrict__ x, size_t 
 #pragma unroll
 					for (int u = 0; u < BS; u++) {
 #pragma unroll
-						for (int b = 0; b < B; b++) xn[b][u] = (double)xb[b][row];
-						row += Dw; if (row >= N) row -= N;
-						const unsigned lu = l + (unsigned)(h * BS + u) * d.D;
-						const bool ok = mvalid && lu < d.L;
-						tp[u] = ws[ok ? lu : 0];
-						if (!ok) tp[u] = make_double2(0.0, 0.0); // taps past the filter end / idle lanes contribute exactly nothing
+						for (int b = 0; b < B; b++) xn[b][u] = ldx(b, row);
+						if constexpr (BUF) {
+							row += Dwb; row = min(row, row - Nb);
+							const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rw, tb, 0, 0); // past the filter end / idle lane: zeros
+							tp[u] = make_double2(__hiloint2double((int)raw[1], (int)raw[0]), __hiloint2double((int)raw[3], (int)raw[2]));
+							tb += D16;
+						} else {
+							row += Dw; if (row >= N) row -= N;
+							const unsigned lu = l + (unsigned)(h * BS + u) * d.D;
+							const bool ok = mvalid && lu < d.L;
+							tp[u] = ws[ok ? lu : 0];
+							if (!ok) tp[u] = make_double2(0.0, 0.0); // taps past the filter end / idle lanes contribute exactly nothing
+						}
 					}
 #pragma unroll
 					for (int u = 0; u < BS; u++) {
@@ -387,8 +415,19 @@ __global__ void __launch_bounds__(256) k_fwd_poly(const TIn *__restrict__ x, siz
 		if (sc[mid].wave_off <= wid) lo = mid; else hi = mid;
 	}
 	const ScaleDesc d = sc[lo];
-	if (d.r16) fwd_poly_wave<TIn, B, 16, 4>(x, ld, ntr, N, d, w, part, npart, wid - d.wave_off, lane);
-	else fwd_poly_wave<TIn, B, FWD_R, FWD_R>(x, ld, ntr, N, d, w, part, npart, wid - d.wave_off, lane);
+	// buffer-load form: byte offsets of a trace and of the scale's taps (+ the steps past its end a wave may request) stay below 2^31
+	// (float traces: the many-trace single-stage batches, where this kernel sets the call's duration beside k_fwd_tl -- cfg2 3.27 -> 3.12 ms
+	// with the register-move-free k_fwd_tl loop; FP64 partial stacks run it beside k_fwd_lds, off the critical path: cfg3 unchanged, cfg4 + 0.6 %)
+	const bool buf = sizeof(TIn) == 4 && (unsigned long long)N * sizeof(TIn) < 0x80000000ull && ((unsigned long long)d.L + (unsigned long long)(d.Q + 16u) * d.D + 64u) * 16ull < 0x80000000ull;
+	if constexpr (sizeof(TIn) == 4) {
+		if (buf) {
+			if (d.r16) fwd_poly_wave<TIn, B, 16, 4, true>(x, ld, ntr, N, d, w, part, npart, wid - d.wave_off, lane);
+			else fwd_poly_wave<TIn, B, FWD_R, FWD_R, true>(x, ld, ntr, N, d, w, part, npart, wid - d.wave_off, lane);
+			return;
+		}
+	}
+	if (d.r16) fwd_poly_wave<TIn, B, 16, 4, false>(x, ld, ntr, N, d, w, part, npart, wid - d.wave_off, lane);
+	else fwd_poly_wave<TIn, B, FWD_R, FWD_R, false>(x, ld, ntr, N, d, w, part, npart, wid - d.wave_off, lane);
 }
 
 // Y[b][coef] = sum over the scale's split partials (plain coefficient layout; API / tests)
