@@ -1,0 +1,41 @@
+"""What the drop-in's host-to-device upload costs piece by piece (hipHostRegister / copy / unregister of a 5.24-GB user buffer), and
+whether pinning and copying in pieces -- piece i + 1 is registered while piece i travels -- hides the registration.
+usage (GPU box): python tools/probes/upload_probe.py [GB]"""
+import ctypes as C, sys, time
+import numpy as np, torch
+hip = C.CDLL("libamdhip64.so")
+GB = float(sys.argv[1]) if len(sys.argv) > 1 else 5.24
+N = int(GB * 1e9) // 4096 * 4096
+x = np.ones(N // 4, np.float32)           # pages touched
+d = torch.empty(N // 4, dtype=torch.float32, device="cuda")
+torch.cuda.synchronize()
+vp, sz = C.c_void_p, C.c_size_t
+def T(f):
+    t0 = time.perf_counter(); r = f(); return (time.perf_counter() - t0) * 1e3, r
+for rep in range(2):
+    tr, rc = T(lambda: hip.hipHostRegister(vp(x.ctypes.data), sz(N), 0))
+    tc, _ = T(lambda: (hip.hipMemcpy(vp(d.data_ptr()), vp(x.ctypes.data), sz(N), 1), hip.hipDeviceSynchronize()))
+    tu, _ = T(lambda: hip.hipHostUnregister(vp(x.ctypes.data)))
+    print(f"whole buffer {N/1e9:.2f} GB: register {tr:.1f} ms (rc {rc}), copy {tc:.1f} ms ({N/tc/1e6:.1f} GB/s), unregister {tu:.1f} ms, sum {tr+tc+tu:.1f} ms")
+s = C.c_void_p()
+hip.hipStreamCreate(C.byref(s))
+for piece_mb in (64, 128, 256, 512, 1024):
+    P = piece_mb << 20
+    for rep in range(2):
+        t0 = time.perf_counter()
+        off = 0
+        hip.hipHostRegister(vp(x.ctypes.data), sz(min(P, N)), 0)
+        while off < N:
+            n = min(P, N - off)
+            hip.hipMemcpyAsync(vp(d.data_ptr() + off), vp(x.ctypes.data + off), sz(n), 1, s)
+            nxt = off + n
+            if nxt < N:
+                hip.hipHostRegister(vp(x.ctypes.data + nxt), sz(min(P, N - nxt)), 0)   # while the piece above travels
+            off = nxt
+        hip.hipStreamSynchronize(s)
+        t1 = time.perf_counter()
+        off = 0
+        while off < N:
+            hip.hipHostUnregister(vp(x.ctypes.data + off)); off += P
+        t2 = time.perf_counter()
+    print(f"pieces of {piece_mb} MB: upload {1e3*(t1-t0):.1f} ms ({N/(t1-t0)/1e9:.1f} GB/s), unregister {1e3*(t2-t1):.1f} ms, sum {1e3*(t2-t0):.1f} ms")
