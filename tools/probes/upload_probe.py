@@ -39,3 +39,33 @@ for piece_mb in (64, 128, 256, 512, 1024):
             hip.hipHostUnregister(vp(x.ctypes.data + off)); off += P
         t2 = time.perf_counter()
     print(f"pieces of {piece_mb} MB: upload {1e3*(t1-t0):.1f} ms ({N/(t1-t0)/1e9:.1f} GB/s), unregister {1e3*(t2-t1):.1f} ms, sum {1e3*(t2-t0):.1f} ms")
+
+# FIRST upload of a buffer (what a one-call process such as the command line pays): fresh pages every time
+def fresh():
+    return np.ones(N // 4, np.float32)
+for mode in ("whole", 64, 256, 1024, "pageable"):
+    y = fresh()
+    t0 = time.perf_counter()
+    if mode == "whole":
+        hip.hipHostRegister(vp(y.ctypes.data), sz(N), 0)
+        hip.hipMemcpyAsync(vp(d.data_ptr()), vp(y.ctypes.data), sz(N), 1, s); hip.hipStreamSynchronize(s)
+    elif mode == "pageable":
+        hip.hipMemcpy(vp(d.data_ptr()), vp(y.ctypes.data), sz(N), 1); hip.hipDeviceSynchronize()
+    else:
+        P = mode << 20
+        off = 0
+        while off < N:
+            n = min(P, N - off)
+            hip.hipHostRegister(vp(y.ctypes.data + off), sz(n), 0)
+            hip.hipMemcpyAsync(vp(d.data_ptr() + off), vp(y.ctypes.data + off), sz(n), 1, s)
+            off += n
+        hip.hipStreamSynchronize(s)
+    t1 = time.perf_counter()
+    if mode == "whole":
+        hip.hipHostUnregister(vp(y.ctypes.data))
+    elif mode != "pageable":
+        off = 0
+        while off < N:
+            hip.hipHostUnregister(vp(y.ctypes.data + off)); off += mode << 20
+    print(f"first upload of fresh pages, {mode}: {1e3*(t1-t0):.1f} ms ({N/(t1-t0)/1e9:.1f} GB/s)")
+    del y

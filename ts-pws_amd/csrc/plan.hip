@@ -280,8 +280,10 @@ extern "C" int tspws_hip_alloc(void **d, size_t bytes, int device)
 	return 0;
 }
 extern "C" int tspws_hip_free(void *d) { if (d) HIP_TRY(hipFree(d)); return 0; }
-// Large host buffers are pinned in place for the duration of the copy: measured on the MI355X box, a pageable 2 GB
-// hipMemcpy runs at ~16 GB/s while hipHostRegister (~10 ms per GB) + copy runs at ~57 GB/s.
+// Large host buffers are pinned in place for the duration of the copy, PIECE BY PIECE: piece i + 1 is registered while piece i travels,
+// so pinning fresh pages hides behind the link (tools/probes/upload_probe.py, 5.24 GB of fresh pages on the MI355X box: registered as
+// a whole + copied 105 ms, plain pageable hipMemcpy 104 ms, 64-MB ... 1-GB pieces 93-97 ms; pages that were pinned before 91 ms = 57.6 GB/s
+// either way -- the link).
 static bool pin_for_copy(const void *h, size_t bytes)
 {
 	return bytes >= ((size_t)32 << 20) && hipHostRegister(const_cast<void *>(h), bytes, hipHostRegisterDefault) == hipSuccess;
@@ -289,11 +291,33 @@ static bool pin_for_copy(const void *h, size_t bytes)
 
 extern "C" int tspws_hip_upload(void *d, const void *h, size_t bytes, void *s)
 {
-	const bool pinned = pin_for_copy(h, bytes);
-	if (!pinned) (void)hipGetLastError(); // a failed registration is not an error: fall back to the pageable path
-	hipError_t e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, S_(s));
-	if (e == hipSuccess) e = hipStreamSynchronize(S_(s));
-	if (pinned) (void)hipHostUnregister(const_cast<void *>(h));
+	const size_t piece = (size_t)128 << 20;
+	if (bytes < 2 * piece) {
+		const bool pinned = pin_for_copy(h, bytes);
+		if (!pinned) (void)hipGetLastError(); // a failed registration is not an error: fall back to the pageable path
+		hipError_t e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, S_(s));
+		if (e == hipSuccess) e = hipStreamSynchronize(S_(s));
+		if (pinned) (void)hipHostUnregister(const_cast<void *>(h));
+		HIP_TRY(e);
+		return 0;
+	}
+	// pieces end on page boundaries of the HOST address (two registrations must not share a page)
+	const uintptr_t h0 = (uintptr_t)h, h1 = h0 + bytes;
+	auto cut = [&](size_t k) -> uintptr_t { const uintptr_t a = (h0 + k * piece + 4095) & ~(uintptr_t)4095; return k == 0 ? h0 : std::min(a, h1); };
+	hipError_t e = hipSuccess;
+	size_t npinned = 0; // leading pieces that are registered (a piece that cannot be pinned travels pageable, like the rest after it)
+	bool pin = true;
+	for (size_t k = 0; cut(k) < h1 && e == hipSuccess; k++) {
+		const uintptr_t a = cut(k), b = cut(k + 1);
+		if (pin) {
+			if (hipHostRegister((void *)a, b - a, hipHostRegisterDefault) == hipSuccess) npinned++;
+			else { (void)hipGetLastError(); pin = false; }
+		}
+		e = hipMemcpyAsync((char *)d + (a - h0), (const void *)a, b - a, hipMemcpyHostToDevice, S_(s));
+	}
+	const hipError_t es = hipStreamSynchronize(S_(s));
+	if (e == hipSuccess) e = es;
+	for (size_t k = 0; k < npinned; k++) (void)hipHostUnregister((void *)cut(k));
 	HIP_TRY(e);
 	return 0;
 }
