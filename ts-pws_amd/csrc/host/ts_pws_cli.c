@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "sacio_min.h"
 #include "ts_pws1f_lib.h"
@@ -235,8 +236,17 @@ static int write_bin(const char *name, float **y, unsigned M, unsigned first, co
 	return 0;
 }
 
+/* TSPWS_CLI_TIMES=1: wall time of the phases (tools/cli_timing.py) */
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 int main(int argc, char *argv[])
 {
+	const double t_start = now_s();
 	/* defaults of the reference, ts_pws1f.c:140-142 */
 	t_tsPWS p;
 	memset(&p, 0, sizeof p);
@@ -282,6 +292,7 @@ int main(int argc, char *argv[])
 	memset(&in, 0, sizeof in);
 	int er = read_data(&in, p.filein, p.bin, p.verbose);
 	if (er) return er;
+	const double t_read = now_s();
 	if (!in.hdr.mtr) return 0;
 
 	t_tsPWS_out out;
@@ -333,7 +344,10 @@ int main(int argc, char *argv[])
 
 	if (p.subsmpl_N) for (unsigned i = 1; i < out.M; i++) out.mtr_subsmpl[i] = (unsigned)(out.mtr * p.subsmpl_p); /* :277 (entry 0 stays 0) */
 
+	const double t_call0 = now_s();
 	er = tspws_main(&p, &out, &in);
+	const double t_call1 = now_s();
+	if (getenv("TSPWS_CLI_TIMES")) printf("cli: read %.1f ms, set-up %.1f ms, tspws_main %.1f ms\n", 1e3 * (t_read - t_start), 1e3 * (t_call0 - t_read), 1e3 * (t_call1 - t_call0));
 
 	if (!er) {
 		t_hdr hdr = in.hdr;
