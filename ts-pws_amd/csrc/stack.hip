@@ -257,6 +257,25 @@ extern "C" int tspws_hip_stack(tspws_hip_plan *pl, const t_tsPWS *p, const float
 	const bool ride = is_two_stage(p, mtr); // the streaming pass of a two-stage call takes both of its events (tspws_run_chunks)
 	if (ride) { pl->le.first_start = prof ? pe[0] : nullptr; pl->le.last_stop = prof ? pe[1] : pl->ev_fork; }
 	else if (prof) HIP_TRY(hipEventRecord(pe[0], S_(s)));
+	if (!ride) {
+		// single-stage on one device: the launch that completes ST / PS also writes the weighted coefficients -- no copy of the stacks
+		// into the finish block, no weighting pass (the halves stack_local / stack_finish keep them for the all-reduce in between)
+		double *OUT, *ST, *PS;
+		bool weighted = false;
+		if (!(rc = finish_block(pl, &OUT, &ST, &PS))) {
+			const WeightArgs wa = weight_args(p, OUT, (unsigned)mtr, mtr);
+			rc = tspws_stacks_f32(pl, d_x, mtr, ld, ST, PS, S_(s), false, &wa, &weighted, ScaleRange());
+		}
+		if (!rc && prof) rc = hip_rc(hipEventRecord(pe[1], S_(s)), "stack: event");
+		pl->le.call_end = (!rc && prof) ? pe[2] : nullptr;
+		if (!rc) rc = finish_tail(pl, p, mtr, d_ls, d_ts, s, weighted);
+		if (!rc && prof) {
+			if (pl->le.call_end) rc = hip_rc(hipEventRecord(pe[2], S_(s)), "stack: event");
+			pl->prof_used += 3;
+		}
+		pl->le = tspws_hip_plan::LaunchEvents();
+		return rc;
+	}
 	rc = tspws_hip_stack_local(pl, p, d_x, ld, mtr, 0, mtr, s);
 	if (!rc) {
 		if (prof && (!ride || pl->le.last_stop)) rc = hip_rc(hipEventRecord(pe[1], S_(s)), "stack: event");
