@@ -423,7 +423,7 @@ bool tspws_many_trace_path(const tspws_hip_plan *p, size_t ntr)
 	if (!(p->tl[0].n || p->tl[1].n) || tspws_generic_forward()) return false;
 	const long forced = tl_min_env();
 	if (forced > 0) return ntr >= (size_t)forced;
-	return p->V > 2 && ntr >= 160 && (double)ntr * (double)p->N >= 7.0 * 1048576.0;
+	return p->V > 2 && ntr >= 128 && (double)ntr * (double)p->N >= 7.0 * 1048576.0; // (tools/experiments/tl_threshold.sh: 128 x 65536 0.94 vs 0.86 ms, 160 x 32768 0.63 vs 0.69, 1024 x 4096 0.58 vs 0.70, 499 x 16501 1.17 vs 0.99)
 }
 
 template <typename TIn>
@@ -519,7 +519,8 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 	int rc;
 	void *v;
 	// decomposition: many trace blocks and more than two voices per octave -> tl[0], else tl[1] (tspws_build_forward)
-	const unsigned pick = ((ntr + 63) / 64 >= 12 && p->V > 2) ? 0u : 1u;
+	unsigned pick = ((ntr + 63) / 64 >= 12 && p->V > 2) ? 0u : 1u;
+	if (const char *e = getenv("TSPWS_TL_PICK")) pick = atoi(e) ? 1u : 0u; // sweeps: force a decomposition
 	const TlTable &T = p->tl[p->tl[pick].n ? pick : 1u - pick]; // (a short frame may leave one of them without trace-lane items)
 	// traces per batch: transposed copy <= 1 GiB, at most 4096 (64 plane pairs), a multiple of 64
 	size_t batch = std::min<size_t>(4096, std::max<size_t>(64, (((size_t)1 << 30) / ((size_t)p->N * sizeof(TIn))) & ~(size_t)63));

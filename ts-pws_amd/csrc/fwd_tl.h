@@ -29,7 +29,12 @@
 #pragma once
 
 #define TL_NT 256
-#define TL_VMAX 4            /* voices per work item */
+#ifndef TL_VMAX
+#define TL_VMAX 3            /* voices per work item: V = 4 as 2 + 2 (twice the workgroups; 499 x 16501 1.16 -> 1.00 ms, 2048 x 8192 1.56 -> 1.48), V = 5 as 3 + 2 either way */
+#endif
+#ifndef TL_WGS
+#define TL_WGS 2             /* workgroups per CU the register budget is set for */
+#endif
 #define TL_QMAX 32           /* tap rows per voice */
 #define TL_XRMAX 72          /* staged rows per residue (multiple of 4): 32 outputs + tap rows + spread of a_v */
 #define TL_PMAX 256          /* residues one workgroup walks */
@@ -70,7 +75,7 @@ __global__ void __launch_bounds__(256) k_transpose_traces(const TIn *__restrict_
 }
 
 template <typename TIn>
-__global__ void __launch_bounds__(TL_NT, 2) k_fwd_tl(const TIn *__restrict__ xT, unsigned TP, unsigned ntr, unsigned N,
+__global__ void __launch_bounds__(TL_NT, TL_WGS) k_fwd_tl(const TIn *__restrict__ xT, unsigned TP, unsigned ntr, unsigned N,
                                                      const TLItem *__restrict__ items, unsigned nitems, const double2 *__restrict__ w,
                                                      double2 *__restrict__ accST, double2 *__restrict__ accPS, size_t acc_stride,
                                                      double2 *__restrict__ part, size_t npart)
