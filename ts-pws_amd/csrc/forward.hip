@@ -243,7 +243,9 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINN
 		d.part_off = poff;
 		if (!(is_tl[s] && d.fuse_ok)) poff += (unsigned long long)d.nsplit * d.Ns; // fused scales never write partials
 		d.acc2_off = ablk;
-		ablk += d.nsplit > 1 ? (d.Ns + 3) / 4 : (d.Ns + 255) / 256; // split scales: 4 coefficients per block (k_accumulate_parts, many)
+		// 4 coefficients per block, a wave each, for every scale whose per-trace partials are added by k_accumulate_parts (`many`): its lanes
+		// take every 64th trace.  (One thread per coefficient walked all traces of the batch in dependent round trips: 80 us at 499 x 16501.)
+		ablk += (d.nsplit > 1 || !d.fuse_ok) ? (d.Ns + 3) / 4 : (d.Ns + 255) / 256;
 	}
 	for (TLItem &o : items) for (unsigned i = 0; i < o.nv; i++) o.part_off[i] = T.sc[o.sc[i]].part_off;
 	T.n = (unsigned)items.size(); T.wgs = wg; T.waves = woff; T.acc2_blocks = ablk; T.npart = poff;

@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(256) k_accumulate_parts(const double2 *__restr
 		if (wa.OUT) wa.OUT[i] = weight_value(st, ps, wa.mode, wa.K, wa.M, wa.wu);
 		return;
 	}
-	const bool wide = nsplit > 1;
+	const bool wide = nsplit > 1 || (many && !sc[lo].fuse_ok); // (the many-trace tables give every unfused scale the wave-per-coefficient geometry)
 	if (wide && many) {
 		// many traces, few coefficients (coarse / residue-split scales of a single-stage batch; table geometry: 4 coefficients
 		// per block): a wave per coefficient, its 64 lanes take every 64th TRACE (all splits of it), then a wave reduction --

@@ -360,12 +360,23 @@ __global__ void __launch_bounds__(256) k_inv_combine(const double *__restrict__ 
 __global__ void __launch_bounds__(256) k_inv_combine_out(const double *__restrict__ obuf, size_t slot_stride, unsigned nslots, size_t N,
                                                          float *__restrict__ ts, float *__restrict__ ls, float mtr)
 {
+	// blockIdx.y = the reconstruction (0: ts-PWS, 1: linear stack); four rows in flight, added in row order (short frames have one row
+	// per SCALE: 44-56 rows of a few thousand samples -- a chain of dependent loads per thread otherwise)
 	const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (n >= N) return;
-	double a = obuf[n], b = obuf[N + n];
-	for (unsigned s = 1; s < nslots; s++) { a += obuf[(size_t)s * slot_stride + n]; b += obuf[(size_t)s * slot_stride + N + n]; }
-	if (ts) ts[n] = (float)a;
-	if (ls) ls[n] = (float)b / mtr;
+	const double *src = obuf + (size_t)blockIdx.y * N + n;
+	double a = src[0];
+	unsigned s = 1;
+	for (; s + 4 <= nslots; s += 4) {
+		double v[4];
+#pragma unroll
+		for (int j = 0; j < 4; j++) v[j] = src[(size_t)(s + (unsigned)j) * slot_stride];
+#pragma unroll
+		for (int j = 0; j < 4; j++) a += v[j];
+	}
+	for (; s < nslots; s++) a += src[(size_t)s * slot_stride];
+	if (blockIdx.y == 0) { if (ts) ts[n] = (float)a; }
+	else if (ls) ls[n] = (float)a / mtr;
 }
 
 // xout[i] = sum of the obuf rows [a0, a0 + na) and [b0, b0 + nb), in that order (a scale sub-range: its octave items form

@@ -133,15 +133,36 @@ static unsigned inv_lds_maxd()
 	return (unsigned)v;
 }
 
-// work list of the polyphase inverse: one item group per run of consecutive scales with the same D
+// work list of the polyphase inverse: one item group per run of consecutive scales with the same D (an octave: its voices are
+// summed in registers).  SHORT frames -- all octave items together fewer than 768 waves, i.e. N < ~28 000 for the default frames --
+// get one item per SCALE instead: the kernel is a chain of dependent round trips per voice, and with less than two waves per SIMD
+// nothing hides them (N = 16501: 105 workgroups on 256 CUs); four times the waves, each a quarter as long, and the combining
+// kernel adds a row per scale (TSPWS_INV_SPLIT=0 / 1 forces either form).  Long frames fill the chip with octave items (round 1:
+// the voices on separate waves 49 vs 50 us at N = 131072).
 int tspws_build_inverse(tspws_hip_plan *p)
 {
 	std::vector<OctDesc> oc;
 	unsigned woff = 0;
 	p->inv_ngeneric = 0;
+	p->og_s0.clear(); p->og_nv.clear();
+	bool split = false;
+	{
+		unsigned waves = 0;
+		for (unsigned s = 0; s < p->S;) {
+			unsigned e = s + 1;
+			while (e < p->S && p->sc[e].D == p->sc[s].D) e++;
+			p->og_s0.push_back(s); p->og_nv.push_back(e - s); // the octaves themselves: what a share of the sharded finish is made of
+			const unsigned D = p->sc[s].D, dl = D >= 64 ? 64u : std::max(1u, 1u << (unsigned)ceil(log2((double)std::max(1u, D))));
+			const unsigned NG = (p->sc[s].Ns + INV_R - 1) / INV_R, GW = 64 / dl;
+			waves += (D > 64 ? (D + 63) / 64 : 1) * ((NG + GW - 1) / GW);
+			s = e;
+		}
+		split = waves < 768; // (tools/experiments/inv_split.sh: 499 x 16501 two-stage 0.157 -> 0.134 ms, 64 x 8192 0.165 -> 0.158; N = 32768 / 65536 / 131072 unchanged or worse)
+		if (const char *e = getenv("TSPWS_INV_SPLIT")) split = atoi(e) != 0;
+	}
 	for (unsigned s = 0; s < p->S;) {
 		unsigned e = s + 1;
-		while (e < p->S && p->sc[e].D == p->sc[s].D) e++;
+		while (!split && e < p->S && p->sc[e].D == p->sc[s].D) e++;
 		OctDesc o;
 		memset(&o, 0, sizeof o);
 		o.gen = p->sc[s].inv_fast ? 0u : 1u;
@@ -250,9 +271,9 @@ static int inverse_launch(tspws_hip_plan *p, const double2 *Y, double *x, hipStr
 	if (NREC == 2 && nb == 1 && (f_ts || f_ls))
 		if (hipEvent_t e1 = p->le.call_end) { // the call's end event rides on its last launch (tspws_hip_stack)
 			p->le.call_end = nullptr;
-			hipExtLaunchKernelGGL(k_inv_combine_out, dim3(nbx), dim3(256), 0, st, nullptr, e1, 0, (const double *)obuf, slot, nslots, (size_t)p->N, f_ts, f_ls, f_mtr);
+			hipExtLaunchKernelGGL(k_inv_combine_out, dim3(nbx, 2), dim3(256), 0, st, nullptr, e1, 0, (const double *)obuf, slot, nslots, (size_t)p->N, f_ts, f_ls, f_mtr);
 		} else
-			hipLaunchKernelGGL(k_inv_combine_out, dim3(nbx), dim3(256), 0, st, obuf, slot, nslots, (size_t)p->N, f_ts, f_ls, f_mtr);
+			hipLaunchKernelGGL(k_inv_combine_out, dim3(nbx, 2), dim3(256), 0, st, obuf, slot, nslots, (size_t)p->N, f_ts, f_ls, f_mtr);
 	else
 		hipLaunchKernelGGL(k_inv_combine, dim3((unsigned)((slot + 255) / 256), nb), dim3(256), 0, st, obuf, slot, nslots, slot, x,
 		                   (size_t)nslots * slot, slot);

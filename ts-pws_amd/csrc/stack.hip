@@ -124,9 +124,9 @@ extern "C" int tspws_hip_finish_shard(const tspws_hip_plan *pl, const t_tsPWS *p
 {
 	if (!pl || !p || !s_begin || !s_end || !world || rank >= world) return fail(TSPWS_E_ARG, "finish_shard: bad argument");
 	if (!finish_shardable(pl, p, mtr_global)) return 1;
-	std::vector<unsigned> items(pl->inv_noct);
-	for (unsigned i = 0; i < pl->inv_noct; i++) items[i] = i;
-	std::sort(items.begin(), items.end(), [&](unsigned a, unsigned b) { return pl->oc_s0[a] < pl->oc_s0[b]; });
+	const std::vector<unsigned> &og_s0 = pl->og_s0, &og_nv = pl->og_nv; // the decimation octaves in scale order
+	std::vector<unsigned> items(og_s0.size());
+	for (unsigned i = 0; i < items.size(); i++) items[i] = i;
 	std::vector<double> cost(items.size());
 	double total = 0;
 	for (size_t k = 0; k < items.size(); k++) {
@@ -136,7 +136,7 @@ extern "C" int tspws_hip_finish_shard(const tspws_hip_plan *pl, const t_tsPWS *p
 		// octave on the north-star frame: 13 us above the launch-chain floor for D <= 128, ~30 us for D >= 256); shares of
 		// many octaves (world 2: 0.148 | 0.157 ms for an even split of the MACs) follow the MAC count
 		const double far_w = world >= 4 ? 2.0 : 1.0;
-		for (unsigned s = pl->oc_s0[items[k]]; s < pl->oc_s0[items[k]] + pl->oc_nv[items[k]]; s++)
+		for (unsigned s = og_s0[items[k]]; s < og_s0[items[k]] + og_nv[items[k]]; s++)
 			c += (double)pl->sc[s].L * (double)pl->sc[s].Ns * (pl->sc[s].D >= 256 ? far_w : 1.0);
 		cost[k] = c; total += c;
 	}
@@ -148,8 +148,8 @@ extern "C" int tspws_hip_finish_shard(const tspws_hip_plan *pl, const t_tsPWS *p
 		if (owner >= world) owner = world - 1;
 		cum += cost[k];
 		if (owner != rank) continue;
-		if (lo == ~0u) lo = pl->oc_s0[items[k]];
-		hi = pl->oc_s0[items[k]] + pl->oc_nv[items[k]];
+		if (lo == ~0u) lo = og_s0[items[k]];
+		hi = og_s0[items[k]] + og_nv[items[k]];
 	}
 	*s_begin = lo == ~0u ? 0u : lo;
 	*s_end = lo == ~0u ? 0u : hi;
@@ -166,7 +166,7 @@ extern "C" int tspws_hip_stack_finish_scales(tspws_hip_plan *pl, const t_tsPWS *
 	hipStream_t st = S_(s);
 	if (s_begin == s_end) { HIP_TRY(hipMemsetAsync(d_x2, 0, 2 * (size_t)pl->N * sizeof(double), st)); return 0; }
 	bool lo_ok = false, hi_ok = false; // whole octaves only
-	for (unsigned i = 0; i < pl->inv_noct; i++) { lo_ok |= pl->oc_s0[i] == s_begin; hi_ok |= pl->oc_s0[i] + pl->oc_nv[i] == s_end; }
+	for (size_t i = 0; i < pl->og_s0.size(); i++) { lo_ok |= pl->og_s0[i] == s_begin; hi_ok |= pl->og_s0[i] + pl->og_nv[i] == s_end; }
 	if (!lo_ok || !hi_ok) return fail(TSPWS_E_ARG, "stack_finish_scales: the range must consist of whole decimation octaves");
 	double *OUT, *ST, *PS, *P;
 	size_t nd;

@@ -177,6 +177,7 @@ struct tspws_hip_plan {
 	// direct kernel, whose parallelism is in the taps): see TlTable
 	TlTable tl[2];
 	std::vector<unsigned> oc_s0, oc_nv, oc_wave_off, oc_nwaves, oc_gen; // host copy of the inverse's octave items (launch order)
+	std::vector<unsigned> og_s0, og_nv; // the decimation octaves (first scale, voices) in scale order, whatever the items are
 	unsigned inv_waves_lds = 0; // ... of which the first inv_waves_lds (octaves with D < 64) run the LDS-staged instantiation
 	unsigned inv_waves = 0, inv_waves_fast = 0, inv_noct = 0, inv_ngeneric = 0; // polyphase inverse: waves (of the octaves whose D divides N first), octave items, scales left to the generic kernel
 	OctDesc *d_oc = nullptr;
