@@ -510,7 +510,19 @@ void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb
 
 // slice length of the fused forward kernel for a batch of nb traces: whole batch when it is small (two-stage: the K
 // partial stacks -> ONE slice that writes ST / PS directly), else 32 traces per slice
-static unsigned fuse_tps(size_t nb) { return (unsigned)std::min<size_t>(nb, 32); }
+// Short frames have few workgroups per slice (N = 8192: 72; the chip holds 512 at a time): slices are halved until the launch has
+// ~256 workgroups (TSPWS_FUSE_WGS), but not below six traces -- a slice's set-up (taps, first window) weighs as much as a few
+// traces: the ten partial stacks of a two-stage call stay ONE slice (499 x 16501 two-stage 0.123 ms as one slice, 0.135-0.139 as
+// two or four).  tools/experiments/fuse_slices.sh: 64 x 8192 single-stage 0.152 -> 0.106 ms, 30 x 4096 0.127 -> 0.065; the
+// slices' plane pairs are added in slice order by the accumulation.
+static unsigned fuse_tps(const tspws_hip_plan *p, size_t nb)
+{
+	static int target = -1;
+	if (target < 0) { const char *e = getenv("TSPWS_FUSE_WGS"); target = e ? std::max(1, atoi(e)) : 256; }
+	unsigned tps = (unsigned)std::min<size_t>(nb, 32);
+	while ((tps + 1) / 2 >= 6 && (size_t)std::max(1u, p->lds_blocks) * ((nb + tps - 1) / tps) < (size_t)target) tps = (tps + 1) / 2;
+	return std::max(1u, tps);
+}
 
 // Many traces (single-stage stacks): trace-lane kernel on the transposed batch (fwd_tl.h); the stacks of the fused scales
 // come back as one plane pair per 64-trace block, the split / coarse scales as per-trace partials in the tl layout.
@@ -604,8 +616,9 @@ static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld,
 	const bool fuse = p->n_fusable != 0;
 	void *vz = nullptr;
 	if (fuse) { // slice planes of the largest batch (unused when the only slice writes ST / PS directly)
-		const unsigned tps = fuse_tps(batch);
-		const size_t nsl = (batch + tps - 1) / tps;
+		const unsigned tps = fuse_tps(p, batch);
+		size_t nsl = (batch + tps - 1) / tps;
+		if (const size_t last = ntr % batch) nsl = std::max(nsl, (last + fuse_tps(p, last) - 1) / fuse_tps(p, last)); // (a shorter last batch may take shorter slices)
 		if (!(nsl == 1 && !keep && batch >= ntr) && (rc = scratch(p, SCR_FZ, nsl * 2 * p->ncoef * sizeof(double2), &vz))) return rc;
 	}
 	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
@@ -614,7 +627,7 @@ static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld,
 		FuseOut fz;
 		unsigned nsl = 0;
 		if (fuse) {
-			fz.tps = fuse_tps(nb);
+			fz.tps = fuse_tps(p, nb);
 			nsl = (unsigned)((nb + fz.tps - 1) / fz.tps);
 			if (nsl == 1 && zero_first) { fz.accST = (double2 *)d_ST; fz.accPS = (double2 *)d_PS; fz.stride = 0; }
 			else { fz.accST = (double2 *)vz; fz.accPS = (double2 *)vz + p->ncoef; fz.stride = 2 * p->ncoef; }
