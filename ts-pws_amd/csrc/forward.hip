@@ -107,7 +107,12 @@ static long tl_min_env()
 #define TL_MINNS0 33 /* many-trace batches: octaves with at least this many outputs on the trace-lane kernel */
 #endif
 #ifndef FWD_STEPS_DEF
-#define FWD_STEPS_DEF 96 /* tap steps per wave of the direct kernel */
+#define FWD_STEPS_DEF 32 /* tap steps per wave of the direct kernel, few traces (the K partial stacks of a two-stage call): its waves are chains of dependent
+                            loads and there are few of them -- 96 -> 32 steps: 100 x 16384 two-stage 0.108 -> 0.086 ms, 499 x 16501 0.121 -> 0.107, 64 x 65536
+                            0.173 -> 0.155, the north star unchanged (tools/experiments/fwd_steps.sh) */
+#endif
+#ifndef FWD_STEPS_TL
+#define FWD_STEPS_TL 96  /* ... beside k_fwd_tl on many traces: there are thousands of waves, longer ones amortise their set-up (cfg2 3.08 vs 3.14 ms at 32) */
 #endif
 static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, TlTable &T);
 
@@ -117,7 +122,8 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINN
 int tspws_build_forward(tspws_hip_plan *p)
 {
 	const unsigned S = p->S;
-	const unsigned FWD_STEPS = FWD_STEPS_DEF;
+	unsigned FWD_STEPS = FWD_STEPS_DEF;
+	if (const char *e = getenv("TSPWS_FWD_STEPS")) FWD_STEPS = (unsigned)std::max(8, atoi(e)); // sweeps
 	const unsigned R = 8, FL_SLOTS_HOST = FL_WAVES * FL_PASSES;
 	unsigned woff = 0, boff = 0;
 	unsigned long long poff = 0;
@@ -160,8 +166,8 @@ int tspws_build_forward(tspws_hip_plan *p)
 	// and Mexican hat (round 3): batches of >= 12 trace blocks are fastest with the octaves of >= 33 outputs on the trace-lane
 	// kernel, smaller batches (and frames with two voices per octave) with >= 257 -- the trace-lane kernel has tl.wgs x blocks
 	// workgroups, the direct kernel splits the taps
-	if (int rc = build_tl_forward(p, FWD_STEPS, TL_MINNS0, p->tl[0])) return rc;
-	return build_tl_forward(p, FWD_STEPS, 257, p->tl[1]);
+	if (int rc = build_tl_forward(p, FWD_STEPS_TL, TL_MINNS0, p->tl[0])) return rc;
+	return build_tl_forward(p, FWD_STEPS_TL, 257, p->tl[1]);
 }
 
 // Decomposition for many-trace batches (fwd_tl.h): octaves (runs of scales with the same D and Ns) with at least MINNS
