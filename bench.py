@@ -478,6 +478,25 @@ def other_configs(abi, tspws, lib, torch, X, N):
         "check": {"kind": kind, "sample": f"first {nsub} traces, whole call", "cpu_seconds": r["seconds"],
                   "relerr": {"ls": abi.relerr(g[0].cpu().numpy(), r["ls"]), "tsPWS": abi.relerr(g[1].cpu().numpy(), r["tsPWS"])}}}
     del X2, pl2
+    # ---- cfg1: the shipped example's shape, 499 x 16501 (N odd: no decimation divides it), single-stage and TwoStage=10 unbiased ---
+    N1, m1 = 16501, 499
+    X1 = tspws.synth(m1, N1, seed=1)
+    X1h = X1.cpu().numpy()
+    l1 = torch.empty(N1, dtype=torch.float32, device="cuda")
+    t1 = torch.empty(N1, dtype=torch.float32, device="cuda")
+    c1 = {}
+    for name, kw in (("single_stage", dict()), ("two_stage_k10_unbiased", dict(Kmax=10, unbiased=1))):
+        pin = abi.default_params(**kw)
+        pl1 = tspws.Plan(tspws.resolve(pin, N1), N1)
+        sec = timeit(torch, lambda: pl1.stack_single(X1, l1, t1), 40, 10)
+        torch.cuda.synchronize()
+        r = call_main(abi, cpu_fn, pin, X1h, N1, m1)   # the WHOLE ensemble on the CPU: this is the reference's own runnable size
+        c1[name] = {"ms_per_call": sec * 1e3, "value": m1 * N1 / sec, "unit": "samples/s", "cpu_seconds": r["seconds"], "speedup_hbm_resident": r["seconds"] / sec,
+                    "relerr": {"ls": abi.relerr(l1.cpu().numpy(), r["ls"]), "tsPWS": abi.relerr(t1.cpu().numpy(), r["tsPWS"])}}
+        del pl1
+    out["cfg1_example_shape_499x16501"] = {"timed_calls": 40, "warmup_calls": 10, "check_kind": kind, "note": "BASELINE configs[0]: synthetic traces of the shipped "
+                                           "example's shape; whole ensemble checked against the CPU path", **c1}
+    del X1
     # ---- cfg4: 10k x 131072, Mexican hat, two-stage K = 10 + jackknife n = 10, d = 1 ---------------------------------------
     mtr = X.shape[0]
     pin = abi.default_params(type=-3, Kmax=10, jackknife_n=10, jackknife_d=1)
