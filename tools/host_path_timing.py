@@ -43,13 +43,13 @@ for name, fn in (("hip tspws_main (host buffers)", lib.tspws_main), ("reference"
     for rep in range(3):
         dt, rc, ts = call(fn, X)
     res[name] = ts
-    print(f"{name:32s} {mtr} x {N}: {dt * 1e3:9.1f} ms  ({mtr * N / dt:.3e} samples/s, {4 * mtr * N / dt / 1e9:.1f} GB/s of input)  rc={rc}")
+    print(f"{name:32s} {mtr} x {N}: {dt * 1e3:9.3f} ms  ({mtr * N / dt:.3e} samples/s, {4 * mtr * N / dt / 1e9:.1f} GB/s of input)  rc={rc}")
 # a caller that hands a NEW buffer every call (fresh pages, never pinned before)
 for rep in range(3):
     Y = X.copy()
     dt, rc, ts = call(lib.tspws_main, Y)
     del Y
-print(f"{'hip tspws_main (fresh buffer)':32s} {mtr} x {N}: {dt * 1e3:9.1f} ms  ({4 * mtr * N / dt / 1e9:.1f} GB/s of input)  rc={rc}")
+print(f"{'hip tspws_main (fresh buffer)':32s} {mtr} x {N}: {dt * 1e3:9.3f} ms  ({4 * mtr * N / dt / 1e9:.1f} GB/s of input)  rc={rc}")
 if len(res) == 2:
     a, b = res.values()
     print("relerr hip vs reference:", abi.relerr(a, b))

@@ -384,7 +384,11 @@ static int main_single(dev_slot *sl, t_tsPWS *tspws, t_tsPWS_out *out, t_data *i
 		if (!do_fold && !tspws->lrm) { free(sub_sel); return TSPWS_E_NOMEM; }
 	}
 
-	TRY(get_trace_buffer(sl, &d_sig, mtr * ld * sizeof(float), dev));
+	/* the two output rows live behind the traces in the slot's buffer: no allocation per call (a small daily ensemble's call is
+	 * ~0.1 ms of kernels -- an allocation, a free and a second blocking copy were as much again) */
+	const size_t sig_bytes = (mtr * ld * sizeof(float) + 255) & ~(size_t)255;
+	TRY(get_trace_buffer(sl, &d_sig, sig_bytes + 2 * ld * sizeof(float), dev));
+	d_out = (float *)((char *)d_sig + sig_bytes);
 	TRY(tspws_hip_upload(d_sig, in->sigall, mtr * ld * sizeof(float), NULL));
 
 	/* in-place prologue on the device, then mirrored back: the caller sees the same mutated
@@ -393,7 +397,6 @@ static int main_single(dev_slot *sl, t_tsPWS *tspws, t_tsPWS_out *out, t_data *i
 	if (tspws->lrm) TRY(tspws_hip_remove_mean(d_sig, mtr, (size_t)max, ld, NULL));
 	if (do_fold || tspws->lrm) TRY(tspws_hip_download(in->sigall, d_sig, mtr * ld * sizeof(float), NULL));
 	if (frame_rc) { rc = TSPWS_E_NOMEM; goto done_quiet; }
-	TRY(tspws_hip_alloc((void **)&d_out, 2 * ld * sizeof(float), dev));
 
 	/* jackknife masks first (host, :385-430): the stack below then streams the traces ONCE for its own groups and for every
 	 * replica; the replicas stay on the device until the point where the reference computes them (:335-345) */
@@ -412,8 +415,15 @@ static int main_single(dev_slot *sl, t_tsPWS *tspws, t_tsPWS_out *out, t_data *i
 		}
 	}
 	if (!jk_ready) TRY(tspws_hip_stack(plan, tspws, d_sig, ld, mtr, d_out, d_out + ld, NULL));
-	TRY(tspws_hip_download(out->ls, d_out, ld * sizeof(float), NULL));
-	TRY(tspws_hip_download(out->tsPWS, d_out + ld, ld * sizeof(float), NULL));
+	if (out->ls + ld == out->tsPWS) TRY(tspws_hip_download(out->ls, d_out, 2 * ld * sizeof(float), NULL)); /* (adjacent rows: one copy) */
+	else {
+		stage = (float *)malloc(2 * ld * sizeof(float)); /* one blocking copy for both rows */
+		if (!stage) { rc = TSPWS_E_NOMEM; goto done; }
+		TRY(tspws_hip_download(stage, d_out, 2 * ld * sizeof(float), NULL));
+		memcpy(out->ls, stage, ld * sizeof(float));
+		memcpy(out->tsPWS, stage + ld, ld * sizeof(float));
+		free(stage); stage = NULL;
+	}
 
 	/* convergence curves, :247-314 */
 	if (tspws->convergence && out->ls_sim && out->tsPWS_sim && out->ls_misfit && out->tsPWS_misfit) {
@@ -477,7 +487,6 @@ done_quiet:
 	tspws_hip_free(d_steps_ts);
 	tspws_hip_free(d_ref);
 	tspws_hip_free(d_jk);
-	tspws_hip_free(d_out);
 	if (!cache_enabled()) slot_release_locked(sl); /* else: the frame and the trace buffer serve the next call on this device */
 	return rc;
 }
