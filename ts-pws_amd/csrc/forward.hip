@@ -167,7 +167,9 @@ int tspws_build_forward(tspws_hip_plan *p)
 	// kernel, smaller batches (and frames with two voices per octave) with >= 257 -- the trace-lane kernel has tl.wgs x blocks
 	// workgroups, the direct kernel splits the taps
 	if (int rc = build_tl_forward(p, FWD_STEPS_TL, TL_MINNS0, p->tl[0])) return rc;
-	return build_tl_forward(p, FWD_STEPS_TL, 257, p->tl[1]);
+	unsigned minns1 = 257;
+	if (const char *e = getenv("TSPWS_TL_MINNS1")) minns1 = (unsigned)std::max(9, atoi(e)); // sweeps
+	return build_tl_forward(p, FWD_STEPS_TL, minns1, p->tl[1]);
 }
 
 // Decomposition for many-trace batches (fwd_tl.h): octaves (runs of scales with the same D and Ns) with at least MINNS
