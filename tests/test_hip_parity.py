@@ -324,6 +324,40 @@ def test_masked_replica_engines_agree(env):
     assert float(line[0].split()[1]) < TOL32, line[0]
 
 
+@pytest.mark.parametrize("env", [dict(), dict(TSPWS_INV_SPLIT="0"), dict(TSPWS_INV_SPLIT="1"), dict(TSPWS_FUSE_WGS="1"), dict(TSPWS_FUSE_WGS="2048"),
+                                 dict(TSPWS_FWD_STEPS="96"), dict(TSPWS_FWD_STEPS="8"), dict(TSPWS_TL_PICK="0"), dict(TSPWS_TL_PICK="1", TSPWS_TL_MINNS1="65")])
+def test_short_frame_and_many_trace_forms_agree(env):
+    """Round-4 rules that pick a launch geometry by frame length / batch size -- inverse items per octave or per scale, slice
+    length of the fused forward launch, tap steps per wave of the direct kernel, decomposition of the many-trace path -- each
+    forced both ways: whole tspws_main calls on short frames and small ensembles against the oracle.  Fresh process per case
+    (the switches are read once per process or per frame)."""
+    import subprocess
+    import sys as _sys
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "shape_engines.py")], capture_output=True, text=True,
+                       timeout=900, env=e)
+    line = [l for l in r.stdout.splitlines() if l.startswith("SHAPE_ENGINES")]
+    assert line, r.stdout[-3000:] + r.stderr[-3000:]
+    assert float(line[0].split()[1]) < TOL32, line[0]
+
+
+def test_upload_in_pieces_of_an_unaligned_host_buffer(lib, torch):
+    """tspws_hip_upload pins and copies large host buffers in page-aligned 128-MB pieces: a source that starts in the middle of a
+    page and ends in the middle of a piece arrives byte for byte (and the plain small copy too)."""
+    import ctypes as C
+    for nbytes in (300 * (1 << 20) + 12345, 5 * (1 << 20) + 3):
+        raw = np.random.default_rng(4).integers(0, 256, nbytes + 4096 + 64, dtype=np.uint8)
+        off = (-raw.ctypes.data) % 4096 + 20                 # 20 bytes into a page
+        src = raw[off:off + nbytes]
+        dst = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        assert lib.tspws_hip_upload(C.c_void_p(dst.data_ptr()), C.c_void_p(src.ctypes.data), C.c_size_t(nbytes), None) == 0
+        assert np.array_equal(dst.cpu().numpy(), src)
+        again = np.empty(nbytes, np.uint8)
+        assert lib.tspws_hip_download(C.c_void_p(again.ctypes.data), C.c_void_p(dst.data_ptr()), C.c_size_t(nbytes), None) == 0
+        assert np.array_equal(again, src)
+
+
 # ------------------------------------------------------- device-resident / sharded path
 @pytest.mark.parametrize("kw", [dict(Kmax=10, unbiased=1), dict(), dict(type=-3, Kmax=4)])
 def test_device_path_and_shards(lib, torch, kw):
