@@ -516,6 +516,13 @@ void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb
 	                   ex ? ex->rowmap : (const unsigned *)nullptr);
 }
 
+unsigned tspws_first_unfused_scale(const tspws_hip_plan *p)
+{
+	unsigned s = 0;
+	while (s < p->S && p->sc[s].fuse_ok) s++;
+	return s;
+}
+
 // slice length of the fused forward kernel for a batch of nb traces: whole batch when it is small (two-stage: the K
 // partial stacks -> ONE slice that writes ST / PS directly), else 32 traces per slice
 // Short frames have few workgroups per slice (N = 8192: 72; the chip holds 512 at a time): slices are halved until the launch has
@@ -640,8 +647,8 @@ static int stacks_impl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld,
 			if (nsl == 1 && zero_first) { fz.accST = (double2 *)d_ST; fz.accPS = (double2 *)d_PS; fz.stride = 0; }
 			else { fz.accST = (double2 *)vz; fz.accPS = (double2 *)vz + p->ncoef; fz.stride = 2 * p->ncoef; }
 		}
-		if ((rc = forward_parts<TIn>(p, d_x + t0 * ld, nb, ld, (double2 *)v, st, fuse ? &fz : nullptr, rg))) return rc;
 		const bool all = nb == ntr && !keep; // one batch holds every trace: the accumulation completes the stacks
+		if ((rc = forward_parts<TIn>(p, d_x + t0 * ld, nb, ld, (double2 *)v, st, fuse ? &fz : nullptr, rg))) return rc;
 		tspws_launch_accumulate(p, (const double2 *)v, (unsigned)nb, (double2 *)d_ST, (double2 *)d_PS, zero_first, &fz, nsl, st, 1, 0, 0, nullptr, all ? wa : nullptr, rg);
 		if (all && wa && wa->OUT && weighted) *weighted = true;
 	}

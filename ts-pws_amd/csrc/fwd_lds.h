@@ -540,7 +540,7 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 								}
 								st.x = s0.x + st.x; st.y = s0.y + st.y; ps.x = p0.x + ps.x; ps.y = p0.y + ps.y;
 							}
-							ff.OUT[slice * ff.out_stride + ci] = weight_value(st, ps, ff.mode, ff.K, ff.Mv[slice], ff.wu);
+							ff.OUT[slice * ff.out_stride + ci] = weight_value(st, ps, ff.mode, ff.K, ff.Mv ? ff.Mv[slice] : ff.M, ff.wu);
 							if ((int)slice == ff.keep_slice) ff.keepST[ci] = st;
 						} else { accST[ci] = fst[p][i]; accPS[ci] = fps[p][i]; }
 					}

@@ -627,11 +627,11 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 		// only the scales with phase splits are left; the plain stack's ST goes straight to its set behind the weighted ones (batch C: ST + C y_stack)
 		ex.fused_done = true;
 		double2 *ST_arg = with_stack ? (double2 *)OUT + (size_t)W * nc - (size_t)C * 2 * nc : (double2 *)STr;
-		// (the launch covers the scales behind the last fused one only: the split scales are the far-decimated ones at the end of the list)
-		unsigned s_first = pl->S;
-		while (s_first > 0 && !pl->sc[s_first - 1].fuse_ok) s_first--;
+		// (the launch starts at the first scale the fused kernel left out -- the split scales are the far-decimated ones at the end of the
+		// list --; fused scales inside its range are skipped by the kernel)
+		const unsigned s_first = tspws_first_unfused_scale(pl);
 		ScaleRange rg; rg.s0 = s_first; rg.s1 = pl->S;
-		if (s_first == 0) rg = ScaleRange(); // (no fused scale at all: everything)
+		if (s_first == 0) rg = ScaleRange(); // (no fused scale in front: everything)
 		if (s_first < pl->S) tspws_launch_accumulate(pl, (const double2 *)part, KM, ST_arg, (double2 *)STr + nc, 1, &fa, mp.nstage, st, W, 0, 2 * nc, nullptr, &wa, rg, &ex);
 	} else {
 		tspws_launch_accumulate(pl, (const double2 *)part, KM, (double2 *)STr, (double2 *)STr + nc, 1, fuse ? &fa : nullptr, mp.nstage, st, W, 0, 2 * nc, nullptr, &wa, ScaleRange(), &ex);

@@ -105,7 +105,8 @@ struct FuseFinal {
 	unsigned nprev = 0;
 	double2 *OUT = nullptr;                       // nullptr: off
 	size_t out_stride = 0;
-	const double *Mv = nullptr;
+	const double *Mv = nullptr;                   // trace count per slice (nullptr: M for all)
+	double M = 0;
 	int mode = 0, keep_slice = -1;
 	double2 *keepST = nullptr;                    // [ncoef] set that receives the linear stack of slice keep_slice
 	double K = 0, wu = 0;
@@ -307,6 +308,7 @@ int  tspws_forward_parts_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, s
 // stacks, *weighted tells whether that happened; rg: only these scales)
 int  tspws_stacks_f32(tspws_hip_plan *p, const float *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, hipStream_t st, bool keep,
                       const WeightArgs *wa, bool *weighted, ScaleRange rg);
+unsigned tspws_first_unfused_scale(const tspws_hip_plan *p); // scales [it, S) hold every scale the fused forward kernel does not stack itself
 int  tspws_stacks_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, hipStream_t st, bool keep,
                       const WeightArgs *wa, bool *weighted, ScaleRange rg);
 // k_accumulate_parts for nb transformed traces (nbatch independent stacks side by side: y_part / y_stack apart)
