@@ -526,16 +526,18 @@ unsigned tspws_first_unfused_scale(const tspws_hip_plan *p)
 // slice length of the fused forward kernel for a batch of nb traces: whole batch when it is small (two-stage: the K
 // partial stacks -> ONE slice that writes ST / PS directly), else 32 traces per slice
 // Short frames have few workgroups per slice (N = 8192: 72; the chip holds 512 at a time): slices are halved until the launch has
-// ~256 workgroups (TSPWS_FUSE_WGS), but not below six traces -- a slice's set-up (taps, first window) weighs as much as a few
-// traces: the ten partial stacks of a two-stage call stay ONE slice (499 x 16501 two-stage 0.123 ms as one slice, 0.135-0.139 as
-// two or four).  tools/experiments/fuse_slices.sh: 64 x 8192 single-stage 0.152 -> 0.106 ms, 30 x 4096 0.127 -> 0.065; the
-// slices' plane pairs are added in slice order by the accumulation.
+// ~256 workgroups (TSPWS_FUSE_WGS), down to three traces per slice (TSPWS_FUSE_MINTPS) -- also the ten partial stacks of a
+// two-stage call on a short frame: 64 x 8192 two-stage 0.073 -> 0.064 ms, 30 x 4096 0.070 -> 0.059, 64 x 2048 0.068 -> 0.055;
+// single-stage 64 x 8192 0.152 -> 0.106, 30 x 4096 0.127 -> 0.065 (tools/experiments/fuse_slices.sh).  From N = 16501 up the K
+// partial stacks are one slice again (208 workgroups and more).  The slices' plane pairs are added in slice order by the accumulation.
 static unsigned fuse_tps(const tspws_hip_plan *p, size_t nb)
 {
 	static int target = -1;
 	if (target < 0) { const char *e = getenv("TSPWS_FUSE_WGS"); target = e ? std::max(1, atoi(e)) : 256; }
 	unsigned tps = (unsigned)std::min<size_t>(nb, 32);
-	while ((tps + 1) / 2 >= 6 && (size_t)std::max(1u, p->lds_blocks) * ((nb + tps - 1) / tps) < (size_t)target) tps = (tps + 1) / 2;
+	static int mintps = -1;
+	if (mintps < 0) { const char *e = getenv("TSPWS_FUSE_MINTPS"); mintps = e ? std::max(1, atoi(e)) : 3; }
+	while ((tps + 1) / 2 >= (unsigned)mintps && (size_t)std::max(1u, p->lds_blocks) * ((nb + tps - 1) / tps) < (size_t)target) tps = (tps + 1) / 2;
 	return std::max(1u, tps);
 }
 
