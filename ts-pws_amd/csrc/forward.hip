@@ -114,7 +114,7 @@ static long tl_min_env()
 #ifndef FWD_STEPS_TL
 #define FWD_STEPS_TL 96  /* ... beside k_fwd_tl on many traces: there are thousands of waves, longer ones amortise their set-up (cfg2 3.08 vs 3.14 ms at 32) */
 #endif
-static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, TlTable &T);
+static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, unsigned TLSTEPS, TlTable &T);
 
 // Work decomposition of the forward kernels.  Scales with >= 8 output groups and (D >= 64 or D a power of two) run on the
 // LDS-staged kernel; the rest (very coarse scales, odd small decimations) on the direct kernel, which aims at ~FWD_STEPS
@@ -164,20 +164,23 @@ int tspws_build_forward(tspws_hip_plan *p)
 	if (const char *e = getenv("TSPWS_FWD_QT")) { const int v = atoi(e); if (v == 24 || v == 32) p->lds_qt = (unsigned)v; } // (sweeps)
 	// two many-trace decompositions (see stacks_tl for the choice): sweeps on 128 .. 2048 traces x 8192 .. 32768 samples, Morlet
 	// and Mexican hat (round 3): batches of >= 12 trace blocks are fastest with the octaves of >= 33 outputs on the trace-lane
-	// kernel, smaller batches (and frames with two voices per octave) with >= 257 -- the trace-lane kernel has tl.wgs x blocks
+	// kernel, smaller batches (and frames with two voices per octave) with >= 129 -- the trace-lane kernel has tl.wgs x blocks
 	// workgroups, the direct kernel splits the taps
-	if (int rc = build_tl_forward(p, FWD_STEPS_TL, TL_MINNS0, p->tl[0])) return rc;
-	unsigned minns1 = 257;
+	// table 0 (>= 12 trace blocks): octaves with >= 33 outputs on the trace-lane kernel, ~96 residue steps per workgroup; table 1 (fewer
+	// blocks: the launch has few workgroups): >= 129 outputs, ~48 steps -- tools/experiments/tl_pick.sh and the 2-D sweep of round 4:
+	// 499 x 16501 0.893 -> 0.865 ms, 256 x 32768 0.797 -> 0.780, 512 x 16384 0.885 -> 0.806 against (257, 96); cfg2 (table 0) 3.06 vs 3.16 at 48
+	if (int rc = build_tl_forward(p, FWD_STEPS_TL, TL_MINNS0, 96, p->tl[0])) return rc;
+	unsigned minns1 = 129, tlsteps1 = 48;
+	if (const char *e = getenv("TSPWS_TLSTEPS")) tlsteps1 = (unsigned)std::max(8, atoi(e)); // sweeps
 	if (const char *e = getenv("TSPWS_TL_MINNS1")) minns1 = (unsigned)std::max(9, atoi(e)); // sweeps
-	return build_tl_forward(p, FWD_STEPS_TL, minns1, p->tl[1]);
+	return build_tl_forward(p, FWD_STEPS_TL, minns1, tlsteps1, p->tl[1]);
 }
 
 // Decomposition for many-trace batches (fwd_tl.h): octaves (runs of scales with the same D and Ns) with at least MINNS
 // outputs become trace-lane work items (voice subsets of <= TL_VMAX voices), the rest stays on the direct kernel; T.sc is
 // the scale table of that decomposition (partial layout, fused flags, accumulate geometry).
-static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, TlTable &T)
+static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, unsigned TLSTEPS, TlTable &T)
 {
-	const unsigned TLSTEPS = 96; // ~96 residue steps per workgroup (sweeps on 1024 x 32768 and 499 x 16501)
 	T.minns = MINNS;
 	T.sc = p->sc;
 	std::vector<TLItem> items;
