@@ -540,7 +540,7 @@ static unsigned fuse_tps(const tspws_hip_plan *p, size_t nb)
 	unsigned tps = (unsigned)std::min<size_t>(nb, 32);
 	static int mintps = -1;
 	if (mintps < 0) { const char *e = getenv("TSPWS_FUSE_MINTPS"); mintps = e ? std::max(1, atoi(e)) : 3; }
-	while ((tps + 1) / 2 >= (unsigned)mintps && (size_t)std::max(1u, p->lds_blocks) * ((nb + tps - 1) / tps) < (size_t)target) tps = (tps + 1) / 2;
+	while (tps > 1 && (tps + 1) / 2 >= (unsigned)mintps && (size_t)std::max(1u, p->lds_blocks) * ((nb + tps - 1) / tps) < (size_t)target) tps = (tps + 1) / 2;
 	return std::max(1u, tps);
 }
 
