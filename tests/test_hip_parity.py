@@ -324,7 +324,7 @@ def test_masked_replica_engines_agree(env):
     assert float(line[0].split()[1]) < TOL32, line[0]
 
 
-@pytest.mark.parametrize("env", [dict(), dict(TSPWS_INV_SPLIT="0"), dict(TSPWS_INV_SPLIT="1"), dict(TSPWS_FUSE_WGS="1"), dict(TSPWS_FUSE_WGS="2048"),
+@pytest.mark.parametrize("env", [dict(), dict(TSPWS_INV_SPLIT="0"), dict(TSPWS_INV_SPLIT="1"), dict(TSPWS_FUSE_WGS="1"), dict(TSPWS_FUSE_WGS="2048"), dict(TSPWS_FUSE_WGS="2048", TSPWS_FUSE_MINTPS="1"),
                                  dict(TSPWS_FWD_STEPS="96"), dict(TSPWS_FWD_STEPS="8"), dict(TSPWS_TL_PICK="0"), dict(TSPWS_TL_PICK="1", TSPWS_TL_MINNS1="65")])
 def test_short_frame_and_many_trace_forms_agree(env):
     """Round-4 rules that pick a launch geometry by frame length / batch size -- inverse items per octave or per scale, slice
