@@ -85,6 +85,11 @@ def main():
     if args.gpus > 1 and world_env != args.gpus:
         if os.environ.get("BENCH_SELF_LAUNCHED"):
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env} inside the launcher")
+        if os.environ.get("BENCH_BACKEND", "nccl") == "nccl":
+            import torch   # (counting devices does not initialise the GPU in this process)
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                raise SystemExit(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s): one rank per GPU over RCCL needs {args.gpus}")
         sys.exit(self_launch(args))
     run(args)
 
@@ -246,7 +251,7 @@ def run(args):
     # csrc/stream.hip, written by profiles/collect_round.sh) -- a changed kernel reports null until its counters are collected again
     traffic = None
     tf = os.path.join(ROOT, "profiles", "pmc_partial_stacks.json")
-    if os.path.exists(tf) and (mtr_local, N, K, shard_of) == (10000, 131072, 10, 1):
+    if os.path.exists(tf) and (mtr_local, N, K, shard_of, world) == (10000, 131072, 10, 1, 1):   # (N > 1: null -- the counters were collected on one GPU)
         try:
             rec = json.load(open(tf))
             same_src = rec.get("stream_hip_sha256") == file_sha256(os.path.join(ROOT, "ts-pws_amd", "csrc", "stream.hip"))
@@ -316,9 +321,15 @@ def run(args):
                                                         res["cpu_baseline"].get("seconds"))
                 del Xh
                 res["other_configs"] = other_configs(abi, tspws, lib, torch, X, N)
+    if world > 1 and rank == 0 and not args.no_cpu:
+        # N > 1: the reference OpenMP path on THIS node's host cores beside the N-GPU number, in the same run (north_star): rank 0
+        # runs it on its own shard after the timed loop (the other ranks wait in the barrier below), and checks its shard-local
+        # partial stacks -- global group index, before any reduction -- against direct FP64 sums of the same traces
+        res["cpu_baseline"] = cpu_baseline_shard(abi, plan, X, abi.default_params(Kmax=K, unbiased=1), N, K, mtr_local, first, mtr_global, red)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -415,6 +426,31 @@ def cpu_baseline(abi, Xh, params_in, ls, ts, N, mtr):
                              "sample": "same traces; trace-/scale-parallel OpenMP restatement (oracle/tspws_oracle.c: orc_tspws_main_mt)",
                              "relerr_vs_reference": {"ls": abi.relerr(r2["ls"], r["ls"]), "tsPWS": abi.relerr(r2["tsPWS"], r["tsPWS"])}}
     return base, (r if n == mtr else None)
+
+
+def cpu_baseline_shard(abi, plan, X, params_in, N, K, mtr_local, first, mtr_global, red):
+    """world > 1, rank 0: the CPU path (reference when oracle/_ref is built, else the restatement) on this rank's own shard -- a
+    bounded sample of the job: 1 / world of the traces --, and the shard-vs-CPU error of the rank's partial-stack buffer."""
+    import numpy as np
+    import torch
+    ref = abi.ref()
+    fn, kind = (ref.tspws_main, "reference") if ref is not None else (abi.oracle().orc_tspws_main, "port")
+    Xh = X.cpu().numpy()
+    r = call_main(abi, fn, params_in, Xh, N, mtr_local)
+    base = {"value": mtr_local * N / r["seconds"], "unit": "samples/s", "cores": os.cpu_count(), "kind": kind, "seconds": r["seconds"], "rc": r["rc"],
+            "sample": f"rank 0's shard: {mtr_local} x {N} of the job's {mtr_global} synthetic traces (copied from HBM), whole tspws_main call on the shard, "
+                      f"OpenMP team = all cores (the reference's trace loop is serial, so ~1 core does the work)"}
+    # shard-local partial stacks (ts_pws1f_lib.c:866-881 with the GLOBAL trace index) against direct FP64 sums on the host
+    plan.stack_local(X, first, mtr_global)
+    torch.cuda.synchronize()
+    got = red.view(K, N).cpu().numpy()
+    g = ((first + np.arange(mtr_local, dtype=np.int64)) * K) // mtr_global
+    want = np.zeros((K, N), np.float64)
+    for k in np.unique(g):
+        idx = np.nonzero(g == k)[0]
+        want[k] = np.add.reduce(Xh[idx[0]:idx[-1] + 1], axis=0, dtype=np.float64)
+    base["shard_partial_stacks_relerr"] = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-300))
+    return base
 
 
 def host_path(abi, lib, Xh, params_in, N, mtr, ref_out, ref_seconds):

@@ -153,8 +153,17 @@ def _bench(args, env_extra=None, timeout=600):
 def test_bench_starts_its_own_ranks():
     """`bench.py --gpus 2` without a launcher around it: the parent starts two ranks before touching the GPU (here both on the
     one GPU of the box, collectives over gloo), rank 0's JSON line comes back through the parent."""
-    r = _bench(["--gpus", "2", "--traces", "64", "--samples", "4096", "--steps", "3", "--warmup", "1", "--no-cpu"], {"BENCH_BACKEND": "gloo"})
+    r = _bench(["--gpus", "2", "--traces", "64", "--samples", "4096", "--steps", "3", "--warmup", "1"], {"BENCH_BACKEND": "gloo"})
     assert r["n_gpus"] == 2 and r["config"]["world_size"] == 2 and r["config"]["backend"] == "gloo"
+    # the N > 1 line is complete: the CPU path on rank 0's shard beside the GPU number (cores stated), the shard's partial stacks
+    # checked against it, the roofline object (counter traffic null: collected on one GPU only), where every rank's step went
+    for k in ("cpu_baseline", "roofline", "per_rank_ms"):
+        assert k in r, k
+    cb = r["cpu_baseline"]
+    assert cb["rc"] == 0 and cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and "shard" in cb["sample"]
+    assert cb["shard_partial_stacks_relerr"] < 1e-12
+    assert r["roofline"]["traffic"] is None and set(("bound", "achieved", "peak", "unit", "frac")) <= set(r["roofline"])
+    assert len(r["per_rank_ms"]["ranks"]) == 2 and r["per_rank_ms"]["columns"] == ["stream", "exposed_collective", "finish"]
     assert r["config"]["traces_total"] == 128 and r["config"]["traces_per_gpu"] == 64
     assert r["value"] > 0 and r["scaling"] == "weak" and r["roofline"]["launches_per_call"] >= 1
     assert r["step_ms_gpu"]["n"] == 3 and r["step_ms_gpu"]["min"] <= r["step_ms_gpu"]["median"] <= r["step_ms_gpu"]["max"]
