@@ -101,6 +101,13 @@ int  tspws_hip_partial_stacks_range(tspws_hip_plan *plan, const float *d_sigall,
  * Takes over complex_1D_wavelet_dec (wavelet_v7.c:43-64) -> cdotx_dc (cdotx.c:35-72). */
 int  tspws_hip_forward_f64(tspws_hip_plan *plan, const double *d_x, size_t ntr, size_t ld, double *d_Y, void *stream);
 int  tspws_hip_forward_f32(tspws_hip_plan *plan, const float  *d_x, size_t ntr, size_t ld, double *d_Y, void *stream);
+/* The same coefficients through the SPECTRAL engine (csrc/spectral.hip): only the scales of the frame's spectral set for octaves of at
+ * most nsmax outputs -- [tspws_hip_spectral_first_scale(plan, nsmax), S) -- are written, the rest of d_Y[ntr][ncoef] is left alone.
+ * Exact for those scales because the reference's FIR is circular (cdotx.c:35-72) and their D divides N.  Returns TSPWS_E_ARG when
+ * the frame has no such set (N not a power of two >= 1024, odd decimations, ...). */
+unsigned tspws_hip_spectral_first_scale(const tspws_hip_plan *plan, unsigned nsmax);
+int  tspws_hip_forward_spectral_f64(tspws_hip_plan *plan, const double *d_x, size_t ntr, size_t ld, double *d_Y, unsigned nsmax, void *stream);
+int  tspws_hip_forward_spectral_f32(tspws_hip_plan *plan, const float  *d_x, size_t ntr, size_t ld, double *d_Y, unsigned nsmax, void *stream);
 /* Real part of the inverse frame transform of nrec coefficient sets d_Y[nrec][ncoef] into
  * d_x[nrec][N] doubles.  Takes over Re_complex_1D_wavelet_rec (wavelet_v7.c:124-150) ->
  * re_cdotx_upsampling_cc (cdotx.c:305-340) / re_cdotx_cc (cdotx.c:176-211). */

@@ -89,6 +89,9 @@ SYMBOLS = {
     "tspws_hip_partial_stacks_range": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _u, _u, _u, _vp, _sz, _vp]),
     "tspws_hip_forward_f64": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "tspws_hip_forward_f32": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "tspws_hip_spectral_first_scale": (_u, [_vp, _u]),
+    "tspws_hip_forward_spectral_f64": (_i, [_vp, _vp, _sz, _sz, _vp, _u, _vp]),
+    "tspws_hip_forward_spectral_f32": (_i, [_vp, _vp, _sz, _sz, _vp, _u, _vp]),
     "tspws_hip_inverse": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "tspws_hip_accumulate": (_i, [_vp, _vp, _sz, _vp, _vp, _i, _vp]),
     "tspws_hip_stacks_double": (_i, [_vp, _vp, _u, _sz, _vp, _vp, _vp]),

@@ -92,6 +92,7 @@ static int forward_generic(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t
 #include "fwd_poly.h"
 #include "fwd_lds.h"
 #include "fwd_tl.h"
+#include "spectral.h"
 
 // TSPWS_TL_MIN=n forces the many-trace path for batches of >= n traces (tests; read at every call), unset: the rule below
 static long tl_min_env()
@@ -114,7 +115,7 @@ static long tl_min_env()
 #ifndef FWD_STEPS_TL
 #define FWD_STEPS_TL 96  /* ... beside k_fwd_tl on many traces: there are thousands of waves, longer ones amortise their set-up (cfg2 3.08 vs 3.14 ms at 32) */
 #endif
-static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, unsigned TLSTEPS, TlTable &T);
+static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, unsigned TLSTEPS, TlTable &T, unsigned spec_first = ~0u);
 
 // Work decomposition of the forward kernels.  Scales with >= 8 output groups and (D >= 64 or D a power of two) run on the
 // LDS-staged kernel; the rest (very coarse scales, odd small decimations) on the direct kernel, which aims at ~FWD_STEPS
@@ -179,16 +180,19 @@ int tspws_build_forward(tspws_hip_plan *p)
 // Decomposition for many-trace batches (fwd_tl.h): octaves (runs of scales with the same D and Ns) with at least MINNS
 // outputs become trace-lane work items (voice subsets of <= TL_VMAX voices), the rest stays on the direct kernel; T.sc is
 // the scale table of that decomposition (partial layout, fused flags, accumulate geometry).
-static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, unsigned TLSTEPS, TlTable &T)
+// spec_first: the scales [spec_first, S) are left to the spectral engine (spectral.hip) -- no work items here, and the scale table
+// marks them as stacked by their producer (one plane pair per 64-trace block, like the trace-lane kernel's fused scales).
+static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, unsigned TLSTEPS, TlTable &T, unsigned spec_first)
 {
 	T.minns = MINNS;
 	T.sc = p->sc;
 	std::vector<TLItem> items;
 	std::vector<char> is_tl(p->S, 0);
 	unsigned wg = 0;
-	for (unsigned s = 0; s < p->S;) {
+	const unsigned S_fir = std::min(p->S, spec_first);
+	for (unsigned s = 0; s < S_fir;) {
 		unsigned e = s + 1;
-		while (e < p->S && p->sc[e].D == p->sc[s].D && p->sc[e].Ns == p->sc[s].Ns) e++;
+		while (e < S_fir && p->sc[e].D == p->sc[s].D && p->sc[e].Ns == p->sc[s].Ns) e++;
 		const unsigned D = p->sc[s].D, Ns = p->sc[s].Ns, nv = e - s;
 		bool ok = Ns >= MINNS;
 		std::vector<unsigned> a(nv), b(nv), qr(nv);
@@ -240,7 +244,9 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINN
 	for (unsigned s = 0; s < p->S; s++) {
 		ScaleDesc &d = T.sc[s];
 		d.use_lds = 0; d.lds_off = 0;
-		if (is_tl[s]) {
+		const bool is_spec = s >= spec_first;
+		if (is_spec) { d.nsplit = 1; d.cps = 1; d.fuse_ok = 1; }
+		else if (is_tl[s]) {
 			d.nsplit = (d.D + TL_PMAX - 1) / TL_PMAX; d.cps = 1;
 			d.fuse_ok = d.nsplit == 1 ? 1u : 0u;
 		} else { // direct kernel, as in the few-trace table
@@ -250,9 +256,9 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINN
 			d.fuse_ok = 0;
 		}
 		d.wave_off = woff;
-		if (!is_tl[s]) woff += d.ngw * d.nsplit;
+		if (!is_tl[s] && !is_spec) woff += d.ngw * d.nsplit;
 		d.part_off = poff;
-		if (!(is_tl[s] && d.fuse_ok)) poff += (unsigned long long)d.nsplit * d.Ns; // fused scales never write partials
+		if (!((is_tl[s] || is_spec) && d.fuse_ok)) poff += (unsigned long long)d.nsplit * d.Ns; // fused scales never write partials
 		d.acc2_off = ablk;
 		// 4 coefficients per block, a wave each, for every scale whose per-trace partials are added by k_accumulate_parts (`many`): its lanes
 		// take every 64th trace.  (One thread per coefficient walked all traces of the batch in dependent round trips: 80 us at 499 x 16501.)
@@ -260,14 +266,20 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINN
 	}
 	for (TLItem &o : items) for (unsigned i = 0; i < o.nv; i++) o.part_off[i] = T.sc[o.sc[i]].part_off;
 	T.n = (unsigned)items.size(); T.wgs = wg; T.waves = woff; T.acc2_blocks = ablk; T.npart = poff;
-	if (!T.n) return 0;
+	if (!T.n && spec_first >= p->S) return 0;
 	HIP_TRY(hipMalloc(&T.d_sc, p->S * sizeof(ScaleDesc)));
 	HIP_TRY(hipMemcpy(T.d_sc, T.sc.data(), p->S * sizeof(ScaleDesc), hipMemcpyHostToDevice));
+	if (!T.n) return 0;
 	HIP_TRY(hipMalloc(&T.d_items, items.size() * sizeof(TLItem)));
 	HIP_TRY(hipMemcpy(T.d_items, items.data(), items.size() * sizeof(TLItem), hipMemcpyHostToDevice));
 	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_tl<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute((const void *)k_fwd_tl<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	return 0;
+}
+
+int tspws_build_tl_spectral(tspws_hip_plan *p, unsigned s_first, TlTable &T)
+{
+	return build_tl_forward(p, FWD_STEPS_TL, TL_MINNS0, 96, T, s_first);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -431,9 +443,33 @@ bool tspws_fused_forward(const tspws_hip_plan *p) { return p->n_fusable != 0; }
 // (320 x 32768: 1.24 vs 1.40; 1024 x 32768: 3.03 vs 4.19; 256 x 131072: 3.60 vs 4.10); frames with two voices per octave
 // (Mexican hat) stay on the few-trace kernels at every size measured (1024 x 32768: 3.66 vs 4.63; 4096 x 16384: 8.5 vs 9.9) --
 // a trace-lane work item shares its staged rows among the voices of an octave.
+// Engine of a many-trace batch: the first scale of the spectral set (S: every scale on the FIR kernels).  TSPWS_ENGINE=fir / spectral
+// pins it (spectral: every batch that has such a set takes the many-trace path, whatever its size); default: the rule below.
+// TSPWS_SPEC_NSMAX: octaves with at most this many outputs go through the spectrum.
+unsigned tspws_spectral_choice(const tspws_hip_plan *p, size_t ntr)
+{
+	static int eng = -1; // 0 auto, 1 fir, 2 spectral
+	static unsigned nsmax_env = 0;
+	if (eng < 0) {
+		const char *e = getenv("TSPWS_ENGINE");
+		eng = !e ? 0 : !strcmp(e, "fir") ? 1 : !strcmp(e, "spectral") ? 2 : 0;
+		if (const char *m = getenv("TSPWS_SPEC_NSMAX")) nsmax_env = (unsigned)std::max(2, atoi(m));
+	}
+	if (eng == 1 || tspws_generic_forward()) return p->S;
+	if (eng == 0 && ntr < 128) return p->S;
+	return tspws_spectral_first_scale(p, nsmax_env ? nsmax_env : 1024u);
+}
+
+static int spectral_run_t(tspws_hip_plan *p, SpecDecomp *dc, const float *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st)
+{ return tspws_spectral_run_f32(p, dc, xT, TP, ntr, ST, PS, stride, Y, st); }
+static int spectral_run_t(tspws_hip_plan *p, SpecDecomp *dc, const double *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st)
+{ return tspws_spectral_run_f64(p, dc, xT, TP, ntr, ST, PS, stride, Y, st); }
+
 bool tspws_many_trace_path(const tspws_hip_plan *p, size_t ntr)
 {
-	if (!(p->tl[0].n || p->tl[1].n) || tspws_generic_forward()) return false;
+	if (tspws_generic_forward()) return false;
+	if (const char *e = getenv("TSPWS_ENGINE")) if (!strcmp(e, "spectral") && ntr && tspws_spectral_choice(p, ntr) < p->S) return true;
+	if (!(p->tl[0].n || p->tl[1].n)) return false;
 	const long forced = tl_min_env();
 	if (forced > 0) return ntr >= (size_t)forced;
 	return p->V > 2 && ntr >= 128 && (double)ntr * (double)p->N >= 7.0 * 1048576.0; // (tools/experiments/tl_threshold.sh: 128 x 65536 0.94 vs 0.86 ms, 160 x 32768 0.63 vs 0.69, 1024 x 4096 0.58 vs 0.70, 499 x 16501 1.17 vs 0.99)
@@ -467,6 +503,42 @@ extern "C" int tspws_hip_forward_f64(tspws_hip_plan *p, const double *d_x, size_
 extern "C" int tspws_hip_forward_f32(tspws_hip_plan *p, const float *d_x, size_t ntr, size_t ld, double *d_Y, void *s)
 {
 	return forward_impl<float>(p, d_x, ntr, ld, d_Y, S_(s));
+}
+
+// Per-trace coefficients of the spectral set through the spectral engine (parity tests, the per-trace API): batches of <= 4096 traces
+// are transposed like the many-trace stacks, the last inverse pass writes the traces' own coefficients.
+template <typename TIn>
+static int forward_spectral(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double *d_Y, unsigned nsmax, hipStream_t st)
+{
+	if (!p || !d_x || !d_Y) return fail(TSPWS_E_ARG, "forward_spectral: NULL");
+	if (!ntr) return 0;
+	HIP_TRY(hipSetDevice(p->device));
+	const unsigned sf = tspws_spectral_first_scale(p, nsmax);
+	if (sf >= p->S) return fail(TSPWS_E_ARG, "forward_spectral: this frame has no spectral set");
+	SpecDecomp *dc = nullptr;
+	int rc;
+	if ((rc = tspws_spectral_decomp(p, sf, (unsigned)std::min<size_t>((ntr + 63) / 64, 64), &dc))) return rc;
+	const size_t batch = std::min<size_t>(4096, (ntr + 63) & ~(size_t)63);
+	void *v;
+	if ((rc = scratch(p, SCR_XT, (size_t)p->N * batch * sizeof(TIn), &v))) return rc;
+	TIn *xT = (TIn *)v;
+	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
+		const unsigned nb = (unsigned)std::min(batch, ntr - t0), nblk = (nb + 63) / 64, TP = nblk * 64;
+		hipLaunchKernelGGL((k_transpose_traces<TIn>), dim3((p->N + 63) / 64, nblk), dim3(256), 0, st, d_x + t0 * ld, ld, nb, p->N, TP, xT);
+		if ((rc = spectral_run_t(p, dc, (const TIn *)xT, TP, nb, nullptr, nullptr, 0, (double2 *)d_Y + t0 * p->ncoef, st))) return rc;
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+extern "C" unsigned tspws_hip_spectral_first_scale(const tspws_hip_plan *p, unsigned nsmax) { return p ? tspws_spectral_first_scale(p, nsmax) : 0u; }
+extern "C" int tspws_hip_forward_spectral_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, size_t ld, double *d_Y, unsigned nsmax, void *s)
+{
+	return forward_spectral<double>(p, d_x, ntr, ld, d_Y, nsmax, S_(s));
+}
+extern "C" int tspws_hip_forward_spectral_f32(tspws_hip_plan *p, const float *d_x, size_t ntr, size_t ld, double *d_Y, unsigned nsmax, void *s)
+{
+	return forward_spectral<float>(p, d_x, ntr, ld, d_Y, nsmax, S_(s));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -555,7 +627,11 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 	// decomposition: many trace blocks and more than two voices per octave -> tl[0], else tl[1] (tspws_build_forward)
 	unsigned pick = ((ntr + 63) / 64 >= 12 && p->V > 2) ? 0u : 1u;
 	if (const char *e = getenv("TSPWS_TL_PICK")) pick = atoi(e) ? 1u : 0u; // sweeps: force a decomposition
-	const TlTable &T = p->tl[p->tl[pick].n ? pick : 1u - pick]; // (a short frame may leave one of them without trace-lane items)
+	// ... or the spectral engine for the far-decimated octaves (spectral.hip) with its own decomposition of the rest
+	SpecDecomp *dc = nullptr;
+	const unsigned spec_first = tspws_spectral_choice(p, ntr);
+	if (spec_first < p->S && (rc = tspws_spectral_decomp(p, spec_first, (unsigned)std::min<size_t>((ntr + 63) / 64, 64), &dc))) return rc;
+	const TlTable &T = dc ? dc->T : p->tl[p->tl[pick].n ? pick : 1u - pick]; // (a short frame may leave one of them without trace-lane items)
 	// traces per batch: transposed copy <= 1 GiB, at most 4096 (64 plane pairs), a multiple of 64
 	size_t batch = std::min<size_t>(4096, std::max<size_t>(64, (((size_t)1 << 30) / ((size_t)p->N * sizeof(TIn))) & ~(size_t)63));
 	if (T.npart) batch = std::min(batch, std::max<size_t>(64, (tspws_part_budget_bytes() / (T.npart * sizeof(double2))) & ~(size_t)63));
@@ -574,7 +650,14 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 		// the direct kernel (scales with too few outputs for the trace-lane kernel: latency-bound, tl partial layout) on the side
 		// stream: it reads the traces themselves, so it starts with the transposition and runs beside the trace-lane kernel
 		hipStream_t sp = st;
-		if (T.waves) {
+		if (T.waves && dc) { // (a frame whose middle octaves fit neither the trace-lane kernel nor the spectral set: the direct kernel in line)
+			const unsigned nbw = (T.waves + 3) / 4;
+			for (size_t u0 = 0; u0 < nb; u0 += 2 * 32768) {
+				const unsigned nt = (unsigned)std::min<size_t>(nb - u0, 2 * 32768);
+				hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nbw, (nt + 1) / 2), dim3(256), 0, st, xb + u0 * ld, ld, nt, p->N, T.d_sc, p->S, p->d_w,
+				                   part + u0 * T.npart, T.npart, T.waves);
+			}
+		} else if (T.waves) {
 			const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
 			if (!p->side) HIP_TRY(tspws_side_stream(p));
 			if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, evf));
@@ -590,8 +673,21 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 			}
 		}
 		hipLaunchKernelGGL((k_transpose_traces<TIn>), dim3((p->N + 63) / 64, nblk), dim3(256), 0, st, xb, ld, nb, p->N, TP, xT);
-		hipLaunchKernelGGL((k_fwd_tl<TIn>), dim3(T.wgs, nblk), dim3(TL_NT), T.lds, st, (const TIn *)xT, TP, nb, p->N, T.d_items, T.n, p->d_w,
-		                   planes, planes + p->ncoef, 2 * p->ncoef, part, T.npart);
+		// the spectral chain (transforms through HBM / MALL: bandwidth-bound) beside the trace-lane kernel (FP64-bound) on the side stream
+		static const bool spec_serial = getenv("TSPWS_SPEC_SERIAL") != nullptr; // sweeps: one after the other
+		if (dc && T.n && !spec_serial) {
+			const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+			if (!p->side) HIP_TRY(tspws_side_stream(p));
+			if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, evf));
+			if (!p->ev_join) HIP_TRY(hipEventCreateWithFlags(&p->ev_join, evf));
+			HIP_TRY(hipEventRecord(p->ev_fork, st)); // (after the transposition)
+			HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+			sp = p->side;
+		}
+		if (dc && (rc = spectral_run_t(p, dc, (const TIn *)xT, TP, nb, planes, planes + p->ncoef, 2 * p->ncoef, nullptr, dc && T.n && !spec_serial ? sp : st))) return rc;
+		if (T.n)
+			hipLaunchKernelGGL((k_fwd_tl<TIn>), dim3(T.wgs, nblk), dim3(TL_NT), T.lds, st, (const TIn *)xT, TP, nb, p->N, T.d_items, T.n, p->d_w,
+			                   planes, planes + p->ncoef, 2 * p->ncoef, part, T.npart);
 		if (sp != st) {
 			HIP_TRY(hipEventRecord(p->ev_join, sp));
 			HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));

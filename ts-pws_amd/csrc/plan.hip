@@ -228,6 +228,7 @@ extern "C" void tspws_hip_plan_destroy(tspws_hip_plan *p)
 	if (p->xf) (void)hipStreamDestroy(p->xf);
 	for (hipEvent_t e : p->stage_ev) (void)hipEventDestroy(e);
 	if (p->d_oc) (void)hipFree(p->d_oc);
+	tspws_spectral_destroy(p);
 	for (TlTable &T : p->tl) { if (T.d_sc) (void)hipFree(T.d_sc); if (T.d_items) (void)hipFree(T.d_items); }
 	if (p->d_sc) (void)hipFree(p->d_sc);
 	if (p->d_w) (void)hipFree(p->d_w);

@@ -1,0 +1,892 @@
+// spectral.hip -- the flop-reducing forward engine for MANY traces: the far-decimated octaves of the frame through the trace's
+// spectrum instead of per-scale FIR sums.
+//
+// The reference's decimating FIR (cdotx.c:35-72, driver wavelet_v7.c:43-64) is a CIRCULAR correlation sampled every D_s-th lag:
+//     Y_s[k] = conj( r_s[k D_s] ),   r_s[m] = sum_l x[(m - c_s + l) mod N] w_s[l].
+// With X = DFT_N(x) and H_s[f] = (1/N) sum_l w_s[l] e^{+2 pi i f (l - c_s) / N}:   r_s[m] = sum_f X[f] H_s[f] e^{+2 pi i f m / N}, and for
+// D_s | N (N_s = N / D_s) the samples m = k D_s only see the spectrum folded by N_s:
+//     r_s[k D_s] = sum_{q < N_s} G_s[q] e^{+2 pi i q k / N_s},     G_s[q] = sum_{j < D_s} X[q + j N_s] H_s[q + j N_s].
+// Exact (no band limit is assumed: the tables are the spectra of the clipped taps themselves), 4 FMAs per (frequency, scale) instead
+// of 2 L_s / D_s per coefficient: ~8 N flop per scale against 40 .. 76 N for the FIR, plus the transforms.
+//
+// MI355X mapping: everything here runs with lane = TRACE (like fwd_tl.h): the 64 lanes of a wave are 64 traces of a block, so
+//   * every operand that does not depend on the trace -- twiddles, the tables H_s -- is wave-uniform and comes through the SCALAR unit
+//     (s_load into SGPRs; the FMAs take it as their SGPR source), and there is no cross-lane traffic before the very end,
+//   * every load / store is one coalesced 1-KB row (a row = one frequency / sample of the block's 64 traces),
+//   * transforms are Stockham radix-2..32 passes in registers (k_spec_*: one butterfly per wave-item, out of place through HBM / MALL),
+//     the trace transform packs the real samples in pairs (N/2-point complex transform + split, half spectrum X[0 .. N/2]),
+//   * the multiply-and-fold (k_spec_fold) walks a residue class f = r (mod R) in bit-reversed order so that ONE live accumulator per
+//     scale suffices: a scale with D_s = 2^d completes a folded bin every 2^d steps; classes coarser than a scale's N_s leave partial
+//     sums that the first inverse pass adds,
+//   * the last inverse pass conjugates, phase-normalises (ts_pws1f_lib.c:489-492) and adds the 64 traces of the block on the VALU
+//     (lane_reduce.h) straight into the block's ST / PS planes -- per-trace coefficients of these scales never exist in memory.
+// The fine octaves (large N_s: per-coefficient FIR work is smallest there, per-trace spectra largest) stay on k_fwd_tl.
+// Reference citations are relative to /root/reference/src.
+#include "tspws_internal.h"
+#include "lane_reduce.h"
+#include "spectral.h"
+
+// ------------------------------------------------------------------------------------------
+// compile-time twiddles of the register transforms: cos / sin (2 pi k / 32)
+// ------------------------------------------------------------------------------------------
+namespace {
+constexpr double quarter32(int k)
+{ // cos(2 pi k / 32), 0 <= k <= 8
+	return k == 0 ? 1.0 : k == 1 ? 0.9807852804032304 : k == 2 ? 0.9238795325112867 : k == 3 ? 0.8314696123025452 : k == 4 ? 0.7071067811865476
+	     : k == 5 ? 0.5555702330196023 : k == 6 ? 0.38268343236508984 : k == 7 ? 0.19509032201612833 : 0.0;
+}
+constexpr double cos32(int k)
+{
+	k = ((k % 32) + 32) % 32;
+	return k <= 8 ? quarter32(k) : k <= 16 ? -quarter32(16 - k) : k <= 24 ? -quarter32(k - 16) : quarter32(32 - k);
+}
+constexpr double sin32(int k) { return cos32(k - 8); }
+
+__device__ __forceinline__ double2 cadd(const double2 a, const double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(const double2 a, const double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cmul(const double2 a, const double2 b) { return make_double2(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x)); }
+
+// R-point DFT in registers (decimation in time, all indices static): natural order in, natural order out.
+// INV: kernel e^{+2 pi i nk/R}, else e^{-2 pi i nk/R}; unnormalised.
+template <int R, bool INV, int K> struct SpecBfly {
+	static __device__ __forceinline__ void run(double2 (&v)[R], const double2 (&e)[R / 2], const double2 (&o)[R / 2])
+	{
+		constexpr double cs = cos32(K * (32 / R)), sn = INV ? sin32(K * (32 / R)) : -sin32(K * (32 / R));
+		double2 t;
+		if constexpr (K == 0) t = o[0];
+		else if constexpr (4 * K == R) t = INV ? make_double2(-o[K].y, o[K].x) : make_double2(o[K].y, -o[K].x);
+		else t = make_double2(fma(o[K].x, cs, -o[K].y * sn), fma(o[K].x, sn, o[K].y * cs));
+		v[K] = cadd(e[K], t);
+		v[K + R / 2] = csub(e[K], t);
+		if constexpr (K + 1 < R / 2) SpecBfly<R, INV, K + 1>::run(v, e, o);
+	}
+};
+template <int R, bool INV> struct SpecDFT {
+	static __device__ __forceinline__ void run(double2 (&v)[R])
+	{
+		constexpr int H = R / 2;
+		double2 e[H], o[H];
+#pragma unroll
+		for (int i = 0; i < H; i++) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+		SpecDFT<H, INV>::run(e);
+		SpecDFT<H, INV>::run(o);
+		SpecBfly<R, INV, 0>::run(v, e, o);
+	}
+};
+template <bool INV> struct SpecDFT<1, INV> { static __device__ __forceinline__ void run(double2 (&)[1]) {} };
+
+__device__ __forceinline__ const SpecSeg *spec_find_seg(const SpecSeg *__restrict__ segs, unsigned nseg, unsigned item)
+{
+	unsigned lo = 0, hi = nseg;
+	while (hi - lo > 1) {
+		const unsigned mid = (lo + hi) >> 1;
+		if (segs[mid].item0 <= item) lo = mid; else hi = mid;
+	}
+	return segs + lo;
+}
+
+// twiddle e^{-+ 2 pi i idx / N} from the table of the forward kernel (tw[i] = e^{-2 pi i i / N}); idx is wave-uniform
+template <bool INV>
+__device__ __forceinline__ double2 spec_tw(const double2 *__restrict__ tw, unsigned idx)
+{
+	const double2 t = tw[idx];
+	return INV ? make_double2(t.x, -t.y) : t;
+}
+} // namespace
+
+// ------------------------------------------------------------------------------------------
+// plan-time kernels: twiddle table, tap norms, the tables H_s
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_spec_twiddle(double2 *__restrict__ tw, unsigned N)
+{
+	const unsigned i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= N) return;
+	double s, c;
+	sincospi(-2.0 * (double)i / (double)N, &s, &c);
+	tw[i] = make_double2(c, s);
+}
+
+// ||w_s||_2 of every scale: one workgroup per scale
+__global__ void __launch_bounds__(256) k_spec_wnorm(const ScaleDesc *__restrict__ sc, const double2 *__restrict__ w, double *__restrict__ out)
+{
+	__shared__ double red[4];
+	const ScaleDesc d = sc[blockIdx.x];
+	double a = 0;
+	for (unsigned l = threadIdx.x; l < d.L; l += 256) { const double2 t = w[d.tap_off + l]; a = fma(t.x, t.x, fma(t.y, t.y, a)); }
+	a = wave_sum(a);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+	__syncthreads();
+	if (threadIdx.x == 0) out[blockIdx.x] = sqrt(red[0] + red[1] + red[2] + red[3]);
+}
+
+// h[blk][n][lane]: the taps of slot (blk, lane) placed circularly, tap l at n = (l - c) mod N (the buffer was zeroed)
+__global__ void __launch_bounds__(256) k_spec_place(const ScaleDesc *__restrict__ sc, const double2 *__restrict__ w, const unsigned *__restrict__ slot_scale,
+                                                    unsigned N, double2 *__restrict__ h)
+{
+	const unsigned slot = blockIdx.y, s = slot_scale[slot];
+	if (s == ~0u) return;
+	const ScaleDesc d = sc[s];
+	const unsigned l = blockIdx.x * 256 + threadIdx.x;
+	if (l >= d.L) return;
+	long long n = (long long)l - d.c;
+	n %= (long long)N; if (n < 0) n += N;
+	h[((size_t)(slot >> 6) * N + (size_t)n) * 64 + (slot & 63)] = w[d.tap_off + l];
+}
+
+// Htab[((g R + r) nsteps + c) NS + s] = Hfull[slot = g NS + s][f = r + R bitrev(c)] / N
+__global__ void __launch_bounds__(256) k_spec_permute(const double2 *__restrict__ hf, unsigned N, unsigned R, unsigned logsteps, unsigned NS, unsigned ngroups,
+                                                      double2 *__restrict__ tab)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	const size_t total = (size_t)ngroups * N * NS;
+	if (i >= total) return;
+	const unsigned s = (unsigned)(i % NS);
+	const size_t rc = i / NS;                 // (g R + r) nsteps + c
+	const unsigned nsteps = 1u << logsteps;
+	const unsigned c = (unsigned)(rc & (nsteps - 1));
+	const size_t gr = rc >> logsteps;
+	const unsigned r = (unsigned)(gr % R), g = (unsigned)(gr / R);
+	const unsigned ib = logsteps ? (__brev(c) >> (32 - logsteps)) : 0u;
+	const unsigned f = r + R * ib;
+	const unsigned slot = g * NS + s;
+	const double2 v = hf[((size_t)(slot >> 6) * N + f) * 64 + (slot & 63)];
+	const double inv = 1.0 / (double)N;
+	tab[i] = make_double2(v.x * inv, v.y * inv);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-call kernels
+// ------------------------------------------------------------------------------------------
+// largest |sample| of every trace of the transposed batch (the noise floor of the transforms scales with it): amax[t] as float bits
+template <typename TIn>
+__global__ void __launch_bounds__(256) k_spec_colmax(const TIn *__restrict__ xT, unsigned TP, unsigned N, unsigned rows_per_wave, unsigned *__restrict__ amax)
+{
+	const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const unsigned w = blockIdx.x * 4 + wv, tb = blockIdx.y;
+	const unsigned n0 = w * rows_per_wave;
+	if (n0 >= N) return;
+	const unsigned n1 = min(N, n0 + rows_per_wave);
+	const TIn *col = xT + (size_t)tb * 64 + lane;
+	float m = 0.f;
+	bool bad = false;
+	unsigned n = n0;
+	for (; n + 8 <= n1; n += 8) { // eight rows in flight
+		TIn v[8];
+#pragma unroll
+		for (int i = 0; i < 8; i++) v[i] = col[(size_t)(n + i) * TP];
+#pragma unroll
+		for (int i = 0; i < 8; i++) { const float a = fabsf((float)v[i]); bad |= !(a == a); m = fmaxf(m, a); }
+	}
+	for (; n < n1; n++) { const float a = fabsf((float)col[(size_t)n * TP]); bad |= !(a == a); m = fmaxf(m, a); }
+	if (bad) m = __int_as_float(0x7f800000); // NaN in the trace: everything is above the floor
+	atomicMax(amax + (size_t)tb * 64 + lane, __float_as_uint(m * 1.0000002f));
+}
+
+// ---- first pass of the trace transform: z[m] = x[2m] + i x[2m+1] from the transposed batch, L = 1 (no twiddles) -------------------
+template <typename TIn, int R>
+__device__ __forceinline__ void spec_fwd_first_body(const TIn *__restrict__ col, unsigned TP, double2 *__restrict__ dst, unsigned j, unsigned m)
+{
+	double2 v[R];
+#pragma unroll
+	for (int n = 0; n < R; n++) {
+		const size_t idx = (size_t)j + (size_t)n * m;
+		v[n] = make_double2((double)col[(2 * idx) * TP], (double)col[(2 * idx + 1) * TP]);
+	}
+	SpecDFT<R, false>::run(v);
+#pragma unroll
+	for (int n = 0; n < R; n++) dst[((size_t)j * R + n) * 64] = v[n];
+}
+
+template <typename TIn>
+__global__ void __launch_bounds__(256) k_spec_fwd_first(const TIn *__restrict__ xT, unsigned TP, double2 *__restrict__ dst, size_t dst_rows, unsigned M, unsigned radix)
+{
+	const unsigned lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const unsigned m = M / radix;
+	const unsigned j = blockIdx.x * 4 + wv, tb = blockIdx.y;
+	if (j >= m) return;
+	const TIn *col = xT + (size_t)tb * 64 + lane;
+	double2 *d = dst + (size_t)tb * dst_rows * 64 + lane;
+	switch (radix) {
+	case 32: spec_fwd_first_body<TIn, 32>(col, TP, d, j, m); break;
+	case 16: spec_fwd_first_body<TIn, 16>(col, TP, d, j, m); break;
+	default: spec_fwd_first_body<TIn, 8>(col, TP, d, j, m); break;
+	}
+}
+
+// ---- generic Stockham pass: out[j0 + n L] = DFT_R( tw_n in[j + n len/R] ), k = j mod L, j0 = (j - k) R + k ---------------------------
+template <int R, bool INV>
+__device__ __forceinline__ void spec_load_tw(double2 (&v)[R], const double2 *__restrict__ src, const SpecSeg *__restrict__ sg, unsigned j, unsigned k,
+                                             const double2 *__restrict__ tw)
+{
+	const unsigned m = sg->len / R, nfold = sg->nfold;
+#pragma unroll
+	for (int n = 0; n < R; n++) v[n] = src[((size_t)j + (size_t)n * m) * 64];
+	for (unsigned p = 1; p < nfold; p++) { // partial folds of a coarse scale (first inverse pass): entry q = sum of the rows q + p len -- R loads in flight per round
+		double2 a[R];
+#pragma unroll
+		for (int n = 0; n < R; n++) a[n] = src[((size_t)j + (size_t)n * m + (size_t)p * sg->len) * 64];
+#pragma unroll
+		for (int n = 0; n < R; n++) v[n] = cadd(v[n], a[n]);
+	}
+	if (k) {
+#pragma unroll
+		for (int n = 1; n < R; n++) v[n] = cmul(v[n], spec_tw<INV>(tw, (unsigned)n * k * sg->tw_mul));
+	}
+}
+
+template <int R, bool INV>
+__device__ __forceinline__ void spec_mid_body(const double2 *__restrict__ src, double2 *__restrict__ dst, const SpecSeg *__restrict__ sg, unsigned j,
+                                              const double2 *__restrict__ tw)
+{
+	const unsigned L = sg->L, k = j & (L - 1);
+	double2 v[R];
+	spec_load_tw<R, INV>(v, src, sg, j, k, tw);
+	SpecDFT<R, INV>::run(v);
+	const size_t j0 = (size_t)(j - k) * R + k;
+#pragma unroll
+	for (int n = 0; n < R; n++) dst[(j0 + (size_t)n * L) * 64] = v[n];
+}
+
+template <bool INV>
+__global__ void __launch_bounds__(256) k_spec_mid(const SpecSeg *__restrict__ segs, unsigned nseg, unsigned nitems, const double2 *__restrict__ src, size_t src_rows,
+                                                  double2 *__restrict__ dst, size_t dst_rows, const double2 *__restrict__ tw)
+{
+	const unsigned lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const unsigned item = blockIdx.x * 4 + wv, tb = blockIdx.y;
+	if (item >= nitems) return;
+	const SpecSeg *sg = spec_find_seg(segs, nseg, item);
+	const unsigned j = item - sg->item0;
+	const double2 *s = src + ((size_t)tb * src_rows + sg->src) * 64 + lane;
+	double2 *d = dst + ((size_t)tb * dst_rows + sg->dst) * 64 + lane;
+	switch (sg->radix) {
+	case 32: spec_mid_body<32, INV>(s, d, sg, j, tw); break;
+	case 16: spec_mid_body<16, INV>(s, d, sg, j, tw); break;
+	case 8: spec_mid_body<8, INV>(s, d, sg, j, tw); break;
+	case 4: spec_mid_body<4, INV>(s, d, sg, j, tw); break;
+	default: spec_mid_body<2, INV>(s, d, sg, j, tw); break;
+	}
+}
+
+// ---- last pass of the trace transform: butterflies k and L - k together, split of the packed pairs, half spectrum X[0 .. M] ---------
+//   X[f] = 1/2 ( (Z[f] + conj Z[M - f]) - i e^{-2 pi i f / N} (Z[f] - conj Z[M - f]) )
+template <int R>
+__device__ __forceinline__ void spec_fwd_last_body(const double2 *__restrict__ src, double2 *__restrict__ dst, unsigned M, unsigned k, const double2 *__restrict__ tw)
+{
+	const unsigned L = M / R, kb = (L - k) & (L - 1);
+	double2 za[R], zb[R];
+#pragma unroll
+	for (int n = 0; n < R; n++) { za[n] = src[((size_t)k + (size_t)n * L) * 64]; zb[n] = src[((size_t)kb + (size_t)n * L) * 64]; }
+	if (k) {
+#pragma unroll
+		for (int n = 1; n < R; n++) { za[n] = cmul(za[n], tw[2u * (unsigned)n * k]); zb[n] = cmul(zb[n], tw[2u * (unsigned)n * kb]); } // e^{-2 pi i n k / M}
+	}
+	SpecDFT<R, false>::run(za);
+	SpecDFT<R, false>::run(zb);
+	auto split = [&](const double2 zf, const double2 zm, const unsigned f) { // zm = Z[M - f] (not conjugated yet)
+		const double2 e = make_double2(zf.x + zm.x, zf.y - zm.y), o = make_double2(zf.x - zm.x, zf.y + zm.y); // Z[f] +- conj Z[M-f]
+		const double2 w = tw[f];                                                                              // e^{-2 pi i f / N}
+		// -i w o = (w.y o.x + w.x o.y) - i (w.x o.x - w.y o.y)
+		const double2 t = make_double2(fma(w.y, o.x, w.x * o.y), -fma(w.x, o.x, -w.y * o.y));
+		dst[(size_t)f * 64] = make_double2(0.5 * (e.x + t.x), 0.5 * (e.y + t.y));
+	};
+	if (k) {
+#pragma unroll
+		for (int n = 0; n < R; n++) {
+			split(za[n], zb[R - 1 - n], k + (unsigned)n * L);
+			split(zb[n], za[R - 1 - n], kb + (unsigned)n * L);
+		}
+	} else { // f = n L: the partner M - f = (R - n) L is in the same butterfly; f = M closes the half spectrum
+#pragma unroll
+		for (int n = 0; n < R; n++) split(za[n], za[(R - n) % R], (unsigned)n * L);
+		dst[(size_t)M * 64] = make_double2(za[0].x - za[0].y, 0.0);
+	}
+}
+
+__global__ void __launch_bounds__(256) k_spec_fwd_last(const double2 *__restrict__ src, size_t src_rows, double2 *__restrict__ dst, size_t dst_rows, unsigned M,
+                                                       unsigned radix, const double2 *__restrict__ tw)
+{
+	const unsigned lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const unsigned L = M / radix;
+	const unsigned k = blockIdx.x * 4 + wv, tb = blockIdx.y;
+	if (k > L / 2) return;
+	const double2 *s = src + (size_t)tb * src_rows * 64 + lane;
+	double2 *d = dst + (size_t)tb * dst_rows * 64 + lane;
+	switch (radix) {
+	case 16: spec_fwd_last_body<16>(s, d, M, k, tw); break;
+	case 8: spec_fwd_last_body<8>(s, d, M, k, tw); break;
+	case 4: spec_fwd_last_body<4>(s, d, M, k, tw); break;
+	default: spec_fwd_last_body<2>(s, d, M, k, tw); break;
+	}
+}
+
+// ---- multiply-and-fold ---------------------------------------------------------------------------------------------------------------
+// workgroup = ONE class r: its WG scale groups x WT sets of NTB trace blocks (a wave = one group, one set).  Steps c = 0 .. nsteps-1 over
+// f = r + R bitrev(c).  Slot s of the group (scales in the order of growing D, partial ones last) adds X[f] H_s[f]; it completes bin
+// q = r + R bitrev(c >> d_s) whenever (c + 1) % 2^{d_s} == 0.
+//
+// The table values H_s[f] are the same for every lane.  Three ways to bring them to the FMAs were measured on 1024 x 32768 (cfg2):
+//   * scalar loads (SGPR operands): two SGPR sets of 8 values + everything else do not fit 102 SGPRs -- the compiler spills the freshly
+//     loaded set through v_writelane / v_readlane (two VALU instructions per FMA pair) and waits for every request on the spot: 380-430 us;
+//   * vector loads of one address: the 64 lanes' copies come back over the 64 B/clk L1 return path like any 1-KB load: slower still;
+//   * THIS: the class's table stream is staged into LDS by global_load_lds (1 KB per instruction, a ring of SP_RB blocks: requests run
+//     thousands of cycles ahead, in order) and read as broadcast ds_read_b128 (4 LDS cycles per wave-instruction; with two trace blocks
+//     per wave a value feeds 8 FMAs, so the LDS pipe is at ~50 %); no SGPR pressure, no VALU overhead.
+#define SP_RB 4 /* ring blocks of 1 KB per scale group */
+template <int NS, int NTB>
+__global__ void __launch_bounds__(512) k_spec_fold(const double2 *__restrict__ Xh, size_t xrows, const double2 *__restrict__ tab, const SpecSlot *__restrict__ slots,
+                                                   unsigned R, unsigned logsteps, unsigned N, unsigned nblk, unsigned WG, double2 *__restrict__ G, size_t grows, unsigned abl)
+{
+	static_assert(NS == 8 || NS == 16, "a 1-KB block of the table stream holds a whole number of steps");
+	constexpr unsigned SPL = 64 / NS;               // steps per 1-KB block
+	extern __shared__ __attribute__((aligned(16))) char smem[]; // [WG][SP_RB][64] double2
+	typedef __attribute__((address_space(3))) void lds_void;
+	typedef __attribute__((address_space(1))) const void glb_void;
+	const unsigned lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const unsigned r = blockIdx.x, g = wv % WG, ts = wv / WG, WT = (blockDim.x >> 6) / WG;
+	const unsigned nsets = (nblk + NTB - 1) / NTB;
+	unsigned tbs = blockIdx.y * WT + ts;
+	if (tbs >= nsets) tbs = nsets - 1;              // (a spare wave repeats the last set: same values to the same places -- it must keep the barriers)
+	const unsigned item = g * R + r;
+	const unsigned nsteps = 1u << logsteps, M = N >> 1;
+	const double2 *__restrict__ hp = tab + (size_t)item * nsteps * NS; // this group's table stream of the class: step c, slot s at hp[c NS + s]
+	const SpecSlot *__restrict__ sl = slots + (size_t)g * NS;
+	const double2 *xc[NTB];
+	double2 *gc[NTB];
+#pragma unroll
+	for (int b = 0; b < NTB; b++) {
+		const unsigned tb = (NTB * tbs + b < nblk) ? NTB * tbs + b : NTB * tbs; // (block count not a multiple of NTB: the last wave does a block twice)
+		xc[b] = Xh + (size_t)tb * xrows * 64 + lane;
+		gc[b] = G + (size_t)tb * grows * 64 + lane;
+	}
+	double2 acc[NTB][NS];
+#pragma unroll
+	for (int b = 0; b < NTB; b++)
+#pragma unroll
+		for (int s = 0; s < NS; s++) acc[b][s] = make_double2(0.0, 0.0);
+	const unsigned mask0 = (1u << sl[0].ld) - 1u;   // the finest scale of the group: nothing completes before it does
+	auto xrow = [&](const unsigned c, bool &cj) -> size_t {
+		const unsigned ib = logsteps ? (__brev(c) >> (32 - logsteps)) : 0u;
+		const unsigned f = r + R * ib;
+		cj = f > M;
+		if (abl & 1u) return (size_t)((c & 7u) * 64); // ABLATION: eight hot rows instead of the class's rows
+		return (size_t)(cj ? N - f : f) * 64;
+	};
+	// table ring of this group: block k (steps k SPL ..) in slot k % SP_RB; the set-0 wave of the group loads it
+	char *ringb = smem + (size_t)g * SP_RB * 1024;
+	const bool loader = ts == 0;
+	const unsigned nblocks = nsteps / SPL;           // (nsteps >= 16 >= SPL)
+	auto request = [&](const unsigned k) {           // block k -> its ring slot (one wave-instruction: 64 lanes x 16 B)
+		__builtin_amdgcn_global_load_lds((glb_void *)(hp + (size_t)k * 64 + lane), (lds_void *)(ringb + (size_t)(k % SP_RB) * 1024), 16, 0, 0);
+	};
+	if (loader) {
+#pragma unroll
+		for (unsigned k = 0; k < SP_RB - 1; k++) if (k < nblocks) request(k);
+	}
+	constexpr int XU = 2;                            // rows of the spectra in flight: the next XU steps travel while these are computed
+	double2 xa[XU][NTB], xb[XU][NTB];
+	bool ca[XU], cb[XU];
+#pragma unroll
+	for (int u = 0; u < XU; u++) {
+		const size_t o = xrow((unsigned)u, ca[u]);
+#pragma unroll
+		for (int b = 0; b < NTB; b++) xa[u][b] = xc[b][o];
+	}
+	for (unsigned k = 0; k < nblocks; k++) {
+		// block k has landed (the loader waits for its own request -- older than every row it has asked for since) and everybody is done
+		// with block k - 1, whose slot the next request overwrites
+		if (loader && !(abl & 4u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		if (!(abl & 8u)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+		if (loader && k + SP_RB - 1 < nblocks) request(k + SP_RB - 1);
+		const double2 *__restrict__ hb = (const double2 *)(ringb + (size_t)(k % SP_RB) * 1024);
+		// the block's 64 table values in chunks of 8: chunk i + 1 is requested from LDS BEFORE the FMAs of chunk i (two register sets;
+		// the scheduling barriers keep the compiler from sinking the request to its use)
+		constexpr int CPS = NS / 8, NCB = 8;          // chunks per step, chunks per block
+		double2 hq[2][8];
+#pragma unroll
+		for (int i = 0; i < 8; i++) hq[0][i] = hb[i]; // same address in every lane: broadcast
+#pragma unroll
+		for (int ci = 0; ci < NCB; ci++) {
+			const int c1 = ci / CPS, ch = ci % CPS, u = c1 % XU;
+			const unsigned c = k * SPL + (unsigned)c1;
+			if (ch == 0 && u == 0 && c + XU < nsteps) { // the rows of the next XU steps
+#pragma unroll
+				for (int uu = 0; uu < XU; uu++) {
+					const size_t o = xrow(c + XU + (unsigned)uu, cb[uu]);
+#pragma unroll
+					for (int b = 0; b < NTB; b++) xb[uu][b] = xc[b][o];
+				}
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			if (ci + 1 < NCB) {
+#pragma unroll
+				for (int i = 0; i < 8; i++) hq[(ci + 1) & 1][i] = hb[(ci + 1) * 8 + i];
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			double xr[NTB], xi[NTB];
+#pragma unroll
+			for (int b = 0; b < NTB; b++) { xr[b] = xa[u][b].x; xi[b] = ca[u] ? -xa[u][b].y : xa[u][b].y; }
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				const double2 hv = hq[ci & 1][i];
+				const int s = ch * 8 + i;
+#pragma unroll
+				for (int b = 0; b < NTB; b++) {
+					acc[b][s].x = fma(xr[b], hv.x, acc[b][s].x);
+					acc[b][s].y = fma(xr[b], hv.y, acc[b][s].y);
+				}
+#pragma unroll
+				for (int b = 0; b < NTB; b++) {
+					acc[b][s].x = fma(-xi[b], hv.y, acc[b][s].x);
+					acc[b][s].y = fma(xi[b], hv.x, acc[b][s].y);
+				}
+			}
+			if (ch == CPS - 1) { // end of step c
+				if (((c + 1) & mask0) == 0) {
+#pragma unroll
+					for (int s = 0; s < NS; s++) {
+						const unsigned ld = sl[s].ld;
+						if (((c + 1) & ((1u << ld) - 1u)) != 0) break; // (partial slots carry ld = 31)
+						const unsigned lb = sl[s].lb;
+						const unsigned ilo = lb ? (__brev(c >> ld) >> (32 - lb)) : 0u;
+						const size_t o = (sl[s].goff + r + (size_t)R * ilo) * 64;
+#pragma unroll
+						for (int b = 0; b < NTB; b++) { if (!(abl & 2u)) gc[b][o] = acc[b][s]; acc[b][s] = make_double2(0.0, 0.0); }
+					}
+				}
+				if (u == XU - 1) {
+#pragma unroll
+					for (int uu = 0; uu < XU; uu++) {
+						ca[uu] = cb[uu];
+#pragma unroll
+						for (int b = 0; b < NTB; b++) xa[uu][b] = xb[uu][b];
+					}
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int s = 0; s < NS; s++)
+		if (sl[s].ld == 31u && sl[s].lb != 31u) { // partial sums of the classes (lb == 31: an idle pad slot)
+			const size_t o = (sl[s].goff + r) * 64;
+#pragma unroll
+			for (int b = 0; b < NTB; b++) gc[b][o] = acc[b][s];
+		}
+}
+
+// ---- inverse transforms of the folded spectra + stacks -----------------------------------------------------------------------------
+// A segment = one pass of one scale.  Passes before the last write the other ping-pong buffer; the last pass conjugates
+// (Y = conj r), phase-normalises and adds the block's 64 traces into the block's ST / PS planes (COEF: writes the traces' own
+// coefficients instead -- the per-trace API and the parity tests).
+struct SpecEpi {
+	double2 *ST, *PS;          // planes of trace block 0; block tb at + tb * stride
+	size_t stride;
+	const unsigned *amax;      // float bits of max |x| per trace (lane)
+	double2 *Y;                // COEF: [trace][ncoef]
+	size_t ncoef;
+	unsigned ntr;
+};
+
+template <int R, bool COEF>
+__device__ __forceinline__ void spec_inv_last_body(const double2 *__restrict__ src, const SpecSeg *__restrict__ sg, unsigned j, const double2 *__restrict__ tw,
+                                                   const SpecEpi &ep, unsigned tb, unsigned lane)
+{
+	const unsigned L = sg->L, k = j & (L - 1);
+	double2 v[R];
+	spec_load_tw<R, true>(v, src, sg, j, k, tw);
+	SpecDFT<R, true>::run(v);
+	const size_t j0 = (size_t)(j - k) * R + k;
+	const unsigned t = tb * 64 + lane;
+	if constexpr (COEF) {
+		if (t < ep.ntr) {
+			double2 *y = ep.Y + (size_t)t * ep.ncoef + sg->coff;
+#pragma unroll
+			for (int n = 0; n < R; n++) y[j0 + (size_t)n * L] = make_double2(v[n].x, -v[n].y);
+		}
+		return;
+	}
+	// noise floor of the transforms for this (trace, scale): a coefficient at or below it is an exact zero of the FIR form (all samples
+	// under the filter are zero) and is skipped by the phase stack like the reference's 0 / 0 (ts_pws1f_lib.c:491-492)
+	const double fl = sg->tau * (double)__uint_as_float(ep.amax[t]);
+	const double fl2 = fl * fl;
+	const unsigned o16 = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1); // element left by valu_reduce16
+	double2 *pS = ep.ST + (size_t)tb * ep.stride + sg->coff, *pP = ep.PS + (size_t)tb * ep.stride + sg->coff;
+	constexpr int NCH = (R + 7) / 8;
+#pragma unroll
+	for (int ch = 0; ch < NCH; ch++) {
+		double st16[16], ps16[16];
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			const int n = ch * 8 + i;
+			double2 y = make_double2(0.0, 0.0), u = make_double2(0.0, 0.0);
+			if (n < R) {
+				y = make_double2(v[n < R ? n : 0].x, -v[n < R ? n : 0].y);
+				const double r2 = fma(y.x, y.x, y.y * y.y);
+				if (r2 > fl2) add_unit_phasor(u, y);
+			}
+			st16[2 * i] = y.x; st16[2 * i + 1] = y.y;
+			ps16[2 * i] = u.x; ps16[2 * i + 1] = u.y;
+		}
+		const double sm = valu_reduce16(st16, lane), q = valu_reduce16(ps16, lane);
+		const int n = ch * 8 + (int)(o16 >> 1);
+		if ((lane & 3) == 0 && n < R) {
+			const size_t kk = j0 + (size_t)n * L;
+			((double *)(pS + kk))[o16 & 1] = sm;
+			((double *)(pP + kk))[o16 & 1] = q;
+		}
+	}
+}
+
+template <bool COEF>
+__global__ void __launch_bounds__(256) k_spec_inv(const SpecSeg *__restrict__ segs, unsigned nseg, unsigned nitems, const double2 *__restrict__ src, size_t src_rows,
+                                                  double2 *__restrict__ dst, size_t dst_rows, const double2 *__restrict__ tw, const SpecEpi ep)
+{
+	const unsigned lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const unsigned item = blockIdx.x * 4 + wv, tb = blockIdx.y;
+	if (item >= nitems) return;
+	const SpecSeg *sg = spec_find_seg(segs, nseg, item);
+	const unsigned j = item - sg->item0;
+	const double2 *s = src + ((size_t)tb * src_rows + sg->src) * 64 + lane;
+	if (sg->last) {
+		switch (sg->radix) {
+		case 16: spec_inv_last_body<16, COEF>(s, sg, j, tw, ep, tb, lane); break;
+		case 8: spec_inv_last_body<8, COEF>(s, sg, j, tw, ep, tb, lane); break;
+		case 4: spec_inv_last_body<4, COEF>(s, sg, j, tw, ep, tb, lane); break;
+		default: spec_inv_last_body<2, COEF>(s, sg, j, tw, ep, tb, lane); break;
+		}
+		return;
+	}
+	double2 *d = dst + ((size_t)tb * dst_rows + sg->dst) * 64 + lane;
+	switch (sg->radix) {
+	case 32: spec_mid_body<32, true>(s, d, sg, j, tw); break;
+	case 16: spec_mid_body<16, true>(s, d, sg, j, tw); break;
+	case 8: spec_mid_body<8, true>(s, d, sg, j, tw); break;
+	case 4: spec_mid_body<4, true>(s, d, sg, j, tw); break;
+	default: spec_mid_body<2, true>(s, d, sg, j, tw); break;
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static unsigned ilog2u(unsigned v) { unsigned l = 0; while ((1u << l) < v) l++; return l; }
+
+// radices (as bit counts) of a 2^m-point transform: as few passes as possible with <= 5 bits each, the LAST pass <= last_max bits
+static std::vector<unsigned> radix_bits(unsigned m, unsigned last_max)
+{
+	std::vector<unsigned> b;
+	if (!m) return b;
+	for (unsigned np = (m + 4) / 5;; np++) {
+		const unsigned base = m / np, extra = m % np;
+		if (base > last_max || base + (extra ? 1u : 0u) > 5u) continue;
+		for (unsigned i = 0; i < np; i++) b.push_back(base + (i < extra ? 1u : 0u));
+		return b;
+	}
+}
+
+struct SpecPlan {
+	unsigned s_first = 0;                 // scales [s_first, S) are spectral
+	unsigned N = 0, M = 0, R = 0, logsteps = 0, NS = 0, ngroups = 0;
+	size_t grows = 0;                     // rows of a trace block's folded spectra (all slots)
+	std::vector<unsigned> fwd_bits;       // passes of the trace transform
+	double2 *d_tw = nullptr, *d_tab = nullptr;
+	SpecSlot *d_slots = nullptr;
+	SpecSeg *d_fseg = nullptr;            // middle passes of the trace transform (one segment each)
+	std::vector<SpecSeg *> d_iseg;        // inverse levels
+	std::vector<unsigned> iseg_n, iseg_items;
+};
+
+void tspws_spectral_destroy(tspws_hip_plan *p)
+{
+	for (SpecDecomp *d : p->spec) {
+		if (!d) continue;
+		if (SpecPlan *sp = d->sp) {
+			if (sp->d_tw) (void)hipFree(sp->d_tw);
+			if (sp->d_tab) (void)hipFree(sp->d_tab);
+			if (sp->d_slots) (void)hipFree(sp->d_slots);
+			if (sp->d_fseg) (void)hipFree(sp->d_fseg);
+			for (SpecSeg *s : sp->d_iseg) if (s) (void)hipFree(s);
+			delete sp;
+		}
+		if (d->T.d_sc) (void)hipFree(d->T.d_sc);
+		if (d->T.d_items) (void)hipFree(d->T.d_items);
+		delete d;
+	}
+	p->spec.clear();
+}
+
+// Can scale s go through the spectrum?  N a power of two >= 1024, D a power of two that divides N, at least two outputs.
+static bool spec_scale_ok(const tspws_hip_plan *p, unsigned s)
+{
+	const unsigned N = p->N, D = p->sc[s].D;
+	return N >= 1024 && (N & (N - 1)) == 0 && D >= 2 && (D & (D - 1)) == 0 && N % D == 0 && p->sc[s].Ns == N / D && p->sc[s].Ns >= 2 && p->sc[s].L <= N;
+}
+
+// first scale of the spectral set when every octave with at most nsmax outputs is to go through the spectrum (S: none).
+// The set is a run at the coarse end of the frame: whole octaves, D strictly growing from octave to octave.
+unsigned tspws_spectral_first_scale(const tspws_hip_plan *p, unsigned nsmax)
+{
+	unsigned first = p->S;
+	for (unsigned e = p->S; e > 0;) {
+		unsigned s = e - 1;
+		while (s > 0 && p->sc[s - 1].D == p->sc[e - 1].D && p->sc[s - 1].Ns == p->sc[e - 1].Ns) s--;
+		bool ok = p->sc[s].Ns <= nsmax && p->S - s <= 128; // (at most 8 groups of 16 accumulators)
+		for (unsigned v = s; v < e && ok; v++) ok = spec_scale_ok(p, v);
+		if (ok && e < p->S && p->sc[e].D != 2 * p->sc[s].D) ok = false; // consecutive octaves double the decimation
+		if (!ok) break;
+		first = s;
+		e = s;
+	}
+	return first;
+}
+
+static int spec_build(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, SpecPlan **out)
+{
+	SpecPlan *sp = new SpecPlan;
+	*out = sp;
+	const unsigned N = p->N, M = N / 2, S = p->S, nsc = S - s_first;
+	sp->s_first = s_first; sp->N = N; sp->M = M;
+	// scale groups: groups of at most 16 scales (a wave's accumulators for two trace blocks: 128 VGPRs), padded to 8 or 16 slots (a 1-KB
+	// block of a group's table stream holds 8 or 4 steps); the groups of a class share a workgroup (k_spec_fold)
+	if (nsc > 128) return fail(TSPWS_E_ARG, "spectral: more than 128 scales in the spectral set");
+	unsigned nsw = 16;
+	if (const char *e = getenv("TSPWS_SPEC_NSW")) nsw = atoi(e) <= 8 ? 8u : 16u; // sweeps
+	if (nsc > 8 * nsw) nsw = 16;
+	const unsigned ngroups = (nsc + nsw - 1) / nsw;
+	const unsigned per = (nsc + ngroups - 1) / ngroups, NS = per <= 8 ? 8u : 16u;
+	sp->ngroups = ngroups; sp->NS = NS;
+	// classes: enough waves for the chip (>= ~4096 items with the caller's trace blocks), at least 16 steps per wave, at most N / 4 .. and
+	// not more classes than the finest spectral scale has outputs would be wasteful but is legal (partial sums)
+	unsigned R = 64;
+	while ((size_t)R * ngroups * std::max(1u, nblk_hint) < 4096 && N / (2 * R) >= 32) R *= 2;
+	sp->R = R; sp->logsteps = ilog2u(N / R);
+	// slots of a group in the order of the scales (D grows), partial ones (N_s < R) last by construction; pads are idle
+	std::vector<SpecSlot> slots((size_t)ngroups * NS);
+	std::vector<unsigned> slot_scale((size_t)ngroups * NS, ~0u);
+	std::vector<size_t> goff(S, 0);
+	size_t rows = 0;
+	for (unsigned g = 0; g < ngroups; g++) {
+		for (unsigned i = 0; i < NS; i++) {
+			SpecSlot &sl = slots[(size_t)g * NS + i];
+			const unsigned s = s_first + g * per + i;
+			if (i < per && s < S) {
+				const unsigned D = p->sc[s].D, Ns = p->sc[s].Ns;
+				slot_scale[(size_t)g * NS + i] = s;
+				goff[s] = rows;
+				sl.goff = rows;
+				if (Ns >= R) { sl.ld = ilog2u(D); sl.lb = ilog2u(Ns / R); rows += Ns; }
+				else { sl.ld = 31; sl.lb = 0; rows += R; }
+			} else { sl.ld = 31; sl.lb = 31; sl.goff = 0; }
+		}
+		// a group whose FIRST slot is partial never completes anything inside the loop: mask0 must not fire -- ld = 31 gives mask 2^31 - 1
+	}
+	sp->grows = rows;
+	HIP_TRY(hipMalloc(&sp->d_slots, slots.size() * sizeof(SpecSlot)));
+	HIP_TRY(hipMemcpy(sp->d_slots, slots.data(), slots.size() * sizeof(SpecSlot), hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc(&sp->d_tw, (size_t)N * sizeof(double2)));
+	hipLaunchKernelGGL(k_spec_twiddle, dim3((N + 255) / 256), dim3(256), 0, 0, sp->d_tw, N);
+	// ---- trace transform: M = N / 2 complex points, last pass <= 16 (it holds two butterflies) ----
+	sp->fwd_bits = radix_bits(ilog2u(M), 4);
+	{
+		std::vector<SpecSeg> fs;
+		unsigned L = 1;
+		for (size_t i = 0; i < sp->fwd_bits.size(); i++) {
+			const unsigned Rr = 1u << sp->fwd_bits[i];
+			SpecSeg g;
+			memset(&g, 0, sizeof g);
+			g.len = M; g.L = L; g.radix = Rr; g.nfold = 1; g.tw_mul = N / (L * Rr);
+			fs.push_back(g);
+			L *= Rr;
+		}
+		HIP_TRY(hipMalloc(&sp->d_fseg, fs.size() * sizeof(SpecSeg)));
+		HIP_TRY(hipMemcpy(sp->d_fseg, fs.data(), fs.size() * sizeof(SpecSeg), hipMemcpyHostToDevice));
+	}
+	// ---- tap norms (noise floor of a scale) ----
+	std::vector<double> wn(S, 0.0);
+	{
+		double *d_wn = nullptr;
+		HIP_TRY(hipMalloc(&d_wn, S * sizeof(double)));
+		hipLaunchKernelGGL(k_spec_wnorm, dim3(S), dim3(256), 0, 0, (const ScaleDesc *)p->d_sc, (const double2 *)p->d_w, d_wn);
+		HIP_TRY(hipMemcpy(wn.data(), d_wn, S * sizeof(double), hipMemcpyDeviceToHost));
+		(void)hipFree(d_wn);
+	}
+	// ---- inverse transforms: level l = pass l of every scale with more than l passes ----
+	{
+		std::vector<std::vector<SpecSeg>> lev;
+		for (unsigned s = s_first; s < S; s++) {
+			const unsigned Ns = p->sc[s].Ns;
+			const std::vector<unsigned> bits = radix_bits(ilog2u(Ns), 4); // (last pass <= 16 points: its epilogue holds the normalised copies too)
+			unsigned L = 1;
+			for (size_t i = 0; i < bits.size(); i++) {
+				if (lev.size() <= i) lev.emplace_back();
+				const unsigned Rr = 1u << bits[i];
+				SpecSeg g;
+				memset(&g, 0, sizeof g);
+				g.len = Ns; g.L = L; g.radix = Rr; g.tw_mul = N / (L * Rr);
+				g.nfold = (i == 0 && Ns < R) ? R / Ns : 1u;
+				g.src = g.dst = goff[s];
+				g.last = (i + 1 == bits.size()) ? 1u : 0u;
+				g.coff = p->sc[s].coef_off;
+				// |error| of an output of the FFT-based correlation <~ eps log2(N) ||x||_2 ||w||_2 <= eps log2(N) sqrt(N) max|x| ||w||_2; x 8
+				g.tau = 8.0 * 1.1102230246251565e-16 * (double)ilog2u(N) * sqrt((double)N) * wn[s];
+				lev[i].push_back(g);
+				L *= Rr;
+			}
+		}
+		for (std::vector<SpecSeg> &v : lev) {
+			unsigned items = 0;
+			for (SpecSeg &g : v) { g.item0 = items; items += g.len / g.radix; }
+			SpecSeg *d = nullptr;
+			HIP_TRY(hipMalloc(&d, v.size() * sizeof(SpecSeg)));
+			HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(SpecSeg), hipMemcpyHostToDevice));
+			sp->d_iseg.push_back(d); sp->iseg_n.push_back((unsigned)v.size()); sp->iseg_items.push_back(items);
+		}
+	}
+	// ---- tables H_s: taps placed circularly -> N-point transform with lane = slot -> class / step order, 1 / N ----
+	{
+		const unsigned nslots = ngroups * NS, nsb = (nslots + 63) / 64;
+		unsigned *d_ss = nullptr;
+		double2 *a = nullptr, *b = nullptr;
+		const size_t bytes = (size_t)nsb * N * 64 * sizeof(double2);
+		HIP_TRY(hipMalloc(&d_ss, slot_scale.size() * sizeof(unsigned)));
+		HIP_TRY(hipMemcpy(d_ss, slot_scale.data(), slot_scale.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+		HIP_TRY(hipMalloc(&a, bytes));
+		HIP_TRY(hipMalloc(&b, bytes));
+		HIP_TRY(hipMemset(a, 0, bytes));
+		hipLaunchKernelGGL(k_spec_place, dim3((N + 255) / 256, nslots), dim3(256), 0, 0, (const ScaleDesc *)p->d_sc, (const double2 *)p->d_w, (const unsigned *)d_ss, N, a);
+		const std::vector<unsigned> bits = radix_bits(ilog2u(N), 5);
+		std::vector<SpecSeg> ts;
+		unsigned L = 1;
+		for (unsigned bt : bits) {
+			SpecSeg g;
+			memset(&g, 0, sizeof g);
+			g.len = N; g.L = L; g.radix = 1u << bt; g.nfold = 1; g.tw_mul = N / (L * g.radix);
+			ts.push_back(g);
+			L *= g.radix;
+		}
+		SpecSeg *d_ts = nullptr;
+		HIP_TRY(hipMalloc(&d_ts, ts.size() * sizeof(SpecSeg)));
+		HIP_TRY(hipMemcpy(d_ts, ts.data(), ts.size() * sizeof(SpecSeg), hipMemcpyHostToDevice));
+		for (size_t i = 0; i < ts.size(); i++) {
+			const unsigned items = N / ts[i].radix;
+			hipLaunchKernelGGL((k_spec_mid<true>), dim3((items + 3) / 4, nsb), dim3(256), 0, 0, (const SpecSeg *)(d_ts + i), 1u, items, (const double2 *)a, (size_t)N, b,
+			                   (size_t)N, (const double2 *)sp->d_tw);
+			std::swap(a, b);
+		}
+		const size_t total = (size_t)ngroups * N * NS;
+		HIP_TRY(hipMalloc(&sp->d_tab, (total + 8) * sizeof(double2)));
+		HIP_TRY(hipMemset(sp->d_tab + total, 0, 8 * sizeof(double2)));
+		hipLaunchKernelGGL(k_spec_permute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, (const double2 *)a, N, R, sp->logsteps, NS, ngroups, sp->d_tab);
+		HIP_TRY(hipDeviceSynchronize());
+		(void)hipFree(a); (void)hipFree(b); (void)hipFree(d_ts); (void)hipFree(d_ss);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// The decomposition of a many-trace batch with the scales [s_first, S) on the spectral engine (built on first use, kept by the plan).
+int tspws_spectral_decomp(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, SpecDecomp **out)
+{
+	for (SpecDecomp *d : p->spec) if (d->s_first == s_first) { *out = d; return 0; }
+	SpecDecomp *d = new SpecDecomp;
+	d->s_first = s_first;
+	p->spec.push_back(d);
+	if (int rc = spec_build(p, s_first, nblk_hint, &d->sp)) return rc;
+	if (int rc = tspws_build_tl_spectral(p, s_first, d->T)) return rc;
+	*out = d;
+	return 0;
+}
+
+// Everything between the transposed batch and the planes of the spectral scales.  xT: [N][TP] (TP = nblk 64, pad lanes zero);
+// planes of block tb at ST / PS + tb * stride; Y != NULL: per-trace coefficients [ntr][ncoef] of the spectral scales instead.
+template <typename TIn>
+static int spectral_run(tspws_hip_plan *p, SpecDecomp *dc, const TIn *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st)
+{
+	SpecPlan *sp = dc->sp;
+	const unsigned N = sp->N, M = sp->M, nblk = TP / 64;
+	const size_t xrows = (size_t)M + 1;
+	void *v;
+	int rc;
+	if ((rc = scratch(p, SCR_SPA, (size_t)nblk * xrows * 64 * sizeof(double2), &v))) return rc;
+	double2 *A = (double2 *)v;
+	if ((rc = scratch(p, SCR_SPB, (size_t)nblk * xrows * 64 * sizeof(double2), &v))) return rc;
+	double2 *B = (double2 *)v;
+	if ((rc = scratch(p, SCR_SPG, (size_t)nblk * sp->grows * 64 * sizeof(double2), &v))) return rc;
+	double2 *G = (double2 *)v;
+	if ((rc = scratch(p, SCR_SPM, (size_t)TP * sizeof(unsigned), &v))) return rc;
+	unsigned *amax = (unsigned *)v;
+	HIP_TRY(hipMemsetAsync(amax, 0, (size_t)TP * sizeof(unsigned), st));
+	{
+		const unsigned rpw = 64, waves = (N + rpw - 1) / rpw;
+		hipLaunchKernelGGL((k_spec_colmax<TIn>), dim3((waves + 3) / 4, nblk), dim3(256), 0, st, xT, TP, N, rpw, amax);
+	}
+	// trace transform
+	const size_t np = sp->fwd_bits.size();
+	{
+		const unsigned R0 = 1u << sp->fwd_bits[0];
+		hipLaunchKernelGGL((k_spec_fwd_first<TIn>), dim3((M / R0 + 3) / 4, nblk), dim3(256), 0, st, xT, TP, A, xrows, M, R0);
+	}
+	double2 *cur = A, *oth = B;
+	for (size_t i = 1; i + 1 < np; i++) {
+		const unsigned items = M >> sp->fwd_bits[i];
+		hipLaunchKernelGGL((k_spec_mid<false>), dim3((items + 3) / 4, nblk), dim3(256), 0, st, (const SpecSeg *)(sp->d_fseg + i), 1u, items, (const double2 *)cur, xrows, oth,
+		                   xrows, (const double2 *)sp->d_tw);
+		std::swap(cur, oth);
+	}
+	{
+		const unsigned Rl = 1u << sp->fwd_bits[np - 1], L = M / Rl;
+		hipLaunchKernelGGL(k_spec_fwd_last, dim3((L / 2 + 1 + 3) / 4, nblk), dim3(256), 0, st, (const double2 *)cur, xrows, oth, xrows, M, Rl, (const double2 *)sp->d_tw);
+		std::swap(cur, oth);
+	}
+	const double2 *Xh = cur;
+	// multiply-and-fold
+	{
+		static int ntb = -1;
+		if (ntb < 0) { const char *e = getenv("TSPWS_SPEC_NTB"); ntb = (e && atoi(e) == 1) ? 1 : 2; } // sweeps
+		const unsigned NTB = (unsigned)ntb;
+		static const unsigned abl = getenv("TSPWS_SPEC_ABL") ? (unsigned)atoi(getenv("TSPWS_SPEC_ABL")) : 0u; // timing ablations (results wrong)
+		const unsigned WG = sp->ngroups, WT = std::max(1u, 8u / WG); // (spec_build: at most 8 groups)
+		const unsigned nsets = (nblk + NTB - 1) / NTB;
+		const dim3 grid(sp->R, (nsets + WT - 1) / WT), block(64 * WG * WT);
+		const size_t lds = (size_t)WG * SP_RB * 1024;
+#define SPEC_FOLD(NSV, NT) hipLaunchKernelGGL((k_spec_fold<NSV, NT>), grid, block, lds, st, Xh, xrows, (const double2 *)sp->d_tab, (const SpecSlot *)sp->d_slots, sp->R, sp->logsteps, N, nblk, WG, G, sp->grows, abl)
+		if (NTB == 2) { if (sp->NS == 8) SPEC_FOLD(8, 2); else SPEC_FOLD(16, 2); }
+		else { if (sp->NS == 8) SPEC_FOLD(8, 1); else SPEC_FOLD(16, 1); }
+#undef SPEC_FOLD
+	}
+	// inverse transforms: ping-pong between the folded spectra and the (now free) trace-transform buffer that does not hold Xh
+	SpecEpi ep;
+	ep.ST = ST; ep.PS = PS; ep.stride = stride; ep.amax = amax; ep.Y = Y; ep.ncoef = p->ncoef; ep.ntr = ntr;
+	double2 *g2 = oth; // rows: xrows >= grows?  not in general: own buffer when it is too small
+	size_t g2rows = xrows;
+	if (sp->d_iseg.size() > 1 && sp->grows > xrows) {
+		if ((rc = scratch(p, SCR_SPH, (size_t)nblk * sp->grows * 64 * sizeof(double2), &v))) return rc;
+		g2 = (double2 *)v; g2rows = sp->grows;
+	}
+	const double2 *src = G;
+	size_t src_rows = sp->grows;
+	double2 *dst = g2;
+	size_t dst_rows = g2rows;
+	for (size_t l = 0; l < sp->d_iseg.size(); l++) {
+		const unsigned items = sp->iseg_items[l];
+		if (Y) hipLaunchKernelGGL((k_spec_inv<true>), dim3((items + 3) / 4, nblk), dim3(256), 0, st, (const SpecSeg *)sp->d_iseg[l], sp->iseg_n[l], items, src, src_rows, dst, dst_rows,
+		                          (const double2 *)sp->d_tw, ep);
+		else hipLaunchKernelGGL((k_spec_inv<false>), dim3((items + 3) / 4, nblk), dim3(256), 0, st, (const SpecSeg *)sp->d_iseg[l], sp->iseg_n[l], items, src, src_rows, dst, dst_rows,
+		                        (const double2 *)sp->d_tw, ep);
+		// the next level reads what this one wrote; the level after that may overwrite this level's input
+		const double2 *ns = dst;
+		const size_t nr = dst_rows;
+		dst = (double2 *)src; dst_rows = src_rows;
+		src = ns; src_rows = nr;
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int tspws_spectral_run_f32(tspws_hip_plan *p, SpecDecomp *dc, const float *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st)
+{
+	return spectral_run<float>(p, dc, xT, TP, ntr, ST, PS, stride, Y, st);
+}
+int tspws_spectral_run_f64(tspws_hip_plan *p, SpecDecomp *dc, const double *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st)
+{
+	return spectral_run<double>(p, dc, xT, TP, ntr, ST, PS, stride, Y, st);
+}

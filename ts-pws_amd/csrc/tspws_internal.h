@@ -146,7 +146,7 @@ struct AccExtra {
 	bool fused_done = false;          // the fused forward kernel completed (and weighted) the stacks of its scales itself: only the others are left
 };
 
-enum { SCR_Y = 0, SCR_PART, SCR_XT, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_JKTAB, SCR_N };
+enum { SCR_Y = 0, SCR_PART, SCR_XT, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_JKTAB, SCR_SPA, SCR_SPB, SCR_SPG, SCR_SPH, SCR_SPM, SCR_N };
 
 struct OctDesc; // inverse work items (inv_poly.h)
 struct TLItem;  // many-trace forward work items (fwd_tl.h)
@@ -161,6 +161,8 @@ struct TlTable {
 	unsigned n = 0, wgs = 0, waves = 0, acc2_blocks = 0; // items, workgroups per trace block, direct-kernel waves, accumulate blocks
 	size_t npart = 0, lds = 0;
 };
+
+struct SpecDecomp; // spectral engine (spectral.h)
 
 struct tspws_hip_plan {
 	int device = 0, type = -1;
@@ -177,6 +179,7 @@ struct tspws_hip_plan {
 	// many-trace decompositions (fwd_tl.h): tl[0] for batches of many 64-trace blocks, tl[1] for few (more scales on the
 	// direct kernel, whose parallelism is in the taps): see TlTable
 	TlTable tl[2];
+	std::vector<SpecDecomp *> spec; // spectral sets built so far, with their many-trace decompositions (spectral.hip)
 	std::vector<unsigned> oc_s0, oc_nv, oc_wave_off, oc_nwaves, oc_gen; // host copy of the inverse's octave items (launch order)
 	std::vector<unsigned> og_s0, og_nv; // the decimation octaves (first scale, voices) in scale order, whatever the items are
 	unsigned inv_waves_lds = 0; // ... of which the first inv_waves_lds (octaves with D < 64) run the LDS-staged instantiation
@@ -317,8 +320,16 @@ void tspws_launch_accumulate(tspws_hip_plan *p, const double2 *part, unsigned nb
                              ScaleRange rg, const AccExtra *ex = nullptr);
 bool tspws_fused_forward(const tspws_hip_plan *p);        // the few-trace forward kernel stacks some scales in registers
 bool tspws_many_trace_path(const tspws_hip_plan *p, size_t ntr); // a batch this size goes to the trace-lane kernel
+unsigned tspws_spectral_choice(const tspws_hip_plan *p, size_t ntr); // first scale of the batch's spectral set (S: none)
 size_t tspws_part_budget_bytes();
 bool tspws_generic_forward();
+// spectral.hip: the far-decimated octaves of a many-trace batch through the traces' spectra
+unsigned tspws_spectral_first_scale(const tspws_hip_plan *p, unsigned nsmax); // first scale of the spectral set for octaves of <= nsmax outputs (S: none)
+int  tspws_spectral_decomp(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, SpecDecomp **out);
+int  tspws_build_tl_spectral(tspws_hip_plan *p, unsigned s_first, TlTable &T); // (forward.hip) scale table + trace-lane items of that decomposition
+int  tspws_spectral_run_f32(tspws_hip_plan *p, SpecDecomp *dc, const float *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st);
+int  tspws_spectral_run_f64(tspws_hip_plan *p, SpecDecomp *dc, const double *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st);
+void tspws_spectral_destroy(tspws_hip_plan *p);
 // inverse.hip
 int  tspws_build_inverse(tspws_hip_plan *p);
 int  tspws_weight_mode(double wu, int unbiased, unsigned K);
