@@ -1,0 +1,57 @@
+"""Child process of tests/test_spectral_gpu.py: whole tspws_main calls with the forward engine pinned by TSPWS_ENGINE (read once per
+process by the library) -- every single-stage / two-stage golden of the reference (16 x 2048: with TSPWS_ENGINE=spectral even these
+small ensembles take the many-trace path and the spectral engine) and seeded ensembles against the oracle, among them all-zero
+traces and traces with stretches of exact zeros (the reference skips 0 / 0 in the phase stack, ts_pws1f_lib.c:491-492).
+Prints SPECTRAL_ENGINE <worst relative error> <digest of all float outputs>."""
+import hashlib
+import importlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import abi
+from test_oracle_vs_golden import check_main, main_case_names
+
+tspws = importlib.import_module("ts-pws_amd")
+lib = tspws.load()
+worst = 0.0
+h = hashlib.sha1()
+
+g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mains.npz"), allow_pickle=False)
+for name in main_case_names(g):
+    r = check_main(lib.tspws_main, g, name, 2e-6)
+    worst = max(worst, abi.relerr(r["ls"], g[f"{name}/ls"]), abi.relerr(r["tsPWS"], g[f"{name}/tsPWS"]))
+    h.update(r["ls"].tobytes()); h.update(r["tsPWS"].tobytes())
+
+
+def check(kw, mtr, N, seed, holes=True):
+    global worst
+    X = abi.synth_traces(mtr, N, seed=seed)
+    if holes:
+        X[mtr // 3] = 0                                   # an all-zero trace
+        X[mtr // 2, N // 4: N // 2] = 0                   # a stretch of exact zeros longer than most filters
+        X[mtr - 1, : N // 8] = 0
+    p = abi.default_params(**kw)
+    a = abi.run_main(lib.tspws_main, p, X)
+    b = abi.run_main(abi.oracle().orc_tspws_main, p, X)
+    assert a["rc"] == 0 and b["rc"] == 0, (a["rc"], b["rc"])
+    e = max(abi.relerr(a["ls"], b["ls"]), abi.relerr(a["tsPWS"], b["tsPWS"]))
+    assert e < 2e-6, (kw, mtr, N, e)
+    worst = max(worst, e)
+    h.update(a["ls"].tobytes()); h.update(a["tsPWS"].tobytes())
+
+
+check(dict(), 100, 4096, 1)
+check(dict(w0=2 * np.pi), 200, 8192, 2)                  # V = 5
+check(dict(type=-3), 70, 4096, 3)                        # Mexican hat: two voices per octave
+check(dict(type=-2, unbiased=1), 130, 2048, 4)           # exact Morlet, unbiased
+check(dict(wu=1.5), 64, 1024, 5)                         # the smallest frame with a spectral set
+check(dict(V=7, J=6), 90, 4096, 6)
+check(dict(b0=4.0), 66, 16384, 7)                        # D = 8 .. : every octave spectral when the bound allows
+check(dict(lrm=1, wu=1.0), 257, 2048, 8)                 # five trace blocks, the last one with a single trace
+check(dict(), 40, 3000, 9, holes=False)                  # N not a power of two: no spectral set, the FIR kernels whatever the switch says
+check(dict(Kmax=200, unbiased=1), 600, 2048, 10)         # two-stage with 200 groups: the partial stacks are a many-trace batch (double input)
+print("SPECTRAL_ENGINE", worst, h.hexdigest()[:16])

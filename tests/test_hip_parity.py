@@ -15,6 +15,7 @@ import pytest
 
 import abi
 from test_oracle_vs_golden import check_main, main_case_names, _case_params
+from conftest import SWEEPS_LIB
 
 pytestmark = pytest.mark.gpu
 
@@ -317,6 +318,7 @@ def test_masked_replica_engines_agree(env):
     import sys as _sys
     e = dict(os.environ)
     e.update(env)
+    e["TSPWS_LIB_PATH"] = SWEEPS_LIB   # (the shipped library does not read the switches)
     r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "masked_engines.py")], capture_output=True, text=True,
                        timeout=900, env=e)
     line = [l for l in r.stdout.splitlines() if l.startswith("MASKED_ENGINES")]
@@ -335,6 +337,7 @@ def test_short_frame_and_many_trace_forms_agree(env):
     import sys as _sys
     e = dict(os.environ)
     e.update(env)
+    e["TSPWS_LIB_PATH"] = SWEEPS_LIB   # (the shipped library does not read the switches)
     r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "shape_engines.py")], capture_output=True, text=True,
                        timeout=900, env=e)
     line = [l for l in r.stdout.splitlines() if l.startswith("SHAPE_ENGINES")]
@@ -660,12 +663,13 @@ def test_random_subsampling_vs_oracle(lib, kw):
 
 # ------------------------------------------------------------------------------- layout edge cases
 @pytest.mark.parametrize("pad", [4, 1])
-def test_padded_rows_and_many_traces(lib, torch, pad, monkeypatch):
+def test_padded_rows_and_many_traces(sweeps, torch, pad, monkeypatch):
     """Row stride ld > N (vectorised when ld % 4 == 0, scalar otherwise) through the device-resident path."""
+    sw, swlib = sweeps   # the build that reads TSPWS_TL_MIN / TSPWS_TL_BATCH (conftest.py)
     monkeypatch.setenv("TSPWS_TL_MIN", "64")   # (the single-stage part below goes through the many-trace kernel)
     mtr, N, K = 70, 4096, 7
-    p = tspws.resolve(abi.default_params(Kmax=K, unbiased=1), N)
-    pl = tspws.Plan(p, N)
+    p = sw.resolve(abi.default_params(Kmax=K, unbiased=1), N)
+    pl = sw.Plan(p, N)
     X = abi.synth_traces(mtr, N, seed=44)
     buf = torch.zeros((mtr, N + pad), dtype=torch.float32, device="cuda")
     buf[:, :N] = torch.as_tensor(X, device="cuda")
@@ -676,8 +680,8 @@ def test_padded_rows_and_many_traces(lib, torch, pad, monkeypatch):
     want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(Kmax=K, unbiased=1), X)
     assert abi.relerr(ls.cpu().numpy(), want["ls"]) < TOL32 and abi.relerr(ts.cpu().numpy(), want["tsPWS"]) < TOL32
     # single-stage through the same strided view (float input path of the forward kernels)
-    p1 = tspws.resolve(abi.default_params(), N)
-    pl1 = tspws.Plan(p1, N)
+    p1 = sw.resolve(abi.default_params(), N)
+    pl1 = sw.Plan(p1, N)
     ls1, ts1 = pl1.stack(view[:12])
     torch.cuda.synchronize()
     want1 = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(), X[:12])
@@ -933,28 +937,30 @@ def test_sharded_jackknife_rows_add_up(lib, torch, kw, bounds):
     (dict(b0=4.0), 8192, 80), (dict(b0=3.0), 12288, 70),
     (dict(Kmax=80, unbiased=1), 2048, 200),   # two-stage with many groups: the 80 FP64 partial stacks take the many-trace path too
 ])
-def test_many_trace_single_stage_vs_oracle(lib, torch, kw, N, mtr, monkeypatch):
+def test_many_trace_single_stage_vs_oracle(sweeps, torch, kw, N, mtr, monkeypatch):
     """Single-stage stacks of >= 64 traces run on the trace-lane kernel (csrc/fwd_tl.h: transposed batch, lanes = traces, fused
     phase stack per 64-trace block, residue splits for large decimations, direct kernel for the coarsest scales): whole call
     against the oracle, device-resident and through tspws_main, including partially filled trace blocks and an all-zero trace.
     (TSPWS_TL_MIN forces that path: by default ensembles this small stay on the few-trace kernels.)"""
+    sw, swlib = sweeps   # the build that reads TSPWS_TL_MIN / TSPWS_TL_BATCH (conftest.py)
     monkeypatch.setenv("TSPWS_TL_MIN", "64")
     X = abi.synth_traces(mtr, N, seed=41)
     X[mtr // 3] = 0.0
     want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), X)
-    pl = tspws.Plan(tspws.resolve(abi.default_params(**kw), N), N)
+    pl = sw.Plan(sw.resolve(abi.default_params(**kw), N), N)
     ls, ts = pl.stack(torch.as_tensor(X, device="cuda"))
     torch.cuda.synchronize()
     assert abi.relerr(ls.cpu().numpy(), want["ls"]) < TOL32 and abi.relerr(ts.cpu().numpy(), want["tsPWS"]) < TOL32
-    got = abi.run_main(lib.tspws_main, abi.default_params(**kw), X)
+    got = abi.run_main(swlib.tspws_main, abi.default_params(**kw), X)
     assert abi.relerr(got["ls"], want["ls"]) < TOL32 and abi.relerr(got["tsPWS"], want["tsPWS"]) < TOL32
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw,mtr,N", [(dict(), 100, 8192), (dict(), 1000, 8192), (dict(type=-3), 1000, 8192)])
-def test_single_stage_path_choice_is_invisible(lib, torch, kw, mtr, N, monkeypatch):
+def test_single_stage_path_choice_is_invisible(sweeps, torch, kw, mtr, N, monkeypatch):
     """The library picks the forward path of a single-stage batch by its size and frame (few-trace kernels below ~7 M samples and
     for two-voice frames, the trace-lane kernel above): forced either way and left alone, the call gives the oracle's outputs."""
+    sw, swlib = sweeps   # the build that reads TSPWS_TL_MIN / TSPWS_TL_BATCH (conftest.py)
     X = abi.synth_traces(mtr, N, seed=48)
     want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), X)
     Xd = torch.as_tensor(X, device="cuda")
@@ -963,38 +969,40 @@ def test_single_stage_path_choice_is_invisible(lib, torch, kw, mtr, N, monkeypat
             monkeypatch.delenv("TSPWS_TL_MIN", raising=False)
         else:
             monkeypatch.setenv("TSPWS_TL_MIN", force)
-        pl = tspws.Plan(tspws.resolve(abi.default_params(**kw), N), N)
+        pl = sw.Plan(sw.resolve(abi.default_params(**kw), N), N)
         ls, ts = pl.stack(Xd)
         torch.cuda.synchronize()
         assert abi.relerr(ls.cpu().numpy(), want["ls"]) < TOL32 and abi.relerr(ts.cpu().numpy(), want["tsPWS"]) < TOL32, force
 
 
 @pytest.mark.gpu
-def test_many_trace_batches(lib, torch, monkeypatch):
+def test_many_trace_batches(sweeps, torch, monkeypatch):
     """The trace-lane path walks large ensembles in batches (transposed copy <= 1 GiB): forced here to 64 / 128 traces per batch,
     the later batches add to the stacks of the first, the last one is partial."""
+    sw, swlib = sweeps   # the build that reads TSPWS_TL_MIN / TSPWS_TL_BATCH (conftest.py)
     monkeypatch.setenv("TSPWS_TL_MIN", "64")
     mtr, N = 200, 2048
     X = abi.synth_traces(mtr, N, seed=47)
     want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(), X)
     for b in ("64", "128"):
         monkeypatch.setenv("TSPWS_TL_BATCH", b)
-        pl = tspws.Plan(tspws.resolve(abi.default_params(), N), N)
+        pl = sw.Plan(sw.resolve(abi.default_params(), N), N)
         ls, ts = pl.stack(torch.as_tensor(X, device="cuda"))
         torch.cuda.synchronize()
         assert abi.relerr(ls.cpu().numpy(), want["ls"]) < TOL32 and abi.relerr(ts.cpu().numpy(), want["tsPWS"]) < TOL32
 
 
 @pytest.mark.gpu
-def test_many_trace_path_matches_the_few_trace_kernels(lib, torch, monkeypatch):
+def test_many_trace_path_matches_the_few_trace_kernels(sweeps, torch, monkeypatch):
     """Same ensemble through the trace-lane decomposition (stack_local on 192 traces: the single-stage all-reduce payload
     ST || PS) and through the per-trace forward API (k_fwd_lds / k_fwd_poly, coefficients of every trace) with the stacks
     formed on the host: the FP64 stacks agree to rounding."""
+    sw, swlib = sweeps   # the build that reads TSPWS_TL_MIN / TSPWS_TL_BATCH (conftest.py)
     monkeypatch.setenv("TSPWS_TL_MIN", "64")
     mtr, N = 192, 8192
-    p = tspws.resolve(abi.default_params(), N)
-    Xd = tspws.synth(mtr, N, seed=43)
-    pl = tspws.Plan(p, N)
+    p = sw.resolve(abi.default_params(), N)
+    Xd = sw.synth(mtr, N, seed=43)
+    pl = sw.Plan(p, N)
     pl.stack_local(Xd, 0, mtr)
     torch.cuda.synchronize()
     buf = pl.reduce_buffer(mtr).cpu().numpy()

@@ -1,0 +1,177 @@
+"""GPU parity tests of the spectral forward engine (ts-pws_amd/csrc/spectral.hip): the far-decimated octaves of a many-trace batch
+through the traces' spectra instead of per-scale FIR sums.  Exact because the reference's decimating FIR is a circular correlation
+(FWTa/cdotx.c:35-72, driver FWTa/wavelet_v7.c:43-64) and those octaves' D divides N.  Tolerances as in test_hip_parity.py: 1e-11 on
+the FP64 coefficients, 2e-6 on the float32 outputs."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import abi
+from conftest import SWEEPS_LIB
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1e-11
+TOL32 = 2e-6
+
+tspws = importlib.import_module("ts-pws_amd")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = tspws.load()
+    assert lib.tspws_hip_device_count() > 0, "no MI355X visible: the HIP path cannot run (there is no CPU fallback)"
+    return lib
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def dev_forward_spectral(lib, torch, pl, X, nsmax):
+    ntr, N = X.shape
+    Xd = torch.as_tensor(X, device="cuda")
+    Y = torch.zeros((ntr, 2 * pl.ncoef), dtype=torch.float64, device="cuda")
+    fn = lib.tspws_hip_forward_spectral_f64 if X.dtype == np.float64 else lib.tspws_hip_forward_spectral_f32
+    tspws.check(fn(pl.h, Xd.data_ptr(), ntr, N, Y.data_ptr(), nsmax, None), "forward_spectral")
+    torch.cuda.synchronize()
+    return Y.cpu().numpy().view(np.complex128)
+
+
+def test_spectral_coefficients_golden(lib, torch, golden):
+    """The reference's own coefficients of one trace (tests/golden/cwt.npz): every scale of the frame's largest spectral set."""
+    g = golden["cwt"]
+    seen = 0
+    for name in sorted({k.split("/")[0] for k in g.files}):
+        x = g[f"{name}/x"]
+        N = len(x)
+        p = abi.default_params()
+        p.type, p.J, p.V = int(g[f"{name}/type"]), int(g[f"{name}/J"]), int(g[f"{name}/V"])
+        p.s0, p.b0, p.w0 = float(g[f"{name}/s0"]), float(g[f"{name}/b0"]), float(g[f"{name}/w0"])
+        pl = tspws.Plan(p, N)
+        f = abi.OracleFrame.from_params(p, N)
+        sf = lib.tspws_hip_spectral_first_scale(pl.h, 1 << 30)
+        if N & (N - 1):                                  # N = 1501: no decimation divides it
+            assert sf == pl.S, name
+            continue
+        assert sf < pl.S, name
+        off = np.concatenate([[0], np.cumsum(f.Ns.astype(np.int64))])
+        want = g[f"{name}/Y"]
+        for X in (x[None, :].astype(np.float64), x[None, :].astype(np.float32)):
+            Y = dev_forward_spectral(lib, torch, pl, np.ascontiguousarray(X), 1 << 30)[0]
+            for s in range(sf, pl.S):
+                a, b = int(off[s]), int(off[s + 1])
+                assert f.D[s] >= 8 and N % int(f.D[s]) == 0
+                assert abi.relerr(Y[a:b], want[a:b]) < TOL64, (name, s)
+        seen += 1
+    assert seen >= 2
+
+
+@pytest.mark.parametrize("kw,N,ntr,nsmax", [
+    (dict(), 1024, 3, 1 << 20), (dict(), 4096, 70, 256), (dict(), 131072, 2, 1 << 20), (dict(type=-3), 32768, 5, 4096),
+    (dict(w0=2 * np.pi), 32768, 7, 1024), (dict(type=-2), 8192, 2, 1 << 20), (dict(b0=4.0), 65536, 2, 2048), (dict(J=3), 2048, 4, 1 << 20),
+    (dict(V=7), 4096, 130, 1 << 20), (dict(s0=4.0, J=5), 8192, 65, 1 << 20), (dict(b0=0.25), 16384, 3, 1 << 20),
+])
+def test_spectral_coefficients_vs_oracle(lib, torch, kw, N, ntr, nsmax):
+    """Per-trace coefficients of the spectral set [first, S) for float and double input; one trace carries a stretch of exact zeros."""
+    p = abi.resolve(abi.default_params(**kw), N)
+    f = abi.OracleFrame.from_params(p, N)
+    pl = tspws.Plan(p, N)
+    sf = lib.tspws_hip_spectral_first_scale(pl.h, nsmax)
+    assert sf < f.S
+    # the set is a run of whole octaves at the coarse end: D >= 8, a power of two, at most nsmax outputs
+    assert all(int(f.D[s]) >= 8 and int(f.Ns[s]) <= nsmax for s in range(sf, f.S))
+    assert sf == 0 or int(f.D[sf - 1]) < 8 or int(f.Ns[sf - 1]) > nsmax or f.S - sf >= 128 - int(p.V)
+    X = abi.synth_traces(ntr, N, seed=5)
+    X[ntr // 2, N // 3: N // 3 + N // 4] = 0
+    off = np.concatenate([[0], np.cumsum(f.Ns.astype(np.int64))])
+    Y64 = dev_forward_spectral(lib, torch, pl, X.astype(np.float64), nsmax)
+    Y32 = dev_forward_spectral(lib, torch, pl, X, nsmax)
+    for t in sorted({0, ntr // 2, ntr - 1}):
+        Yo = f.forward(X[t].astype(np.float64))
+        for s in range(sf, f.S):
+            a, b = int(off[s]), int(off[s + 1])
+            assert abi.relerr(Y64[t][a:b], Yo[a:b]) < TOL64, (t, s)
+            assert abi.relerr(Y32[t][a:b], Yo[a:b]) < TOL64, (t, s)
+        assert not Y64[t][:int(off[sf])].any()           # the other scales are left alone
+
+
+def test_frames_without_a_spectral_set(lib):
+    """Odd N, N not a power of two, N < 1024, decimations 3 * 2^j: TSPWS_E_ARG from the per-trace entry, first scale == S."""
+    import torch
+    for kw, N in [(dict(), 16501), (dict(), 3000), (dict(), 512), (dict(b0=3.0), 49152)]:
+        p = abi.resolve(abi.default_params(**kw), N)
+        pl = tspws.Plan(p, N)
+        assert lib.tspws_hip_spectral_first_scale(pl.h, 1 << 30) == pl.S
+        X = torch.zeros((2, N), dtype=torch.float64, device="cuda")
+        Y = torch.zeros((2, 2 * pl.ncoef), dtype=torch.float64, device="cuda")
+        assert lib.tspws_hip_forward_spectral_f64(pl.h, X.data_ptr(), 2, N, Y.data_ptr(), 1 << 30, None) != 0
+
+
+def test_engine_choice_rule(lib):
+    """Default rule (no TSPWS_ENGINE): batches of the many-trace size of frames with more than two voices per octave send the octaves
+    with D >= 32 through the spectrum; small batches, two-voice frames and frames without a spectral set stay on the FIR kernels."""
+    if os.environ.get("TSPWS_ENGINE") or os.environ.get("TSPWS_SPEC_NSMAX"):
+        pytest.skip("engine pinned by the environment")
+    N = 32768
+    p = abi.resolve(abi.default_params(), N)
+    pl = tspws.Plan(p, N)
+    f = abi.OracleFrame.from_params(p, N)
+    s = lib.tspws_hip_spectral_choice(pl.h, 1024)
+    assert s < pl.S and int(f.D[s]) == 32 and int(f.D[s - 1]) == 16
+    assert lib.tspws_hip_spectral_choice(pl.h, 100) == pl.S          # fewer than 128 traces
+    assert lib.tspws_hip_spectral_choice(pl.h, 200) == pl.S          # fewer than 7 M samples
+    pm = tspws.Plan(abi.resolve(abi.default_params(type=-3), N), N)
+    assert lib.tspws_hip_spectral_choice(pm.h, 1024) == pm.S         # Mexican hat: two voices per octave
+    po = tspws.Plan(abi.resolve(abi.default_params(), 16501), 16501)
+    assert lib.tspws_hip_spectral_choice(po.h, 4096) == po.S         # odd N
+
+
+def _child(env):
+    e = dict(os.environ)
+    e.update(env)
+    if "TSPWS_SPEC_NSMAX" in env:
+        e["TSPWS_LIB_PATH"] = SWEEPS_LIB   # (the octave bound is a sweep switch: only the -DTSPWS_SWEEPS build reads it)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "spectral_engine.py")], capture_output=True, text=True,
+                       timeout=1500, env=e)
+    line = [l for l in r.stdout.splitlines() if l.startswith("SPECTRAL_ENGINE")]
+    assert line, r.stdout[-3000:] + r.stderr[-3000:]
+    return float(line[0].split()[1]), line[0].split()[2]
+
+
+def test_whole_calls_with_the_engine_pinned():
+    """Every whole-call golden of the reference and ten seeded ensembles (zero traces, stretches of zeros, V = 5 / 7, Mexican hat,
+    two-stage with 200 groups) through tspws_main with TSPWS_ENGINE=spectral -- all octaves with D >= 8 spectral -- and with the bound
+    of the default rule; the same cases on the FIR kernels agree to the last bit of the float outputs or to 2e-6."""
+    e_all, d_all = _child({"TSPWS_ENGINE": "spectral", "TSPWS_SPEC_NSMAX": str(1 << 30)})
+    e_def, d_def = _child({"TSPWS_ENGINE": "spectral"})
+    e_fir, d_fir = _child({"TSPWS_ENGINE": "fir"})
+    assert max(e_all, e_def, e_fir) < TOL32
+
+
+def test_large_batch_default_rule_matches_fir(lib, torch):
+    """1024 x 8192 (the default rule picks the spectral engine) against the same call with the FIR kernels forced through the
+    per-trace coefficients: stacks of the spectral scales equal sums of the FIR coefficients."""
+    N, ntr = 8192, 1024
+    p = abi.resolve(abi.default_params(), N)
+    pl = tspws.Plan(p, N)
+    f = abi.OracleFrame.from_params(p, N)
+    X = tspws.synth(ntr, N, seed=3)
+    ls, ts = pl.stack(X)
+    torch.cuda.synchronize()
+    Xh = X.cpu().numpy()
+    sub = 160
+    a = abi.run_main(lib.tspws_main, abi.default_params(), Xh[:sub])       # below the many-trace size? (160 x 8192 < 7 M samples: FIR)
+    b = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(), Xh[:sub])
+    assert abi.relerr(a["tsPWS"], b["tsPWS"]) < TOL32 and abi.relerr(a["ls"], b["ls"]) < TOL32
+    # full batch: linear stack against the frame-filtered mean through the oracle's transform of the FP64 mean trace (linearity)
+    m = Xh.astype(np.float64).sum(axis=0)
+    lin = f.inverse(f.forward(m)) / ntr
+    assert abi.relerr(ls.cpu().numpy(), lin.astype(np.float32)) < TOL32

@@ -97,7 +97,7 @@ static int forward_generic(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t
 // TSPWS_TL_MIN=n forces the many-trace path for batches of >= n traces (tests; read at every call), unset: the rule below
 static long tl_min_env()
 {
-	const char *e = getenv("TSPWS_TL_MIN");
+	const char *e = sweep_env("TSPWS_TL_MIN");
 	return e ? std::max(1, atoi(e)) : -1;
 }
 
@@ -124,7 +124,7 @@ int tspws_build_forward(tspws_hip_plan *p)
 {
 	const unsigned S = p->S;
 	unsigned FWD_STEPS = FWD_STEPS_DEF;
-	if (const char *e = getenv("TSPWS_FWD_STEPS")) FWD_STEPS = (unsigned)std::max(8, atoi(e)); // sweeps
+	if (const char *e = sweep_env("TSPWS_FWD_STEPS")) FWD_STEPS = (unsigned)std::max(8, atoi(e)); // sweeps
 	const unsigned R = 8, FL_SLOTS_HOST = FL_WAVES * FL_PASSES;
 	unsigned woff = 0, boff = 0;
 	unsigned long long poff = 0;
@@ -162,7 +162,7 @@ int tspws_build_forward(tspws_hip_plan *p)
 	// with such scales (24 < Q <= 32) take the QT = 32 instantiation (80 KB of LDS, still two workgroups per CU).
 	p->lds_qt = 24;
 	for (unsigned s = 0; s < S; s++) if (p->sc[s].use_lds && p->sc[s].Q > 24 && p->sc[s].Q <= 32) p->lds_qt = 32;
-	if (const char *e = getenv("TSPWS_FWD_QT")) { const int v = atoi(e); if (v == 24 || v == 32) p->lds_qt = (unsigned)v; } // (sweeps)
+	if (const char *e = sweep_env("TSPWS_FWD_QT")) { const int v = atoi(e); if (v == 24 || v == 32) p->lds_qt = (unsigned)v; } // (sweeps)
 	// two many-trace decompositions (see stacks_tl for the choice): sweeps on 128 .. 2048 traces x 8192 .. 32768 samples, Morlet
 	// and Mexican hat (round 3): batches of >= 12 trace blocks are fastest with the octaves of >= 33 outputs on the trace-lane
 	// kernel, smaller batches (and frames with two voices per octave) with >= 129 -- the trace-lane kernel has tl.wgs x blocks
@@ -172,8 +172,8 @@ int tspws_build_forward(tspws_hip_plan *p)
 	// 499 x 16501 0.893 -> 0.865 ms, 256 x 32768 0.797 -> 0.780, 512 x 16384 0.885 -> 0.806 against (257, 96); cfg2 (table 0) 3.06 vs 3.16 at 48
 	if (int rc = build_tl_forward(p, FWD_STEPS_TL, TL_MINNS0, 96, p->tl[0])) return rc;
 	unsigned minns1 = 129, tlsteps1 = 48;
-	if (const char *e = getenv("TSPWS_TLSTEPS")) tlsteps1 = (unsigned)std::max(8, atoi(e)); // sweeps
-	if (const char *e = getenv("TSPWS_TL_MINNS1")) minns1 = (unsigned)std::max(9, atoi(e)); // sweeps
+	if (const char *e = sweep_env("TSPWS_TLSTEPS")) tlsteps1 = (unsigned)std::max(8, atoi(e)); // sweeps
+	if (const char *e = sweep_env("TSPWS_TL_MINNS1")) minns1 = (unsigned)std::max(9, atoi(e)); // sweeps
 	return build_tl_forward(p, FWD_STEPS_TL, minns1, tlsteps1, p->tl[1]);
 }
 
@@ -303,7 +303,7 @@ static LaunchRange launch_range(const tspws_hip_plan *p, ScaleRange rg)
 // the coarse-scale kernel finish inside the main kernel's time when it is dispatched first?); default: plain.
 static hipError_t tspws_side_stream(tspws_hip_plan *p)
 {
-	const char *e = getenv("TSPWS_SIDE_PRIO");
+	const char *e = sweep_env("TSPWS_SIDE_PRIO");
 	if (!e || !atoi(e)) return hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
 	int lo = 0, hi = 0;
 	hipError_t rc = hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -321,7 +321,7 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 	const bool has_lds = lr.lds1 > lr.lds0, has_poly = lr.wav1 > lr.wav0;
 	hipStream_t sp = st; // stream of the direct kernel
 #if FL_TIMING || FL_ABLATE
-	static const bool serial = getenv("TSPWS_FWD_SERIAL") != nullptr; // debug builds: the two kernels one after the other
+	static const bool serial = sweep_env("TSPWS_FWD_SERIAL") != nullptr; // debug builds: the two kernels one after the other
 #else
 	constexpr bool serial = false;
 #endif
@@ -395,7 +395,7 @@ int tspws_forward_parts_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, si
 // debug build only: only the log2(D) classes of k_fwd_lds named by the hex mask TSPWS_FWD_CLASSES run (results wrong: timing ablation)
 extern "C" int tspws_hip_fwd_ablate(void)
 {
-	if (const char *e = getenv("TSPWS_FWD_CLASSES")) {
+	if (const char *e = sweep_env("TSPWS_FWD_CLASSES")) {
 		const unsigned m = (unsigned)strtoul(e, nullptr, 16);
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(fl_class_mask), &m, sizeof m));
 	}
@@ -431,7 +431,7 @@ size_t tspws_part_budget_bytes()
 bool tspws_generic_forward()
 {
 	static int v = -1;
-	if (v < 0) { const char *e = getenv("TSPWS_FWD_GENERIC"); v = (e && *e == '1') ? 1 : 0; }
+	if (v < 0) { const char *e = sweep_env("TSPWS_FWD_GENERIC"); v = (e && *e == '1') ? 1 : 0; }
 	return v == 1;
 }
 
@@ -444,8 +444,13 @@ bool tspws_fused_forward(const tspws_hip_plan *p) { return p->n_fusable != 0; }
 // (Mexican hat) stay on the few-trace kernels at every size measured (1024 x 32768: 3.66 vs 4.63; 4096 x 16384: 8.5 vs 9.9) --
 // a trace-lane work item shares its staged rows among the voices of an octave.
 // Engine of a many-trace batch: the first scale of the spectral set (S: every scale on the FIR kernels).  TSPWS_ENGINE=fir / spectral
-// pins it (spectral: every batch that has such a set takes the many-trace path, whatever its size); default: the rule below.
-// TSPWS_SPEC_NSMAX: octaves with at most this many outputs go through the spectrum.
+// pins it (spectral: every batch that has such a set takes the many-trace path, whatever its size).  Default: batches of the many-trace
+// size (>= 128 traces, >= 7 M samples) of frames with more than two voices per octave send the octaves with D >= 32 (at most
+// max(512, N / 32) outputs) through the spectrum -- sweeps over 128 .. 4096 traces x 8192 .. 131072 samples (tools/experiments/
+// r5_spec12.sh, default Morlet): 1024 x 32768 2.73 -> 1.81 ms, 2048 x 16384 2.83 -> 1.74, 512 x 65536 3.05 -> 2.02, 1024 x 131072 10.96 ->
+// 7.63 (N_s <= 4096), 4096 x 8192 2.38 -> 1.65; below that size the FIR kernels win (256 x 8192: 0.31 vs 0.38 ms); outputs
+// bit-identical at every size.  TSPWS_SPEC_NSMAX overrides the octave bound.
+static bool many_trace_size(const tspws_hip_plan *p, size_t ntr) { return ntr >= 128 && (double)ntr * (double)p->N >= 7.0 * 1048576.0; }
 unsigned tspws_spectral_choice(const tspws_hip_plan *p, size_t ntr)
 {
 	static int eng = -1; // 0 auto, 1 fir, 2 spectral
@@ -453,11 +458,11 @@ unsigned tspws_spectral_choice(const tspws_hip_plan *p, size_t ntr)
 	if (eng < 0) {
 		const char *e = getenv("TSPWS_ENGINE");
 		eng = !e ? 0 : !strcmp(e, "fir") ? 1 : !strcmp(e, "spectral") ? 2 : 0;
-		if (const char *m = getenv("TSPWS_SPEC_NSMAX")) nsmax_env = (unsigned)std::max(2, atoi(m));
+		if (const char *m = sweep_env("TSPWS_SPEC_NSMAX")) nsmax_env = (unsigned)std::max(2, atoi(m));
 	}
-	if (eng == 1 || tspws_generic_forward()) return p->S;
-	if (eng == 0 && ntr < 128) return p->S;
-	return tspws_spectral_first_scale(p, nsmax_env ? nsmax_env : 1024u);
+	if (eng == 1 || tspws_generic_forward() || !ntr) return p->S;
+	if (eng == 0 && !(many_trace_size(p, ntr) && p->V > 2)) return p->S;
+	return tspws_spectral_first_scale(p, nsmax_env ? nsmax_env : std::max(512u, p->N / 32u));
 }
 
 static int spectral_run_t(tspws_hip_plan *p, SpecDecomp *dc, const float *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st)
@@ -468,11 +473,11 @@ static int spectral_run_t(tspws_hip_plan *p, SpecDecomp *dc, const double *xT, u
 bool tspws_many_trace_path(const tspws_hip_plan *p, size_t ntr)
 {
 	if (tspws_generic_forward()) return false;
-	if (const char *e = getenv("TSPWS_ENGINE")) if (!strcmp(e, "spectral") && ntr && tspws_spectral_choice(p, ntr) < p->S) return true;
+	if (tspws_spectral_choice(p, ntr) < p->S) return true; // (the spectral engine works on the transposed batch of this path)
 	if (!(p->tl[0].n || p->tl[1].n)) return false;
 	const long forced = tl_min_env();
 	if (forced > 0) return ntr >= (size_t)forced;
-	return p->V > 2 && ntr >= 128 && (double)ntr * (double)p->N >= 7.0 * 1048576.0; // (tools/experiments/tl_threshold.sh: 128 x 65536 0.94 vs 0.86 ms, 160 x 32768 0.63 vs 0.69, 1024 x 4096 0.58 vs 0.70, 499 x 16501 1.17 vs 0.99)
+	return p->V > 2 && many_trace_size(p, ntr); // (tools/experiments/tl_threshold.sh: 128 x 65536 0.94 vs 0.86 ms, 160 x 32768 0.63 vs 0.69, 1024 x 4096 0.58 vs 0.70, 499 x 16501 1.17 vs 0.99)
 }
 
 template <typename TIn>
@@ -532,6 +537,7 @@ static int forward_spectral(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_
 }
 
 extern "C" unsigned tspws_hip_spectral_first_scale(const tspws_hip_plan *p, unsigned nsmax) { return p ? tspws_spectral_first_scale(p, nsmax) : 0u; }
+extern "C" unsigned tspws_hip_spectral_choice(const tspws_hip_plan *p, size_t ntr) { return p ? tspws_spectral_choice(p, ntr) : 0u; }
 extern "C" int tspws_hip_forward_spectral_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, size_t ld, double *d_Y, unsigned nsmax, void *s)
 {
 	return forward_spectral<double>(p, d_x, ntr, ld, d_Y, nsmax, S_(s));
@@ -608,10 +614,10 @@ unsigned tspws_first_unfused_scale(const tspws_hip_plan *p)
 static unsigned fuse_tps(const tspws_hip_plan *p, size_t nb)
 {
 	static int target = -1;
-	if (target < 0) { const char *e = getenv("TSPWS_FUSE_WGS"); target = e ? std::max(1, atoi(e)) : 256; }
+	if (target < 0) { const char *e = sweep_env("TSPWS_FUSE_WGS"); target = e ? std::max(1, atoi(e)) : 256; }
 	unsigned tps = (unsigned)std::min<size_t>(nb, 32);
 	static int mintps = -1;
-	if (mintps < 0) { const char *e = getenv("TSPWS_FUSE_MINTPS"); mintps = e ? std::max(1, atoi(e)) : 3; }
+	if (mintps < 0) { const char *e = sweep_env("TSPWS_FUSE_MINTPS"); mintps = e ? std::max(1, atoi(e)) : 3; }
 	while (tps > 1 && (tps + 1) / 2 >= (unsigned)mintps && (size_t)std::max(1u, p->lds_blocks) * ((nb + tps - 1) / tps) < (size_t)target) tps = (tps + 1) / 2;
 	return std::max(1u, tps);
 }
@@ -626,7 +632,7 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 	void *v;
 	// decomposition: many trace blocks and more than two voices per octave -> tl[0], else tl[1] (tspws_build_forward)
 	unsigned pick = ((ntr + 63) / 64 >= 12 && p->V > 2) ? 0u : 1u;
-	if (const char *e = getenv("TSPWS_TL_PICK")) pick = atoi(e) ? 1u : 0u; // sweeps: force a decomposition
+	if (const char *e = sweep_env("TSPWS_TL_PICK")) pick = atoi(e) ? 1u : 0u; // sweeps: force a decomposition
 	// ... or the spectral engine for the far-decimated octaves (spectral.hip) with its own decomposition of the rest
 	SpecDecomp *dc = nullptr;
 	const unsigned spec_first = tspws_spectral_choice(p, ntr);
@@ -635,7 +641,7 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 	// traces per batch: transposed copy <= 1 GiB, at most 4096 (64 plane pairs), a multiple of 64
 	size_t batch = std::min<size_t>(4096, std::max<size_t>(64, (((size_t)1 << 30) / ((size_t)p->N * sizeof(TIn))) & ~(size_t)63));
 	if (T.npart) batch = std::min(batch, std::max<size_t>(64, (tspws_part_budget_bytes() / (T.npart * sizeof(double2))) & ~(size_t)63));
-	if (const char *e = getenv("TSPWS_TL_BATCH")) batch = std::max<size_t>(64, (size_t)atoi(e) & ~(size_t)63); // tests: force several batches
+	if (const char *e = sweep_env("TSPWS_TL_BATCH")) batch = std::max<size_t>(64, (size_t)atoi(e) & ~(size_t)63); // tests: force several batches
 	batch = std::min(batch, (ntr + 63) & ~(size_t)63);
 	const size_t nblk_max = batch / 64;
 	if ((rc = scratch(p, SCR_XT, (size_t)p->N * batch * sizeof(TIn), &v))) return rc;
@@ -674,7 +680,7 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 		}
 		hipLaunchKernelGGL((k_transpose_traces<TIn>), dim3((p->N + 63) / 64, nblk), dim3(256), 0, st, xb, ld, nb, p->N, TP, xT);
 		// the spectral chain (transforms through HBM / MALL: bandwidth-bound) beside the trace-lane kernel (FP64-bound) on the side stream
-		static const bool spec_serial = getenv("TSPWS_SPEC_SERIAL") != nullptr; // sweeps: one after the other
+		static const bool spec_serial = sweep_env("TSPWS_SPEC_SERIAL") != nullptr; // sweeps: one after the other
 		if (dc && T.n && !spec_serial) {
 			const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
 			if (!p->side) HIP_TRY(tspws_side_stream(p));

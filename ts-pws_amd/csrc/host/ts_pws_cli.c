@@ -347,7 +347,10 @@ int main(int argc, char *argv[])
 	const double t_call0 = now_s();
 	er = tspws_main(&p, &out, &in);
 	const double t_call1 = now_s();
+	(void)t_start; (void)t_read; (void)t_call0; (void)t_call1;
+#ifdef TSPWS_SWEEPS
 	if (getenv("TSPWS_CLI_TIMES")) printf("cli: read %.1f ms, set-up %.1f ms, tspws_main %.1f ms\n", 1e3 * (t_read - t_start), 1e3 * (t_call0 - t_read), 1e3 * (t_call1 - t_call0));
+#endif
 
 	if (!er) {
 		t_hdr hdr = in.hdr;

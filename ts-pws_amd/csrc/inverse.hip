@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256) k_inverse_generic(const double2 *__restri
 static unsigned inv_lds_maxd()
 {
 	static int v = -1;
-	if (v < 0) { const char *e = getenv("TSPWS_INV_LDS_MAXD"); v = e ? std::max(0, atoi(e)) : 1; }
+	if (v < 0) { const char *e = sweep_env("TSPWS_INV_LDS_MAXD"); v = e ? std::max(0, atoi(e)) : 1; }
 	return (unsigned)v;
 }
 
@@ -158,7 +158,7 @@ int tspws_build_inverse(tspws_hip_plan *p)
 			s = e;
 		}
 		split = waves < 768; // (tools/experiments/inv_split.sh: 499 x 16501 two-stage 0.157 -> 0.134 ms, 64 x 8192 0.165 -> 0.158; N = 32768 / 65536 / 131072 unchanged or worse)
-		if (const char *e = getenv("TSPWS_INV_SPLIT")) split = atoi(e) != 0;
+		if (const char *e = sweep_env("TSPWS_INV_SPLIT")) split = atoi(e) != 0;
 	}
 	for (unsigned s = 0; s < p->S;) {
 		unsigned e = s + 1;
@@ -186,7 +186,7 @@ int tspws_build_inverse(tspws_hip_plan *p)
 		// the finely decimated octaves (D < 64) come first in scale order: their waves take the LDS-staged instantiation
 		if (!oc[i].gen && oc[i].D <= inv_lds_maxd() && p->inv_waves_lds == oc[i].wave_off) p->inv_waves_lds = woff;
 	}
-	if (const char *e = getenv("TSPWS_INV_LDS")) if (*e == '0') p->inv_waves_lds = 0; // (A/B: the per-lane form for every octave)
+	if (const char *e = sweep_env("TSPWS_INV_LDS")) if (*e == '0') p->inv_waves_lds = 0; // (A/B: the per-lane form for every octave)
 	p->inv_waves = woff; p->inv_noct = (unsigned)oc.size();
 	p->oc_s0.clear(); p->oc_nv.clear(); p->oc_wave_off.clear(); p->oc_nwaves.clear(); p->oc_gen.clear();
 	for (const OctDesc &o : oc) {
@@ -204,7 +204,7 @@ int tspws_build_inverse(tspws_hip_plan *p)
 // debug build only: only the octave classes of k_inv_poly named by the hex mask TSPWS_INV_CLASSES run (results wrong: timing ablation)
 extern "C" int tspws_hip_inv_ablate(void)
 {
-	if (const char *e = getenv("TSPWS_INV_CLASSES")) {
+	if (const char *e = sweep_env("TSPWS_INV_CLASSES")) {
 		const unsigned m = (unsigned)strtoul(e, nullptr, 16);
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(inv_class_mask), &m, sizeof m));
 	}
@@ -215,7 +215,7 @@ extern "C" int tspws_hip_inv_ablate(void)
 bool tspws_generic_inverse()
 {
 	static int v = -1;
-	if (v < 0) { const char *e = getenv("TSPWS_INV_GENERIC"); v = (e && *e == '1') ? 1 : 0; }
+	if (v < 0) { const char *e = sweep_env("TSPWS_INV_GENERIC"); v = (e && *e == '1') ? 1 : 0; }
 	return v == 1;
 }
 

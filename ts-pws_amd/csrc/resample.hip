@@ -216,7 +216,7 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 	mp.valid = false;
 	struct HostTimer { // TSPWS_JK_HOSTTIME=1: what a new selection costs the host (printed per rebuild)
 		std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-		~HostTimer() { static const bool on = getenv("TSPWS_JK_HOSTTIME") != nullptr; if (on) printf("masked_plan: %.1f us of host work\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count()); }
+		~HostTimer() { static const bool on = sweep_env("TSPWS_JK_HOSTTIME") != nullptr; if (on) printf("masked_plan: %.1f us of host work\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count()); }
 	} host_timer;
 	const unsigned W = C + (with_main ? 1u : 0u);
 	mp.KM = KM; mp.gps = gps; mp.W = W;
@@ -337,7 +337,7 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 	if (!mp.direct) { // the snapshot form: segments, carries, rows as signed sums of snapshots
 	// segments: a stage's runs in ~256 / (column blocks) pieces of similar trace counts, each walked by its own workgroups
 	static int seg_wgs = -1; // workgroups the streaming side aims at per stage (sweeps: TSPWS_JK_SEGWG)
-	if (seg_wgs < 0) { const char *e = getenv("TSPWS_JK_SEGWG"); seg_wgs = e ? std::max(1, atoi(e)) : 256; }
+	if (seg_wgs < 0) { const char *e = sweep_env("TSPWS_JK_SEGWG"); seg_wgs = e ? std::max(1, atoi(e)) : 256; }
 	const unsigned bx = (unsigned)((N + 1023) / 1024), want_seg = std::max(1u, (unsigned)seg_wgs / std::max(1u, bx));
 	mp.seg_first.clear(); mp.stage_seg0.assign(nstage + 1, 0);
 	std::vector<unsigned> seg_of(nr, 0), seg_last;      // segment (global numbering) of a run; last run of a segment
@@ -455,8 +455,8 @@ static const MaskedPlan &masked_plan(size_t N, size_t mtr, const char *h_sel, un
 static unsigned masked_gps(unsigned KM)
 {
 	static int gps = -1, nst = -1;
-	if (gps < 0) { const char *e = getenv("TSPWS_JK_GPS"); gps = e ? std::max(0, atoi(e)) : 0; }
-	if (nst < 0) { const char *e = getenv("TSPWS_JK_STAGES"); nst = e ? std::max(1, atoi(e)) : 1; }
+	if (gps < 0) { const char *e = sweep_env("TSPWS_JK_GPS"); gps = e ? std::max(0, atoi(e)) : 0; }
+	if (nst < 0) { const char *e = sweep_env("TSPWS_JK_STAGES"); nst = e ? std::max(1, atoi(e)) : 1; }
 	if (gps > 0) return std::min((unsigned)gps, KM);
 	return std::max(1u, (KM + (unsigned)nst - 1) / (unsigned)nst);
 }
@@ -465,7 +465,7 @@ static unsigned masked_gps(unsigned KM)
 static bool masked_pipeline_ok(const tspws_hip_plan *pl, unsigned KM, unsigned W)
 {
 	static int off = -1;
-	if (off < 0) { const char *e = getenv("TSPWS_JK_PIPELINE"); off = (e && *e == '0') ? 1 : 0; }
+	if (off < 0) { const char *e = sweep_env("TSPWS_JK_PIPELINE"); off = (e && *e == '0') ? 1 : 0; }
 	if (off || tspws_generic_forward()) return false;
 	return (size_t)KM * W * pl->npart * sizeof(double2) <= tspws_part_budget_bytes();
 }
@@ -527,7 +527,7 @@ static int masked_stream_stage(tspws_hip_plan *pl, const MaskedPlan &mp, MaskedD
 static bool masked_allow_direct()
 {
 	static int no_direct = -1; // TSPWS_JK_DIRECT=0: the snapshot form also for few columns (tests, A/B)
-	if (no_direct < 0) { const char *e = getenv("TSPWS_JK_DIRECT"); no_direct = (e && *e == '0') ? 1 : 0; }
+	if (no_direct < 0) { const char *e = sweep_env("TSPWS_JK_DIRECT"); no_direct = (e && *e == '0') ? 1 : 0; }
 	return !no_direct;
 }
 
@@ -577,7 +577,7 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	if (!pl->xf) {
 		int lo = 0, hi = 0;
 		HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi)); // (lo = least urgent)
-		const char *e = getenv("TSPWS_JK_XFPRIO");
+		const char *e = sweep_env("TSPWS_JK_XFPRIO");
 		HIP_TRY(hipStreamCreateWithPriority(&pl->xf, hipStreamNonBlocking, e ? (atoi(e) > 0 ? hi : lo) : 0));
 	}
 	while (pl->stage_ev.size() < mp.nstage + 1) {
@@ -589,7 +589,7 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	// the last stage's forward kernel completes the stacks itself (TSPWS_JK_FINAL: 0 never, 1 always; default: with ONE stage only -- with
 	// earlier stages' plane pairs to add in front the time just moves from the accumulation into the kernel's epilogue)
 	static int fin_env = -2;
-	if (fin_env == -2) { const char *e = getenv("TSPWS_JK_FINAL"); fin_env = e ? atoi(e) : -1; }
+	if (fin_env == -2) { const char *e = sweep_env("TSPWS_JK_FINAL"); fin_env = e ? atoi(e) : -1; }
 	const bool fin_in_kernel = fin_env < 0 ? mp.nstage == 1 : fin_env != 0;
 	for (unsigned sg = 0; sg < mp.nstage; sg++) {
 		// HBM-bound half of the stage on the caller's stream: its rows from its traces

@@ -363,6 +363,10 @@ __global__ void __launch_bounds__(512) k_spec_fold(const double2 *__restrict__ X
 	for (int b = 0; b < NTB; b++)
 #pragma unroll
 		for (int s = 0; s < NS; s++) acc[b][s] = make_double2(0.0, 0.0);
+	// the group's slot descriptors in LDS for the whole walk (a scalar load + wait per slot at every completion was a chain of dependent
+	// round trips to L2 in the middle of the FMA stream; an LDS read is ~100 cycles)
+	SpecSlot *lsl = (SpecSlot *)(smem + (size_t)WG * SP_RB * 1024) + (size_t)wv * NS; // (one copy per wave: no barrier needed before its use)
+	if (lane < (unsigned)NS) lsl[lane] = sl[lane];
 	const unsigned mask0 = (1u << sl[0].ld) - 1u;   // the finest scale of the group: nothing completes before it does
 	auto xrow = [&](const unsigned c, bool &cj) -> size_t {
 		const unsigned ib = logsteps ? (__brev(c) >> (32 - logsteps)) : 0u;
@@ -444,11 +448,12 @@ __global__ void __launch_bounds__(512) k_spec_fold(const double2 *__restrict__ X
 				if (((c + 1) & mask0) == 0) {
 #pragma unroll
 					for (int s = 0; s < NS; s++) {
-						const unsigned ld = sl[s].ld;
+						const SpecSlot d = lsl[s];              // same address in every lane: broadcast
+						const unsigned ld = __builtin_amdgcn_readfirstlane(d.ld);
 						if (((c + 1) & ((1u << ld) - 1u)) != 0) break; // (partial slots carry ld = 31)
-						const unsigned lb = sl[s].lb;
+						const unsigned lb = __builtin_amdgcn_readfirstlane(d.lb);
 						const unsigned ilo = lb ? (__brev(c >> ld) >> (32 - lb)) : 0u;
-						const size_t o = (sl[s].goff + r + (size_t)R * ilo) * 64;
+						const size_t o = ((size_t)__builtin_amdgcn_readfirstlane((unsigned)d.goff) + r + (size_t)R * ilo) * 64;
 #pragma unroll
 						for (int b = 0; b < NTB; b++) { if (!(abl & 2u)) gc[b][o] = acc[b][s]; acc[b][s] = make_double2(0.0, 0.0); }
 					}
@@ -614,11 +619,11 @@ void tspws_spectral_destroy(tspws_hip_plan *p)
 	p->spec.clear();
 }
 
-// Can scale s go through the spectrum?  N a power of two >= 1024, D a power of two that divides N, at least two outputs.
+// Can scale s go through the spectrum?  N a power of two >= 1024, D a power of two >= 8 that divides N, at least two outputs.
 static bool spec_scale_ok(const tspws_hip_plan *p, unsigned s)
 {
 	const unsigned N = p->N, D = p->sc[s].D;
-	return N >= 1024 && (N & (N - 1)) == 0 && D >= 2 && (D & (D - 1)) == 0 && N % D == 0 && p->sc[s].Ns == N / D && p->sc[s].Ns >= 2 && p->sc[s].L <= N;
+	return N >= 1024 && (N & (N - 1)) == 0 && D >= 8 && (D & (D - 1)) == 0 && N % D == 0 && p->sc[s].Ns == N / D && p->sc[s].Ns >= 2 && p->sc[s].L <= N;
 }
 
 // first scale of the spectral set when every octave with at most nsmax outputs is to go through the spectrum (S: none).
@@ -649,7 +654,7 @@ static int spec_build(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, S
 	// block of a group's table stream holds 8 or 4 steps); the groups of a class share a workgroup (k_spec_fold)
 	if (nsc > 128) return fail(TSPWS_E_ARG, "spectral: more than 128 scales in the spectral set");
 	unsigned nsw = 16;
-	if (const char *e = getenv("TSPWS_SPEC_NSW")) nsw = atoi(e) <= 8 ? 8u : 16u; // sweeps
+	if (const char *e = sweep_env("TSPWS_SPEC_NSW")) nsw = atoi(e) <= 8 ? 8u : 16u; // sweeps
 	if (nsc > 8 * nsw) nsw = 16;
 	const unsigned ngroups = (nsc + nsw - 1) / nsw;
 	const unsigned per = (nsc + ngroups - 1) / ngroups, NS = per <= 8 ? 8u : 16u;
@@ -679,6 +684,7 @@ static int spec_build(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, S
 		}
 		// a group whose FIRST slot is partial never completes anything inside the loop: mask0 must not fire -- ld = 31 gives mask 2^31 - 1
 	}
+	if (rows >> 32) return fail(TSPWS_E_ARG, "spectral: folded spectra of a trace block exceed 2^32 rows");
 	sp->grows = rows;
 	HIP_TRY(hipMalloc(&sp->d_slots, slots.size() * sizeof(SpecSlot)));
 	HIP_TRY(hipMemcpy(sp->d_slots, slots.data(), slots.size() * sizeof(SpecSlot), hipMemcpyHostToDevice));
@@ -841,13 +847,13 @@ static int spectral_run(tspws_hip_plan *p, SpecDecomp *dc, const TIn *xT, unsign
 	// multiply-and-fold
 	{
 		static int ntb = -1;
-		if (ntb < 0) { const char *e = getenv("TSPWS_SPEC_NTB"); ntb = (e && atoi(e) == 1) ? 1 : 2; } // sweeps
+		if (ntb < 0) { const char *e = sweep_env("TSPWS_SPEC_NTB"); ntb = (e && atoi(e) == 1) ? 1 : 2; } // sweeps
 		const unsigned NTB = (unsigned)ntb;
-		static const unsigned abl = getenv("TSPWS_SPEC_ABL") ? (unsigned)atoi(getenv("TSPWS_SPEC_ABL")) : 0u; // timing ablations (results wrong)
+		static const unsigned abl = sweep_env("TSPWS_SPEC_ABL") ? (unsigned)atoi(sweep_env("TSPWS_SPEC_ABL")) : 0u; // timing ablations (results wrong)
 		const unsigned WG = sp->ngroups, WT = std::max(1u, 8u / WG); // (spec_build: at most 8 groups)
 		const unsigned nsets = (nblk + NTB - 1) / NTB;
 		const dim3 grid(sp->R, (nsets + WT - 1) / WT), block(64 * WG * WT);
-		const size_t lds = (size_t)WG * SP_RB * 1024;
+		const size_t lds = (size_t)WG * SP_RB * 1024 + (size_t)WG * WT * 16 * sizeof(SpecSlot);
 #define SPEC_FOLD(NSV, NT) hipLaunchKernelGGL((k_spec_fold<NSV, NT>), grid, block, lds, st, Xh, xrows, (const double2 *)sp->d_tab, (const SpecSlot *)sp->d_slots, sp->R, sp->logsteps, N, nblk, WG, G, sp->grows, abl)
 		if (NTB == 2) { if (sp->NS == 8) SPEC_FOLD(8, 2); else SPEC_FOLD(16, 2); }
 		else { if (sp->NS == 8) SPEC_FOLD(8, 1); else SPEC_FOLD(16, 1); }

@@ -49,6 +49,17 @@ int tspws_fail(int code, const char *what, hipError_t e = hipSuccess);
 
 static inline hipStream_t S_(void *s) { return (hipStream_t)s; }
 
+// Tuning / A-B / test switches are read from the environment only in builds with -DTSPWS_SWEEPS (`make sweeps`:
+// lib/libtspws_hip_sweeps.so, what tools/build_variant.sh and the engine-agreement tests load through TSPWS_LIB_PATH).  The shipped
+// library's environment is TSPWS_DEVICE / TSPWS_DEVICES / TSPWS_PLAN_CACHE (tspws_main.c), TSPWS_COMM (comm.hip), TSPWS_PART_MB,
+// TSPWS_ENGINE (forward.hip) and, in the Python binding, TSPWS_SCHEDULE / TSPWS_SHARD_FINISH -- nothing else a caller's
+// environment could reach.
+#ifdef TSPWS_SWEEPS
+static inline const char *sweep_env(const char *name) { return getenv(name); }
+#else
+static inline const char *sweep_env(const char *) { return nullptr; }
+#endif
+
 // ------------------------------------------------------------------------------------------
 // per-scale descriptor (host table sc / sc_tl, device copies d_sc / d_sc_tl)
 // ------------------------------------------------------------------------------------------
