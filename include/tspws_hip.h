@@ -265,6 +265,8 @@ const char *tspws_hip_comm_backend(const tspws_hip_comm *comm);      /* "rccl 2.
 /* In-place sum: d_bufs[i] = `count` doubles on device i; ordered on streams[i] (NULL array / entry: the communicator's
  * stream of that device).  One ncclAllReduce per device inside ncclGroupStart / ncclGroupEnd. */
 int   tspws_hip_allreduce_f64(tspws_hip_comm *comm, double *const *d_bufs, size_t count, void *const *streams);
+/* Sum into device `root` only (one ncclReduce per device): the replica rows of a sharded jackknife go to the device that finishes them. */
+int   tspws_hip_reduce_f64(tspws_hip_comm *comm, double *const *d_bufs, size_t count, int root, void *const *streams);
 /* contiguous shard of `r` of `n`: traces [*first, *first + *count) */
 void  tspws_shard_range(size_t mtr, unsigned r, unsigned n, size_t *first, size_t *count);
 

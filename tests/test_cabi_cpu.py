@@ -144,3 +144,19 @@ def test_comm_needs_a_device(lib):
     h = C.c_void_p()
     assert lib.tspws_hip_comm_create(C.byref(h), 2, None) == 5 and not h.value
     assert lib.tspws_hip_multi_create(C.byref(h), 2, None, -1, 3, 4, 2048, 2.0, 1.0, 5.336, 0) == 5 and not h.value
+
+
+def test_device_list_request_that_needs_one_device_names_the_first_listed(lib, monkeypatch, capfd):
+    """A several-device request (TSPWS_DEVICES) whose call needs the whole ensemble on ONE device -- random subsampling, convergence
+    curves -- runs on the FIRST device of the list, not on TSPWS_DEVICE's default 0 (csrc/host/tspws_main.c: run_call).  Without such
+    a device the call fails with 5 and says which device it wanted."""
+    if lib.tspws_hip_device_count() > 5:
+        pytest.skip("device 5 exists here")
+    monkeypatch.setenv("TSPWS_DEVICES", "5,6")
+    monkeypatch.delenv("TSPWS_DEVICE", raising=False)
+    X = abi.synth_traces(8, 256, seed=2)
+    r = abi.run_main(lib.tspws_main, abi.default_params(subsmpl_N=2, subsmpl_p=0.5), X)
+    assert r["rc"] == 5
+    C.CDLL(None).fflush(None)                            # (the library prints through libc's stdout buffer)
+    out = capfd.readouterr().out
+    assert "no usable HIP device 5" in out, out

@@ -225,3 +225,87 @@ def test_device_list_call_fails_after_the_prologue_like_the_reference(lib, monke
         assert not got["ls"].any() and not got["tsPWS"].any()
     finally:
         lib.tspws_main_release()
+
+
+def test_reduce_to_owner_on_the_local_backend(lib, torch):
+    """tspws_hip_reduce_f64: the sum lands on the root only (list order), the other buffers keep their contents -- what the sharded
+    jackknife uses for the replica rows of a block's owner."""
+    h = C.c_void_p()
+    devs = (C.c_int * 3)(0, 0, 0)
+    tspws.check(lib.tspws_hip_comm_create(C.byref(h), 3, devs), "comm_create")
+    try:
+        rng = np.random.default_rng(4)
+        host = [rng.standard_normal(50003) for _ in range(3)]
+        for root in (0, 2):
+            bufs = [torch.as_tensor(a, device="cuda") for a in host]
+            ptrs = (C.c_void_p * 3)(*[b.data_ptr() for b in bufs])
+            torch.cuda.synchronize()
+            tspws.check(lib.tspws_hip_reduce_f64(h, ptrs, 50003, root, None), "reduce")
+            for i in range(3):
+                tspws.check(lib.tspws_hip_sync(lib.tspws_hip_comm_stream(h, i)), "sync")
+            want = (host[0] + host[1]) + host[2]
+            for i, b in enumerate(bufs):
+                np.testing.assert_array_equal(b.cpu().numpy(), want if i == root else host[i])
+    finally:
+        lib.tspws_hip_comm_destroy(h)
+
+
+@pytest.mark.parametrize("kw,mtr,N,ndev", [(dict(Kmax=10, unbiased=1), 96, 8192, 8), (dict(Kmax=7), 50, 4096, 3), (dict(Kmax=10, unbiased=1), 37, 3001, 4)])
+def test_c_schedules_of_the_device_list_call(lib, torch, monkeypatch, kw, mtr, N, ndev):
+    """tspws_hip_multi_stack places the one logical reduction by TSPWS_SCHEDULE like ts-pws_amd.stack_sharded: `single` and `split`
+    (pieces on the communicator's second streams, finish in pieces on the first device) are bit-identical on integer-valued traces
+    -- every partial sum is exact --, `sharded-finish` ends its sum over octaves in another order (1e-6).  Virtual shards of the one GPU."""
+    X = torch.round(tspws.synth(mtr, N, seed=63) * 64.0).contiguous()     # integers / 64: FP64 sums are exact in any order
+    out = {}
+    for sch in ("single", "split", "sharded-finish"):
+        monkeypatch.setenv("TSPWS_SCHEDULE", sch)
+        out[sch] = _multi_stack(lib, torch, abi.default_params(**kw), X, [0] * ndev)
+    monkeypatch.setenv("TSPWS_SCHEDULE", "nonsense")
+    with pytest.raises(tspws.TspwsError):
+        _multi_stack(lib, torch, abi.default_params(**kw), X, [0] * ndev)
+    monkeypatch.delenv("TSPWS_SCHEDULE")
+    np.testing.assert_array_equal(out["single"][0], out["split"][0])
+    np.testing.assert_array_equal(out["single"][1], out["split"][1])
+    assert abi.relerr(out["sharded-finish"][0], out["single"][0]) < 1e-6 and abi.relerr(out["sharded-finish"][1], out["single"][1]) < 1e-6
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), X.cpu().numpy())
+    assert abi.relerr(out["single"][0], want["ls"]) < TOL32 and abi.relerr(out["single"][1], want["tsPWS"]) < TOL32
+
+
+def test_upload_over_a_device_list_in_pieces(lib, torch):
+    """tspws_hip_multi_upload pins the host array in page-aligned 128-MB pieces cut over the WHOLE array and lets every device copy
+    its shard as soon as its first piece is pinned: shards that start and end in the middle of pieces (and of pages) arrive byte for byte."""
+    N, mtr, ndev = 8192 + 4, 11003, 3                       # 361 MB: three pieces; shard boundaries inside pieces, rows not page-sized
+    p = tspws.resolve(abi.default_params(Kmax=4), 8192)
+    m = C.c_void_p()
+    arr = (C.c_int * ndev)(*([0] * ndev))
+    tspws.check(lib.tspws_hip_multi_create(C.byref(m), ndev, arr, p.type, p.J, p.V, 8192, p.s0, p.b0, p.w0, int(p.uni)), "multi_create")
+    try:
+        raw = np.random.default_rng(8).integers(0, 1 << 30, mtr * N + 1024 + 7, dtype=np.int32).view(np.float32)
+        off = ((-raw.ctypes.data) % 4096) // 4 + 5          # 20 bytes into a page
+        H = raw[off:off + mtr * N].reshape(mtr, N)
+        sh, dl, dt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        tspws.check(lib.tspws_hip_multi_upload(m, H.ctypes.data, N, mtr, C.byref(sh), C.byref(dl), C.byref(dt)), "multi_upload")
+        shards = C.cast(sh, C.POINTER(C.c_void_p))
+        for r in range(ndev):
+            f, c = tspws.shard_range(mtr, r, ndev)
+            got = np.empty((c, N), np.float32)
+            assert lib.tspws_hip_download(C.c_void_p(got.ctypes.data), C.c_void_p(shards[r]), C.c_size_t(got.nbytes), None) == 0
+            assert np.array_equal(got.view(np.int32), H[f:f + c].view(np.int32)), r
+    finally:
+        lib.tspws_hip_multi_destroy(m)
+
+
+def test_device_list_request_runs_on_the_first_listed_device(lib, monkeypatch):
+    """Random subsampling under TSPWS_DEVICES: one device only, and it is the first of the list -- "7,7" has no such device on this box
+    and must fail (5) instead of running on device 0; "0,0" gives the single-device result."""
+    X = abi.synth_traces(12, 1024, seed=5)
+    kw = dict(subsmpl_N=2, subsmpl_p=0.5)
+    abi.srand(3)
+    want = abi.run_main(lib.tspws_main, abi.default_params(**kw), X)
+    monkeypatch.setenv("TSPWS_DEVICES", "0,0")
+    abi.srand(3)
+    got = abi.run_main(lib.tspws_main, abi.default_params(**kw), X)
+    assert got["rc"] == 0 and np.array_equal(got["sub_ts"], want["sub_ts"]) and np.array_equal(got["tsPWS"], want["tsPWS"])
+    if lib.tspws_hip_device_count() <= 7:
+        monkeypatch.setenv("TSPWS_DEVICES", "7,7")
+        assert abi.run_main(lib.tspws_main, abi.default_params(**kw), X)["rc"] == 5

@@ -133,6 +133,7 @@ SYMBOLS = {
     "tspws_hip_comm_stream": (_vp, [_vp, _i]),
     "tspws_hip_comm_backend": (C.c_char_p, [_vp]),
     "tspws_hip_allreduce_f64": (_i, [_vp, _vp, _sz, _vp]),
+    "tspws_hip_reduce_f64": (_i, [_vp, _vp, _sz, _i, _vp]),
     "tspws_shard_range": (None, [_sz, _u, _u, C.POINTER(_sz), C.POINTER(_sz)]),
     "tspws_hip_multi_create": (_i, [C.POINTER(_vp), _i, _vp, _i, _u, _u, _u, _d, _d, _d, _i]),
     "tspws_hip_multi_destroy": (None, [_vp]),

@@ -66,7 +66,9 @@ struct tspws_hip_comm {
 	std::vector<int> dev;
 	std::vector<ncclComm_t> comms;
 	std::vector<hipStream_t> streams;   // one per list entry
+	std::vector<hipStream_t> rstreams;  // ... and a second one per entry: reductions that run beside the streaming of the next piece
 	std::vector<hipEvent_t> ev;         // local backend: "buffer i is ready" / "sum is ready"
+	std::vector<hipEvent_t> ev_a, ev_b; // hand-over between streams[i] and rstreams[i] (tspws_hip_multi_stack's pieces)
 	hipEvent_t ev_sum = nullptr;
 	double **d_ptrs = nullptr;          // local backend: device copy of the buffer pointers
 };
@@ -108,12 +110,24 @@ extern "C" int tspws_hip_comm_create(tspws_hip_comm **out, int ndev, const int *
 		return fail(TSPWS_E_ARG, "comm_create: the local backend (TSPWS_COMM=local / a repeated device) takes one physical device only; distinct devices reduce through RCCL");
 	}
 	for (int i = 0; i < ndev; i++) {
-		hipStream_t s = nullptr;
-		hipEvent_t ev = nullptr;
+		hipStream_t s = nullptr, s2 = nullptr;
+		hipEvent_t ev = nullptr, ea = nullptr, eb = nullptr;
 		if (hipSetDevice(c->dev[i]) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
-		    hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { tspws_hip_comm_destroy(c); return fail(TSPWS_E_HIP, "comm_create: streams"); }
+		    hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&ea, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess) {
+			if (s) c->streams.push_back(s);
+			if (s2) c->rstreams.push_back(s2);
+			if (ev) c->ev.push_back(ev);
+			if (ea) c->ev_a.push_back(ea);
+			if (eb) c->ev_b.push_back(eb);
+			tspws_hip_comm_destroy(c);
+			return fail(TSPWS_E_HIP, "comm_create: streams");
+		}
 		c->streams.push_back(s);
+		c->rstreams.push_back(s2);
 		c->ev.push_back(ev);
+		c->ev_a.push_back(ea);
+		c->ev_b.push_back(eb);
 	}
 	if (c->local) {
 		(void)hipSetDevice(c->dev[0]);
@@ -137,7 +151,10 @@ extern "C" void tspws_hip_comm_destroy(tspws_hip_comm *c)
 	if (!c) return;
 	for (size_t i = 0; i < c->comms.size(); i++) if (c->comms[i]) (void)g_rccl.CommDestroy(c->comms[i]);
 	for (size_t i = 0; i < c->streams.size(); i++) { (void)hipSetDevice(c->dev[i]); (void)hipStreamDestroy(c->streams[i]); }
+	for (size_t i = 0; i < c->rstreams.size(); i++) { (void)hipSetDevice(c->dev[i]); (void)hipStreamDestroy(c->rstreams[i]); }
 	for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+	for (hipEvent_t e : c->ev_a) (void)hipEventDestroy(e);
+	for (hipEvent_t e : c->ev_b) (void)hipEventDestroy(e);
 	if (c->ev_sum) (void)hipEventDestroy(c->ev_sum);
 	if (c->d_ptrs) (void)hipFree(c->d_ptrs);
 	delete c;
@@ -187,6 +204,56 @@ extern "C" int tspws_hip_allreduce_f64(tspws_hip_comm *c, double *const *d_bufs,
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(c->ev_sum, st(0)));
 	for (int i = 1; i < c->ndev; i++) {
+		HIP_TRY(hipSetDevice(c->dev[i]));
+		HIP_TRY(hipStreamWaitEvent(st(i), c->ev_sum, 0));
+	}
+	return 0;
+}
+
+// buf[root][i] = buf[0][i] + buf[1][i] + ... in list order; the other buffers are left alone
+__global__ void __launch_bounds__(256) k_local_reduce(double *const *__restrict__ bufs, int n, int root, size_t count)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= count) return;
+	double a = bufs[0][i];
+	for (int r = 1; r < n; r++) a += bufs[r][i];
+	bufs[root][i] = a;
+}
+
+// Sum over the devices into device `root` only (the replica rows of a jackknife: one owner finishes them): d_bufs[i] holds `count`
+// doubles on device i; ordered on streams[i] like tspws_hip_allreduce_f64.  Several calls may be grouped by the caller's order only --
+// each call is its own RCCL group.
+extern "C" int tspws_hip_reduce_f64(tspws_hip_comm *c, double *const *d_bufs, size_t count, int root, void *const *streams)
+{
+	if (!c || !d_bufs || root < 0 || root >= c->ndev) return fail(TSPWS_E_ARG, "reduce: bad argument");
+	if (!count) return 0;
+	auto st = [&](int i) { return streams && streams[i] ? (hipStream_t)streams[i] : c->streams[i]; };
+	if (!c->local) {
+		if (c->ndev == 1 && !getenv("TSPWS_COMM")) return 0;
+		NCCL_TRY(g_rccl.GroupStart());
+		for (int i = 0; i < c->ndev; i++) {
+			const ncclResult_t r = g_rccl.Reduce(d_bufs[i], d_bufs[i], count, ncclDouble, ncclSum, root, c->comms[i], st(i));
+			if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return nccl_fail("ncclReduce", r); }
+		}
+		NCCL_TRY(g_rccl.GroupEnd());
+		return 0;
+	}
+	// local backend: every stream signals its buffer, the root's stream adds them in list order
+	for (int i = 0; i < c->ndev; i++) {
+		if (i == root) continue;
+		HIP_TRY(hipSetDevice(c->dev[i]));
+		HIP_TRY(hipEventRecord(c->ev[i], st(i)));
+	}
+	HIP_TRY(hipSetDevice(c->dev[root]));
+	for (int i = 0; i < c->ndev; i++) if (i != root) HIP_TRY(hipStreamWaitEvent(st(root), c->ev[i], 0));
+	HIP_TRY(hipMemcpyAsync(c->d_ptrs, d_bufs, c->ndev * sizeof(double *), hipMemcpyHostToDevice, st(root)));
+	HIP_TRY(hipStreamSynchronize(st(root))); // (the pointer table is caller memory)
+	hipLaunchKernelGGL(k_local_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st(root), (double *const *)c->d_ptrs, c->ndev, root, count);
+	HIP_TRY(hipGetLastError());
+	// (the other streams may reuse their buffers only after the sum has read them)
+	HIP_TRY(hipEventRecord(c->ev_sum, st(root)));
+	for (int i = 0; i < c->ndev; i++) {
+		if (i == root) continue;
 		HIP_TRY(hipSetDevice(c->dev[i]));
 		HIP_TRY(hipStreamWaitEvent(st(i), c->ev_sum, 0));
 	}
@@ -247,9 +314,12 @@ extern "C" int tspws_hip_multi_create(tspws_hip_multi **out, int ndev, const int
 	return 0;
 }
 
-// Host traces -> shards: the host array is pinned once (portable: every device can pull from it) and every device copies
-// ITS shard on its own stream, so the PCIe links of all devices run at the same time.  *d_shards = the per-device buffers
-// (owned by m, kept for the next call); *d_ls / *d_ts = the output buffers on the first device.
+// Host traces -> shards: the host array is pinned (portable: every device can pull from it) in page-aligned 128-MB pieces and every
+// device copies ITS shard on its own stream, so the PCIe links of all devices run at the same time -- and every device starts as soon
+// as the first piece of its shard is pinned (one blocking registration of the whole array in front of all copies was 10 ms / GB:
+// 52 GB at BASELINE configs[4]).  The pieces are cut over the WHOLE array (two registrations must not share a page; a piece that
+// straddles a shard boundary is registered once and copied in two parts) and handed out round-robin over the devices.
+// *d_shards = the per-device buffers (owned by m, kept for the next call); *d_ls / *d_ts = the output buffers on the first device.
 extern "C" int tspws_hip_multi_upload(tspws_hip_multi *m, const float *h_sigall, size_t ld, size_t mtr, const float *const **d_shards, float **d_ls,
                                       float **d_ts)
 {
@@ -257,13 +327,13 @@ extern "C" int tspws_hip_multi_upload(tspws_hip_multi *m, const float *h_sigall,
 	tspws_hip_comm *c = m->comm;
 	const int n = c->ndev;
 	const size_t total = mtr * ld * sizeof(float);
-	const bool pinned = total >= ((size_t)32 << 20) && hipHostRegister(const_cast<float *>(h_sigall), total, hipHostRegisterPortable) == hipSuccess;
-	if (!pinned) (void)hipGetLastError();
 	int rc = 0;
+	std::vector<uintptr_t> s0(n), s1(n); // host byte range of every shard
 	for (int r = 0; r < n && !rc; r++) {
 		size_t first, count;
 		tspws_shard_range(mtr, (unsigned)r, (unsigned)n, &first, &count);
 		const size_t bytes = count * ld * sizeof(float);
+		s0[r] = (uintptr_t)(h_sigall + first * ld); s1[r] = s0[r] + bytes;
 		if (hipSetDevice(c->dev[r]) != hipSuccess) { rc = fail(TSPWS_E_HIP, "multi_upload: device"); break; }
 		if (m->shard_bytes[r] < bytes) {
 			if (m->d_shard[r]) (void)hipFree(m->d_shard[r]);
@@ -271,11 +341,38 @@ extern "C" int tspws_hip_multi_upload(tspws_hip_multi *m, const float *h_sigall,
 			if (hipMalloc(&m->d_shard[r], std::max<size_t>(bytes, 16)) != hipSuccess) { rc = fail(TSPWS_E_NOMEM, "multi_upload: device allocation"); break; }
 			m->shard_bytes[r] = bytes;
 		}
-		if (bytes && hipMemcpyAsync(m->d_shard[r], h_sigall + first * ld, bytes, hipMemcpyHostToDevice, c->streams[r]) != hipSuccess)
-			rc = fail(TSPWS_E_HIP, "multi_upload: copy");
+	}
+	if (rc) return rc;
+	const size_t piece = (size_t)128 << 20;
+	const uintptr_t h0 = (uintptr_t)h_sigall, h1 = h0 + total;
+	const bool pin = total >= ((size_t)32 << 20);
+	const size_t npieces = total ? (total + piece - 1) / piece : 0;
+	auto cut = [&](size_t k) -> uintptr_t { if (k == 0) return h0; if (k >= npieces) return h1; return std::min((h0 + k * piece + 4095) & ~(uintptr_t)4095, h1); };
+	std::vector<char> state(npieces, 0); // 0: untouched, 1: registered, 2: registration failed (travels pageable)
+	std::vector<size_t> next(n);         // next piece of every shard
+	for (int r = 0; r < n; r++) { size_t k = 0; while (k < npieces && cut(k + 1) <= s0[r]) k++; next[r] = k; }
+	bool more = true;
+	while (more && !rc) {
+		more = false;
+		for (int r = 0; r < n && !rc; r++) {
+			const size_t k = next[r];
+			if (k >= npieces || cut(k) >= s1[r] || s0[r] == s1[r]) continue;
+			more = true;
+			next[r] = k + 1;
+			const uintptr_t a = cut(k), b = cut(k + 1);
+			if (pin && state[k] == 0) {
+				if (b > a && hipHostRegister((void *)a, b - a, hipHostRegisterPortable) == hipSuccess) state[k] = 1;
+				else { (void)hipGetLastError(); state[k] = 2; }
+			}
+			const uintptr_t lo = std::max(a, s0[r]), hi = std::min(b, s1[r]);
+			if (hi <= lo) continue;
+			if (hipSetDevice(c->dev[r]) != hipSuccess ||
+			    hipMemcpyAsync((char *)m->d_shard[r] + (lo - s0[r]), (const void *)lo, hi - lo, hipMemcpyHostToDevice, c->streams[r]) != hipSuccess)
+				rc = fail(TSPWS_E_HIP, "multi_upload: copy");
+		}
 	}
 	for (int r = 0; r < n; r++) { (void)hipSetDevice(c->dev[r]); if (hipStreamSynchronize(c->streams[r]) != hipSuccess && !rc) rc = fail(TSPWS_E_HIP, "multi_upload: sync"); }
-	if (pinned) (void)hipHostUnregister(const_cast<float *>(h_sigall));
+	for (size_t k = 0; k < npieces; k++) if (state[k] == 1) (void)hipHostUnregister((void *)cut(k));
 	if (rc) return rc;
 	*d_shards = (const float *const *)m->d_shard.data();
 	if (d_ls) *d_ls = m->d_out;
@@ -308,41 +405,122 @@ extern "C" int tspws_hip_multi_prologue(tspws_hip_multi *m, float *h_sigall, siz
 extern "C" tspws_hip_comm *tspws_hip_multi_comm(tspws_hip_multi *m) { return m ? m->comm : nullptr; }
 extern "C" tspws_hip_plan *tspws_hip_multi_plan(tspws_hip_multi *m, int i) { return (m && i >= 0 && i < (int)m->plans.size()) ? m->plans[i] : nullptr; }
 
+// First piece of the two-piece streaming / reduction schedule (the Python binding's split_groups): redundant finish -- about half the
+// groups, the second reduction then hides behind the transforms of the first half; scale-sharded finish (nothing to hide behind) -- all
+// but the last two groups; even when possible (the streaming pass launches the groups two at a time).
+static unsigned multi_split_groups(unsigned K, bool sharded_finish)
+{
+	unsigned half = (sharded_finish && K > 3) ? K - 2 : K / 2;
+	if (half >= 2 && (half & 1)) half--;
+	return half;
+}
+
 // One tspws_main-equivalent call over trace shards that already sit on the devices: d_shards[r] = traces
 // [first_r, first_r + count_r) of the ensemble (tspws_shard_range) on device r, row stride ld.  d_ls / d_ts (max floats each)
 // live on device 0.  All work is ordered on the communicator's streams; returns after synchronising them.
+// The ONE logical fp64 reduction of the stage-1 buffer is placed by TSPWS_SCHEDULE exactly as in ts-pws_amd.stack_sharded (one process
+// per GPU): "single" = local halves, one all-reduce of the whole buffer, finish on the first device; "split" = the groups in two pieces,
+// the first reduction (on the communicator's second streams) beside the streaming of the second piece, the second beside the
+// transforms of the first piece; "sharded-finish" (default) = pieces K - 2 | 2 + the finish stage split by scales over the devices.
 extern "C" int tspws_hip_multi_stack(tspws_hip_multi *m, const t_tsPWS *p, const float *const *d_shards, size_t ld, size_t mtr, float *d_ls,
                                      float *d_ts)
 {
 	if (!m || !p || !d_shards || !d_ls || !d_ts || !mtr) return fail(TSPWS_E_ARG, "multi_stack: bad argument");
 	tspws_hip_comm *c = m->comm;
 	const int n = c->ndev;
+	const size_t N = m->plans[0]->N;
+	const unsigned K = p->Kmax;
 	int rc;
+	const char *se = getenv("TSPWS_SCHEDULE");
+	int schedule = 2; // 0 single, 1 split, 2 sharded-finish
+	if (se && *se) {
+		if (!strcmp(se, "single")) schedule = 0; else if (!strcmp(se, "split")) schedule = 1; else if (!strcmp(se, "sharded-finish")) schedule = 2;
+		else return fail(TSPWS_E_ARG, "multi_stack: TSPWS_SCHEDULE must be single, split or sharded-finish");
+	}
 	std::vector<double *> bufs(n);
 	size_t nd = 0;
-	// local halves, one device after the other: every call below only enqueues work on that device's stream
-	for (int r = 0; r < n; r++) {
-		size_t first, count;
-		tspws_shard_range(mtr, (unsigned)r, (unsigned)n, &first, &count);
-		if ((rc = tspws_hip_stack_local(m->plans[r], p, d_shards[r], ld, count, first, mtr, c->streams[r]))) return rc;
-		if ((rc = tspws_hip_reduce_buffer(m->plans[r], p, mtr, &bufs[r], &nd))) return rc;
-	}
-	if ((rc = tspws_hip_allreduce_f64(c, bufs.data(), nd, nullptr))) return rc;
-	// finish stage: by scales over the devices when every plan can (two-stage, polyphase kernels), else device 0 alone
+	for (int r = 0; r < n; r++) if ((rc = tspws_hip_reduce_buffer(m->plans[r], p, mtr, &bufs[r], &nd))) return rc;
+	// finish stage by scales over the devices when every plan can (two-stage, polyphase kernels)
 	std::vector<unsigned> s0(n), s1(n);
-	bool sharded = n > 1;
+	bool sharded = n > 1 && schedule == 2;
 	for (int r = 0; r < n && sharded; r++) {
 		const int q = tspws_hip_finish_shard(m->plans[r], p, mtr, (unsigned)r, (unsigned)n, &s0[r], &s1[r]);
 		if (q == 1) sharded = false; else if (q) return q;
 	}
-	if (sharded) {
-		for (int r = 0; r < n; r++)
-			if ((rc = tspws_hip_stack_finish_scales(m->plans[r], p, mtr, s0[r], s1[r], m->x2[r], c->streams[r]))) return rc;
-		if ((rc = tspws_hip_allreduce_f64(c, m->x2.data(), 2 * (size_t)m->plans[0]->N, nullptr))) return rc;
-		HIP_TRY(hipSetDevice(c->dev[0]));
-		if ((rc = tspws_hip_epilogue(d_ls, d_ts, m->x2[0] + m->plans[0]->N, m->x2[0], m->plans[0]->N, (unsigned)mtr, c->streams[0]))) return rc;
-	} else if ((rc = tspws_hip_stack_finish(m->plans[0], p, mtr, d_ls, d_ts, c->streams[0]))) return rc;
-	for (int r = 0; r < n; r++) { HIP_TRY(hipSetDevice(c->dev[r])); HIP_TRY(hipStreamSynchronize(c->streams[r])); }
+	const bool two_stage = tspws_is_two_stage(p, mtr);
+	const bool pieces = n > 1 && schedule != 0 && two_stage && K >= 2;
+	if (!pieces) {
+		// local halves, one device after the other: every call below only enqueues work on that device's stream
+		for (int r = 0; r < n; r++) {
+			size_t first, count;
+			tspws_shard_range(mtr, (unsigned)r, (unsigned)n, &first, &count);
+			if ((rc = tspws_hip_stack_local(m->plans[r], p, d_shards[r], ld, count, first, mtr, c->streams[r]))) return rc;
+		}
+		if ((rc = tspws_hip_allreduce_f64(c, bufs.data(), nd, nullptr))) return rc;
+		if (sharded) {
+			for (int r = 0; r < n; r++)
+				if ((rc = tspws_hip_stack_finish_scales(m->plans[r], p, mtr, s0[r], s1[r], m->x2[r], c->streams[r]))) return rc;
+			if ((rc = tspws_hip_allreduce_f64(c, m->x2.data(), 2 * N, nullptr))) return rc;
+			HIP_TRY(hipSetDevice(c->dev[0]));
+			if ((rc = tspws_hip_epilogue(d_ls, d_ts, m->x2[0] + N, m->x2[0], N, (unsigned)mtr, c->streams[0]))) return rc;
+		} else if ((rc = tspws_hip_stack_finish(m->plans[0], p, mtr, d_ls, d_ts, c->streams[0]))) return rc;
+	} else {
+		const unsigned half = std::max(1u, multi_split_groups(K, sharded));
+		std::vector<void *> rs(n);
+		std::vector<double *> b2(n);
+		for (int r = 0; r < n; r++) { rs[r] = (void *)c->rstreams[r]; b2[r] = bufs[r] + (size_t)half * N; }
+		auto stream_piece = [&](unsigned g0, unsigned g1) -> int {
+			for (int r = 0; r < n; r++) {
+				size_t first, count;
+				tspws_shard_range(mtr, (unsigned)r, (unsigned)n, &first, &count);
+				HIP_TRY(hipSetDevice(c->dev[r]));
+				if (int q = tspws_hip_partial_stacks_range(m->plans[r], d_shards[r], ld, count, first, mtr, K, g0, g1, bufs[r], N, c->streams[r])) return q;
+			}
+			return 0;
+		};
+		auto hand_over = [&](std::vector<hipEvent_t> &ev, bool to_reduce) -> int { // streams[r] -> rstreams[r] (or back)
+			for (int r = 0; r < n; r++) {
+				HIP_TRY(hipSetDevice(c->dev[r]));
+				HIP_TRY(hipEventRecord(ev[r], to_reduce ? c->streams[r] : c->rstreams[r]));
+				HIP_TRY(hipStreamWaitEvent(to_reduce ? c->rstreams[r] : c->streams[r], ev[r], 0));
+			}
+			return 0;
+		};
+		// piece 1 streamed; its reduction on the second streams while piece 2 is streamed
+		if ((rc = stream_piece(0, half))) return rc;
+		if ((rc = hand_over(c->ev_a, true))) return rc;
+		if ((rc = tspws_hip_allreduce_f64(c, bufs.data(), (size_t)half * N, rs.data()))) return rc;
+		if ((rc = stream_piece(half, K))) return rc;
+		if (sharded) {
+			// both reductions, then every device transforms / weights / reconstructs its share of the scales
+			if ((rc = hand_over(c->ev_b, true))) return rc;
+			if ((rc = tspws_hip_allreduce_f64(c, b2.data(), (size_t)(K - half) * N, rs.data()))) return rc;
+			if ((rc = hand_over(c->ev_a, false))) return rc;
+			for (int r = 0; r < n; r++)
+				if ((rc = tspws_hip_stack_finish_scales(m->plans[r], p, mtr, s0[r], s1[r], m->x2[r], c->streams[r]))) return rc;
+			if ((rc = tspws_hip_allreduce_f64(c, m->x2.data(), 2 * N, nullptr))) return rc;
+			HIP_TRY(hipSetDevice(c->dev[0]));
+			if ((rc = tspws_hip_epilogue(d_ls, d_ts, m->x2[0] + N, m->x2[0], N, (unsigned)mtr, c->streams[0]))) return rc;
+		} else {
+			// the first device transforms the reduced first piece while the second piece is being reduced
+			HIP_TRY(hipSetDevice(c->dev[0]));
+			HIP_TRY(hipEventRecord(c->ev_a[0], c->rstreams[0])); // (first reduction done on device 0)
+			if ((rc = hand_over(c->ev_b, true))) return rc;
+			if ((rc = tspws_hip_allreduce_f64(c, b2.data(), (size_t)(K - half) * N, rs.data()))) return rc;
+			HIP_TRY(hipSetDevice(c->dev[0]));
+			HIP_TRY(hipStreamWaitEvent(c->streams[0], c->ev_a[0], 0));
+			if ((rc = tspws_hip_stack_finish_range(m->plans[0], p, mtr, 0, half, c->streams[0]))) return rc;
+			HIP_TRY(hipEventRecord(c->ev_b[0], c->rstreams[0])); // (second reduction done)
+			HIP_TRY(hipStreamWaitEvent(c->streams[0], c->ev_b[0], 0));
+			if ((rc = tspws_hip_stack_finish_range(m->plans[0], p, mtr, half, K, c->streams[0]))) return rc;
+			if ((rc = tspws_hip_stack_finish_tail(m->plans[0], p, mtr, d_ls, d_ts, c->streams[0]))) return rc;
+		}
+	}
+	for (int r = 0; r < n; r++) {
+		HIP_TRY(hipSetDevice(c->dev[r]));
+		HIP_TRY(hipStreamSynchronize(c->rstreams[r]));
+		HIP_TRY(hipStreamSynchronize(c->streams[r]));
+	}
 	return 0;
 }
 
@@ -370,7 +548,16 @@ extern "C" int tspws_hip_multi_stack_jackknife(tspws_hip_multi *m, const t_tsPWS
 		if ((rc = tspws_hip_jackknife_buffer(m->plans[r], p, C, &rows[r], &nr))) return rc;
 	}
 	if ((rc = tspws_hip_allreduce_f64(c, bufs.data(), nd, nullptr))) return rc;
-	if ((rc = tspws_hip_allreduce_f64(c, rows.data(), nr, nullptr))) return rc;
+	// the replicas' rows go to their OWNER only (device r finishes the block [r C / n, (r + 1) C / n)): one reduction per owner instead
+	// of an all-reduce of all C Kmax N doubles on every device -- as ts-pws_amd.jackknife_sharded does
+	(void)nr;
+	for (int r = 0; r < n; r++) {
+		const unsigned c0 = (unsigned)((size_t)r * C / n), c1 = (unsigned)((size_t)(r + 1) * C / n);
+		if (c1 == c0) continue;
+		std::vector<double *> blk(n);
+		for (int q = 0; q < n; q++) blk[q] = rows[q] + (size_t)c0 * p->Kmax * N;
+		if ((rc = tspws_hip_reduce_f64(c, blk.data(), (size_t)(c1 - c0) * p->Kmax * N, r, nullptr))) return rc;
+	}
 	if ((rc = tspws_hip_stack_finish(m->plans[0], p, mtr, d_ls, d_ts, c->streams[0]))) return rc;
 	// every device finishes ITS block of replicas at the same time: one host thread per device (the finish call synchronises
 	// its stream, and the current device is a per-thread setting)

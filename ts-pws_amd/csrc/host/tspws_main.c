@@ -68,6 +68,7 @@ static struct {
 	double ms0, mb0, mw0;
 } g_cache;
 static pthread_mutex_t g_multi_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_mutex_t g_rand_lock = PTHREAD_MUTEX_INITIALIZER;  /* one call's libc rand() draws (subsampling masks) stay contiguous */
 
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
 static void init_slots(void)
@@ -328,7 +329,11 @@ static int run_call(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in, int dev, int a
 		const size_t K = (size_t)ceil((double)mtr * tspws->subsmpl_p);
 		sub_sel = (char *)malloc((size_t)M * mtr);
 		if (!sub_sel) return 4;
+		/* one call's draws stay contiguous in libc's rand() stream when callers on several devices arrive together (each call used to
+		 * draw under the one global lock of the library) */
+		pthread_mutex_lock(&g_rand_lock);
 		for (unsigned m = 0; m < M; m++) tspws_subsampling_plan(sub_sel + (size_t)m * mtr, mtr, K);
+		pthread_mutex_unlock(&g_rand_lock);
 	}
 
 	int devs[TSPWS_MAX_DEVICES];
@@ -336,16 +341,19 @@ static int run_call(t_tsPWS *tspws, t_tsPWS_out *out, t_data *in, int dev, int a
 	/* a one-entry TSPWS_DEVICES names THE device of the call (the sharded path on one device only under TSPWS_COMM: tests) */
 	if (ndev == 1 && !getenv("TSPWS_COMM")) { dev = devs[0]; ndev = 0; }
 
+	/* several devices (or TSPWS_COMM set: the sharded path even on one device -- tests); convergence curves and random subsampling
+	 * need the whole ensemble in one place: such a call runs on the FIRST device of the list, not on TSPWS_DEVICE's default */
+	const int needs_one = (tspws->convergence && out->ls_sim && out->tsPWS_sim && out->ls_misfit && out->tsPWS_misfit) ||
+	                      (tspws->subsmpl_N > 0 && tspws->subsmpl_p > 0 && out->ls_subsmpl && out->tsPWS_subsmpl);
+	if (ndev >= 1) dev = devs[0];
 	if (dev < 0 || dev >= TSPWS_MAX_DEVICES || tspws_hip_device_count() <= dev) {
-		printf("tspws_main: no usable HIP device (%s)\n", tspws_hip_last_error());
+		printf("tspws_main: no usable HIP device %d (%s)\n", dev, tspws_hip_last_error());
 		free(sub_sel);
 		return TSPWS_E_NODEV;
 	}
 	pthread_once(&g_once, init_slots);
 
-	if (ndev >= 1) { /* several devices (or TSPWS_COMM set: the sharded path even on one device -- tests) */
-		const int needs_one = (tspws->convergence && out->ls_sim && out->tsPWS_sim && out->ls_misfit && out->tsPWS_misfit) ||
-		                      (tspws->subsmpl_N > 0 && tspws->subsmpl_p > 0 && out->ls_subsmpl && out->tsPWS_subsmpl);
+	if (ndev >= 1) {
 		if (!needs_one && tspws->J && tspws->V) {
 			free(sub_sel);
 			pthread_mutex_lock(&g_multi_lock);
