@@ -556,6 +556,9 @@ def other_configs(abi, tspws, lib, torch, X, N):
         pl4.stack_jackknife(X, sel_b if flip[0] else sel)
     sec_changed = timeit(torch, changed, 10, 2)
     alg = 4.0 * mtr * N + 8.0 * N + 8.0 * 10 * N + 8.0 * Cn * N
+    tab4 = pl4.tables()
+    macs4 = float(np.sum(tab4["L"].astype(np.float64) * tab4["Ns"].astype(np.float64)))
+    flops4 = 4.0 * macs4 * 10 * (Cn + 1)   # K = 10 transforms for the stack and for every replica
     nsub = min(mtr, 1000)
     sel_s = np.zeros((Cn, nsub), np.int8)
     assert lib.tspws_jackknife_plan(sel_s.ctypes.data, times.ctypes.data, nsub, 1, 10, Cn) == 0
@@ -570,6 +573,10 @@ def other_configs(abi, tspws, lib, torch, X, N):
                      "frac": alg / sec / 1e9 / HBM_PEAK_GBS,
                      "note": "every sample read once (the stack and all replicas share ONE pass) + K partials + outputs; the 110 transforms "
                              "(3.6e10 flop) are as long as the stream"},
+        "roofline_fp64": {"bound": "fp64 vector", "flops_per_call": flops4, "achieved": flops4 / sec / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": flops4 / sec / 1e12 / FP64_PEAK_TFLOPS,
+                          "note": "the call's second bound: forward MACs of its 110 transforms (4 flop each) over the WHOLE call time -- the streaming walk "
+                                  "and the transforms run one after the other, so neither fraction can approach 1; per-kernel figures: profiles/r05_timeline_cfg4.txt"},
         "check": {"kind": kind, "sample": f"first {nsub} traces, stack + {Cn} replicas", "cpu_seconds": r["seconds"],
                   "relerr": {"ls": abi.relerr(g[0].cpu().numpy(), r["ls"]), "tsPWS": abi.relerr(g[1].cpu().numpy(), r["tsPWS"]),
                              "jk_ls": abi.relerr(g[2].cpu().numpy(), r["jk_ls"]), "jk_ts": abi.relerr(g[3].cpu().numpy(), r["jk_ts"]),

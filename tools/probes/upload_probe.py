@@ -69,3 +69,37 @@ for mode in ("whole", 64, 256, 1024, "pageable"):
             hip.hipHostUnregister(vp(y.ctypes.data + off)); off += mode << 20
     print(f"first upload of fresh pages, {mode}: {1e3*(t1-t0):.1f} ms ({N/(t1-t0)/1e9:.1f} GB/s)")
     del y
+
+# The library's own two uploads of a 10 000 x 131 072 ensemble (round 5): tspws_hip_upload (one device) against
+# tspws_hip_multi_upload (a device list: here virtual shards of the one GPU, so the link is shared -- the point is that the pieces of
+# the several-device form add nothing in front of the copies any more)
+import importlib, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
+import abi
+tspws = importlib.import_module("ts-pws_amd")
+lib = tspws.load()
+mtr, Ns = 10000, 131072
+del x, d
+torch.cuda.empty_cache()
+H = np.ones((mtr, Ns), np.float32)
+dd = torch.empty((mtr, Ns), dtype=torch.float32, device="cuda")
+for rep in range(3):
+    t0 = time.perf_counter()
+    assert lib.tspws_hip_upload(C.c_void_p(dd.data_ptr()), C.c_void_p(H.ctypes.data), C.c_size_t(H.nbytes), None) == 0
+    t1 = time.perf_counter()
+    print(f"tspws_hip_upload, {H.nbytes/1e9:.2f} GB: {1e3*(t1-t0):.1f} ms ({H.nbytes/(t1-t0)/1e9:.1f} GB/s)")
+del dd
+torch.cuda.empty_cache()
+p = tspws.resolve(abi.default_params(Kmax=10, unbiased=1), Ns)
+for ndev in (2, 4):
+    m = C.c_void_p()
+    arr = (C.c_int * ndev)(*([0] * ndev))
+    tspws.check(lib.tspws_hip_multi_create(C.byref(m), ndev, arr, p.type, p.J, p.V, Ns, p.s0, p.b0, p.w0, int(p.uni)), "multi_create")
+    sh, dl, dt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    for rep in range(3):
+        t0 = time.perf_counter()
+        tspws.check(lib.tspws_hip_multi_upload(m, H.ctypes.data, Ns, mtr, C.byref(sh), C.byref(dl), C.byref(dt)), "multi_upload")
+        t1 = time.perf_counter()
+        print(f"tspws_hip_multi_upload, {ndev} virtual shards: {1e3*(t1-t0):.1f} ms ({H.nbytes/(t1-t0)/1e9:.1f} GB/s)")
+    lib.tspws_hip_multi_destroy(m)

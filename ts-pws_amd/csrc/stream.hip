@@ -232,7 +232,9 @@ __global__ void __launch_bounds__(256) k_prefix_walk(const float *__restrict__ x
 // (`tail`), and k_seg_fix adds it (or, for a column that stores nothing in B, hands tail + B's sum on to the next stage): W rows of
 // fix-up per stage instead of a second set of rows and a pass that adds the two (alternate runs in two halves: 0.97 + 0.05 ms).
 #define ROWS_WMAX 16
-template <bool VEC4>
+// WM: columns the instantiation carries running sums for (12: the jackknife n = 10, d = 1 with its plain stack -- 32 registers less than
+// 16, which NL = 16 loads in flight take); NL: independent 16-byte loads in flight per lane
+template <bool VEC4, int WM, int NL>
 __global__ void __launch_bounds__(256) k_rows_walk(const float *__restrict__ x, size_t ld, size_t N, const RunDesc *__restrict__ runs, unsigned qa0,
                                                    unsigned qm, unsigned qb1, unsigned W, const unsigned *__restrict__ flush_rows,
                                                    double *__restrict__ rows, const double *__restrict__ carry_in, double *__restrict__ endA,
@@ -243,9 +245,9 @@ __global__ void __launch_bounds__(256) k_rows_walk(const float *__restrict__ x, 
 	const size_t col = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
 	if (col >= N) return;
 	const unsigned rem = (N - col) < 4 ? (unsigned)(N - col) : 4u;
-	double P[ROWS_WMAX][4];
+	double P[WM][4];
 #pragma unroll
-	for (int c = 0; c < ROWS_WMAX; c++) {
+	for (int c = 0; c < WM; c++) {
 #pragma unroll
 		for (int k = 0; k < 4; k++) P[c][k] = 0;
 		if (!seg && carry_in && (unsigned)c < W) {
@@ -261,20 +263,20 @@ __global__ void __launch_bounds__(256) k_rows_walk(const float *__restrict__ x, 
 		double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 		if (VEC4) { // the plain pass's loop: eight independent 16-byte non-temporal loads in flight, then their additions
 			unsigned t = 0;
-			for (; t + 8 <= rd.count; t += 8) {
-				v4f v[8];
+			for (; t + NL <= rd.count; t += NL) {
+				v4f v[NL];
 #pragma unroll
-				for (int j = 0; j < 8; j++) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)(t + j) * ld));
+				for (int j = 0; j < NL; j++) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)(t + j) * ld));
 #pragma unroll
-				for (int j = 0; j < 8; j++) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
+				for (int j = 0; j < NL; j++) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
 			}
 			if (t < rd.count) { // the remainder as one batch: rows past the end re-read the last row and are not added
 				const unsigned nv = rd.count - t, last = rd.count - 1u;
-				v4f v[8];
+				v4f v[NL];
 #pragma unroll
-				for (int j = 0; j < 8; j++) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)(t + (unsigned)j < rd.count ? t + (unsigned)j : last) * ld));
+				for (int j = 0; j < NL; j++) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)(t + (unsigned)j < rd.count ? t + (unsigned)j : last) * ld));
 #pragma unroll
-				for (int j = 0; j < 8; j++)
+				for (int j = 0; j < NL; j++)
 					if ((unsigned)j < nv) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
 			}
 		} else {
@@ -288,7 +290,7 @@ __global__ void __launch_bounds__(256) k_rows_walk(const float *__restrict__ x, 
 		}
 		unsigned fr = rd.frow;
 #pragma unroll
-		for (int c = 0; c < ROWS_WMAX; c++) {
+		for (int c = 0; c < WM; c++) {
 			if ((rd.member >> c) & 1u) { P[c][0] += a0; P[c][1] += a1; P[c][2] += a2; P[c][3] += a3; } // (wave-uniform)
 			if ((rd.flush >> c) & 1u) {
 				double *dst = rows + (size_t)flush_rows[fr++] * N + col;
@@ -305,7 +307,7 @@ __global__ void __launch_bounds__(256) k_rows_walk(const float *__restrict__ x, 
 	double *end = seg ? endB : endA; // the live sums of the segment
 	if (end) {
 #pragma unroll
-		for (int c = 0; c < ROWS_WMAX; c++)
+		for (int c = 0; c < WM; c++)
 			if ((unsigned)c < W) {
 				double *d = end + (size_t)c * N + col;
 #pragma unroll
@@ -340,10 +342,16 @@ int tspws_rows_walk_launch(const float *d_x, size_t ld, size_t N, const RunDesc 
 	if (!two) qm = q1;
 	// one segment: its live sums are the carry; two: tail + endB, merged by k_seg_fix
 	double *endA = two ? tail : (carry_out ? carry : nullptr);
-	if (vec) hipLaunchKernelGGL(k_rows_walk<true>, dim3(grid, two ? 2 : 1), dim3(256), 0, st, d_x, ld, N, d_runs, q0, qm, q1, W, d_flush_rows, d_rows,
-	                            (const double *)(carry_in ? carry : nullptr), endA, endB);
-	else hipLaunchKernelGGL(k_rows_walk<false>, dim3(grid, two ? 2 : 1), dim3(256), 0, st, d_x, ld, N, d_runs, q0, qm, q1, W, d_flush_rows, d_rows,
-	                        (const double *)(carry_in ? carry : nullptr), endA, endB);
+	static int nl = -1; // sweeps: loads in flight of the W <= 12 instantiation
+	if (nl < 0) { const char *e = sweep_env("TSPWS_WALK_NL"); nl = e ? atoi(e) : 8; } // (cfg4: 0.888 ms with 8, 0.903 with 16; the 16-column form: 0.909)
+	const dim3 g2(grid, two ? 2 : 1);
+	const double *cin = carry_in ? carry : nullptr;
+#define ROWS_WALK(V, WMV, NLV) hipLaunchKernelGGL((k_rows_walk<V, WMV, NLV>), g2, dim3(256), 0, st, d_x, ld, N, d_runs, q0, qm, q1, W, d_flush_rows, d_rows, cin, endA, endB)
+	if (!vec) ROWS_WALK(false, 16, 8);
+	else if (W <= 12 && nl == 16) ROWS_WALK(true, 12, 16);
+	else if (W <= 12) ROWS_WALK(true, 12, 8);
+	else ROWS_WALK(true, 16, 8);
+#undef ROWS_WALK
 	if (two) hipLaunchKernelGGL(k_seg_fix, dim3((unsigned)((N + 255) / 256), W), dim3(256), 0, st, (const double *)tail, (const double *)endB, d_fix_row, d_rows, carry, N);
 	HIP_TRY(hipGetLastError());
 	return 0;
