@@ -175,3 +175,25 @@ def test_large_batch_default_rule_matches_fir(lib, torch):
     m = Xh.astype(np.float64).sum(axis=0)
     lin = f.inverse(f.forward(m)) / ntr
     assert abi.relerr(ls.cpu().numpy(), lin.astype(np.float32)) < TOL32
+
+
+@pytest.mark.parametrize("kw,mtr,N,n,d", [(dict(type=-3, Kmax=10), 400, 4096, 10, 1), (dict(Kmax=8, unbiased=1), 300, 8192, 9, 1), (dict(Kmax=12, wu=1.0), 500, 2048, 6, 2)])
+def test_jackknife_rows_through_the_spectral_engine(lib, kw, mtr, N, n, d):
+    """The one-pass stack + jackknife call transforms (replicas + 1) x Kmax partial stacks: from 64 rows on, the octaves with D >= 8 of
+    those rows go through the spectral engine (lanes = rows, per-column stacks by k_spec_stack_rows) -- 110 rows (n = 10, d = 1),
+    80 rows, 192 rows -- against the oracle's tspws_main, replicas included; one bin of traces is all zero."""
+    Cn = abi.binomial(n, d)
+    assert (Cn + 1) * kw["Kmax"] >= 64
+    X = abi.synth_traces(mtr, N, seed=71)
+    rng = np.random.default_rng(11)
+    times = (1262304000 + 86400 * np.sort(rng.integers(0, 365, mtr))).astype(np.int64)
+    X[5] = 0
+    X[7, N // 2:] = 0
+    p = abi.default_params(jackknife_n=n, jackknife_d=d, **kw)
+    a = abi.run_main(lib.tspws_main, p, X, times=times)
+    b = abi.run_main(abi.oracle().orc_tspws_main, p, X, times=times)
+    assert a["rc"] == 0 and b["rc"] == 0
+    assert abi.relerr(a["ls"], b["ls"]) < TOL32 and abi.relerr(a["tsPWS"], b["tsPWS"]) < TOL32
+    np.testing.assert_array_equal(a["jk_mtr"], b["jk_mtr"])
+    for c in range(Cn):
+        assert abi.relerr(a["jk_ts"][c], b["jk_ts"][c]) < TOL32 and abi.relerr(a["jk_ls"][c], b["jk_ls"][c]) < TOL32, c

@@ -5,6 +5,7 @@
 //   check kernel (TSPWS_FWD_GENERIC=1): one wave / workgroup per coefficient
 // Reference citations are relative to /root/reference/src.
 #include "tspws_internal.h"
+#include <type_traits>
 
 #ifndef FL_PASSES
 #define FL_PASSES 2
@@ -316,7 +317,52 @@ static hipError_t tspws_side_stream(tspws_hip_plan *p)
 template <typename TIn>
 static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, double2 *d_part, hipStream_t st, FuseOut *fz, ScaleRange rg)
 {
-	if (fz) fz->applied = false;
+	if (fz) { fz->applied = false; fz->spec_first = p->S; }
+	bool spec_join = false;
+	// Few rows in columns (the K partial stacks of every jackknife replica, resample.hip) whose weighted sets the forward launch completes
+	// itself: from FEW_SPEC_MIN rows on, the octaves with D >= 8 go through the spectral engine (lanes = rows; per-column stacks by
+	// k_spec_stack_rows) and the FIR kernels below keep the finer ones.  cfg4 (110 rows of 131072 samples, Mexican hat): forward stage
+	// 1.22 -> see DESIGN.md section 4.  TSPWS_ENGINE=fir switches it off.
+	if constexpr (std::is_same<TIn, double>::value) {
+		if (fz && fz->allow_spec && !rg.on() && fz->fin.OUT && fz->fin.nprev == 0 && ntr <= 512 && fz->tps) {
+			static int min_rows = -1;
+			static unsigned nsmax_env = 0;
+			if (min_rows < 0) {
+				const char *e = sweep_env("TSPWS_FEW_SPEC_MIN"); min_rows = e ? std::max(1, atoi(e)) : 64;
+				if (const char *m = sweep_env("TSPWS_FEW_NSMAX")) nsmax_env = (unsigned)std::max(2, atoi(m));
+			}
+			const char *eng = getenv("TSPWS_ENGINE");
+			if (ntr >= (size_t)min_rows && !(eng && !strcmp(eng, "fir")) && !tspws_generic_forward()) {
+				const unsigned sf = tspws_spectral_first_scale(p, nsmax_env ? nsmax_env : std::max(512u, p->N / 8u));
+				if (sf < p->S) {
+					SpecDecomp *dc = nullptr;
+					int rc;
+					if ((rc = tspws_spectral_decomp(p, sf, (unsigned)((ntr + 63) / 64), &dc, true))) return rc;
+					// the spectral chain (transposition, transforms through HBM: bandwidth-bound) on its own stream beside the FIR kernels of the
+					// finer octaves (FP64-bound) -- joined before this function returns
+					// (measured on cfg4, 110 rows: side by side the two take 1.70 ms -- the chain's LDS users leave room for ONE 80-KB workgroup of
+					// k_fwd_lds per CU, its transposition starves --, one after the other 1.05 ms, the FIR kernels alone 1.20: serial by default)
+					static const bool serial = sweep_env("TSPWS_SPEC_PARALLEL") == nullptr;
+					hipStream_t sx = st;
+					if (!serial && sf > 0) {
+						const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+						if (!p->xs) HIP_TRY(hipStreamCreateWithFlags(&p->xs, hipStreamNonBlocking));
+						if (!p->ev_xs0) HIP_TRY(hipEventCreateWithFlags(&p->ev_xs0, evf));
+						if (!p->ev_xs1) HIP_TRY(hipEventCreateWithFlags(&p->ev_xs1, evf));
+						hipEvent_t ready = p->le.ready;
+						if (!ready) { ready = p->ev_xs0; HIP_TRY(hipEventRecord(ready, st)); }
+						HIP_TRY(hipStreamWaitEvent(p->xs, ready, 0));
+						sx = p->xs;
+					}
+					if ((rc = tspws_spectral_rows_f64(p, dc, (const double *)d_x, ld, (unsigned)ntr, fz->tps, *fz, sx))) return rc;
+					fz->spec_first = sf;
+					if (sf == 0) { fz->applied = true; return 0; } // (every scale went that way)
+					rg.s0 = 0; rg.s1 = sf;
+					spec_join = sx != st;
+				}
+			}
+		}
+	}
 	const LaunchRange lr = launch_range(p, rg);
 	const bool has_lds = lr.lds1 > lr.lds0, has_poly = lr.wav1 > lr.wav0;
 	hipStream_t sp = st; // stream of the direct kernel
@@ -377,6 +423,10 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 	if (sp != st) {
 		HIP_TRY(hipEventRecord(p->ev_join, sp));
 		HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
+	}
+	if (spec_join) {
+		HIP_TRY(hipEventRecord(p->ev_xs1, p->xs));
+		HIP_TRY(hipStreamWaitEvent(st, p->ev_xs1, 0));
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;

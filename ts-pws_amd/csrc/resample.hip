@@ -591,6 +591,7 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	static int fin_env = -2;
 	if (fin_env == -2) { const char *e = sweep_env("TSPWS_JK_FINAL"); fin_env = e ? atoi(e) : -1; }
 	const bool fin_in_kernel = fin_env < 0 ? mp.nstage == 1 : fin_env != 0;
+	unsigned last_spec_first = pl->S; // scales [.., S) of the last stage were completed by the spectral engine (forward.hip)
 	for (unsigned sg = 0; sg < mp.nstage; sg++) {
 		// HBM-bound half of the stage on the caller's stream: its rows from its traces
 		if ((rc = masked_stream_stage(pl, mp, dv, d_x, ld, d_rows, sg, st))) return rc;
@@ -600,6 +601,7 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 		HIP_TRY(hipStreamWaitEvent(pl->xf, pl->stage_ev[sg], 0));
 		FuseOut fz;
 		if (fuse) { fz.accST = planes + (size_t)sg * W * 2 * nc; fz.accPS = fz.accST + nc; fz.stride = 2 * nc; fz.tps = ng; }
+		unsigned stage_spec_first = pl->S;
 		if (fuse && fin_in_kernel && sg + 1 == mp.nstage) {
 			// the last stage completes the columns' stacks in the forward kernel itself: earlier stages' plane pairs in front, weights on
 			// the spot -- no pass over the fused scales (98 % of the coefficients) afterwards
@@ -607,13 +609,20 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 			f.pST = planes; f.pPS = planes + nc; f.pair_stride = (size_t)W * 2 * nc; f.slice_stride = 2 * nc; f.nprev = sg;
 			f.OUT = (double2 *)OUT; f.out_stride = nc; f.Mv = d_Mv; f.mode = tspws_weight_mode(p->wu, p->unbiased, KM); f.K = (double)KM; f.wu = p->wu;
 			f.keep_slice = with_stack ? (int)C : -1; f.keepST = (double2 *)OUT + (size_t)W * nc;
+			fz.allow_spec = true; // (the far-decimated octaves of these ng W rows may go through the spectral engine: forward.hip decides)
 		}
 		if ((rc = tspws_forward_parts_f64(pl, d_rows + (size_t)r0 * N, r1 - r0, N, part + (size_t)r0 * pl->npart, pl->xf, fuse ? &fz : nullptr, ScaleRange()))) return rc;
+		if (fuse) stage_spec_first = fz.spec_first;
+		last_spec_first = stage_spec_first;
 	}
 	HIP_TRY(hipEventRecord(pl->stage_ev[mp.nstage], pl->xf));
-	// time-domain linear stacks of the replicas (:799-811) while the last transforms run
-	if (C) hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, W, mp.gps);
+	// time-domain linear stacks of the replicas (:799-811) while the last transforms run -- unless those start with the spectral chain's
+	// transposition of the same rows: two kernels that walk the rows at a 1-MB stride at the same time take 0.57 + 0.93 ms instead of
+	// 0.03 + 0.06 (cfg4), so the linear stacks then wait for the transforms
+	const bool lin_first = last_spec_first >= pl->S;
+	if (C && lin_first) hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, W, mp.gps);
 	HIP_TRY(hipStreamWaitEvent(st, pl->stage_ev[mp.nstage], 0));
+	if (C && !lin_first) hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, W, mp.gps);
 	// stacks of every column: its plane pairs in stage order + its split partials in group order; weights by the same launch
 	// (K = KM, M = the column's traces)
 	WeightArgs wa;
@@ -629,10 +638,10 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 		double2 *ST_arg = with_stack ? (double2 *)OUT + (size_t)W * nc - (size_t)C * 2 * nc : (double2 *)STr;
 		// (the launch starts at the first scale the fused kernel left out -- the split scales are the far-decimated ones at the end of the
 		// list --; fused scales inside its range are skipped by the kernel)
-		const unsigned s_first = tspws_first_unfused_scale(pl);
-		ScaleRange rg; rg.s0 = s_first; rg.s1 = pl->S;
-		if (s_first == 0) rg = ScaleRange(); // (no fused scale in front: everything)
-		if (s_first < pl->S) tspws_launch_accumulate(pl, (const double2 *)part, KM, ST_arg, (double2 *)STr + nc, 1, &fa, mp.nstage, st, W, 0, 2 * nc, nullptr, &wa, rg, &ex);
+		const unsigned s_first = tspws_first_unfused_scale(pl), s_end = std::min(pl->S, last_spec_first); // (the spectral scales are complete)
+		ScaleRange rg; rg.s0 = s_first; rg.s1 = s_end;
+		if (s_first == 0 && s_end == pl->S) rg = ScaleRange(); // (no fused scale in front, none taken behind: everything)
+		if (s_first < s_end) tspws_launch_accumulate(pl, (const double2 *)part, KM, ST_arg, (double2 *)STr + nc, 1, &fa, mp.nstage, st, W, 0, 2 * nc, nullptr, &wa, rg, &ex);
 	} else {
 		tspws_launch_accumulate(pl, (const double2 *)part, KM, (double2 *)STr, (double2 *)STr + nc, 1, fuse ? &fa : nullptr, mp.nstage, st, W, 0, 2 * nc, nullptr, &wa, ScaleRange(), &ex);
 		if (with_stack) HIP_TRY(hipMemcpyAsync(OUT + (size_t)W * 2 * nc, STr + (size_t)C * 4 * nc, nc * sizeof(double2), hipMemcpyDeviceToDevice, st)); // ST of the plain stack: the last set

@@ -28,6 +28,7 @@ struct SpecSlot {
 // The decomposition of a many-trace batch that goes with a spectral set: trace-lane items for the finer octaves + scale table.
 struct SpecDecomp {
 	unsigned s_first = 0;
+	bool few = false, small = false; // few: no trace-lane table (rows in columns: spectral.hip's tspws_spectral_rows_*); small: built for < 8 trace blocks
 	TlTable T;
 	SpecPlan *sp = nullptr;
 };

@@ -129,6 +129,11 @@ struct FuseOut {
 	unsigned tps = 1;
 	bool applied = false; // set by the forward launch when the fused kernel ran
 	FuseFinal fin;        // (default: off)
+	// few rows in columns (slices of tps rows) whose far-decimated scales may go through the spectral engine (spectral.hip): the caller
+	// allows it; the forward launch reports the first scale it took that way (S: none) -- those scales are COMPLETE afterwards (weighted
+	// sets / plane pairs of every slice written), whatever their fuse_ok / nsplit say
+	bool allow_spec = false;
+	unsigned spec_first = ~0u;
 };
 
 // Phase weighting of one coefficient (tspws_biased :909-943, tspws_unbiased :965-984).
@@ -206,6 +211,8 @@ struct tspws_hip_plan {
 	// side stream, forked from and joined back into the caller's stream
 	hipStream_t side = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	hipStream_t xs = nullptr;          // ... and the spectral chain of a few-row launch beside both (forward.hip)
+	hipEvent_t ev_xs0 = nullptr, ev_xs1 = nullptr;
 	// optional timing inside tspws_hip_stack (bench.py): three events per call -- start, end of the streaming stage, end
 	// Events that ride on kernel launches instead of being recorded as packets of their own (hipExtLaunchKernelGGL: the launch's
 	// start / completion signal IS the event; tools/probes/xstream_probe.hip: the next kernel of the stream follows 2.5 us after
@@ -336,7 +343,8 @@ size_t tspws_part_budget_bytes();
 bool tspws_generic_forward();
 // spectral.hip: the far-decimated octaves of a many-trace batch through the traces' spectra
 unsigned tspws_spectral_first_scale(const tspws_hip_plan *p, unsigned nsmax); // first scale of the spectral set for octaves of <= nsmax outputs (S: none)
-int  tspws_spectral_decomp(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, SpecDecomp **out);
+int  tspws_spectral_decomp(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, SpecDecomp **out, bool few = false);
+int  tspws_spectral_rows_f64(tspws_hip_plan *p, SpecDecomp *dc, const double *d_x, size_t ld, unsigned ntr, unsigned tps, const FuseOut &fz, hipStream_t st); // few rows in columns
 int  tspws_build_tl_spectral(tspws_hip_plan *p, unsigned s_first, TlTable &T); // (forward.hip) scale table + trace-lane items of that decomposition
 int  tspws_spectral_run_f32(tspws_hip_plan *p, SpecDecomp *dc, const float *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st);
 int  tspws_spectral_run_f64(tspws_hip_plan *p, SpecDecomp *dc, const double *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st);
