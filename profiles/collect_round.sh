@@ -15,6 +15,7 @@ bash profiles/collect_pmc.sh $TAG > /dev/null 2>&1
 # the traffic record bench.py quotes: counters of THIS build's streaming kernel, tagged with the hash of its source
 python3 profiles/pmc_record.py gpurun_out/pmc_$TAG > gpurun_out/pmc_partial_stacks.json 2> gpurun_out/${TAG}_pmc_record.err
 python3 tools/cfg1_run.py 2>/dev/null | grep cfg1 > gpurun_out/${TAG}_cfg1.txt
+cp gpurun_out/pmc_partial_stacks.json profiles/pmc_partial_stacks.json 2>/dev/null  # (bench.py quotes it from profiles/: hash-guarded)
 # kernel stats of the other configs (bench.py's other_configs leg times them; these are the per-kernel breakdowns)
 bash tools/gpu_prof_cfg.sh ${TAG}cfg2 tools/cfg2_run.py > /dev/null 2>&1; cp gpurun_out/stats_${TAG}cfg2.txt gpurun_out/${TAG}_stats_cfg2.txt
 bash tools/gpu_timeline_cfg.sh ${TAG}cfg4 70 tools/cfg4_run.py > /dev/null 2>&1; cp gpurun_out/stats_${TAG}cfg4.txt gpurun_out/${TAG}_stats_cfg4.txt; cp gpurun_out/timeline_${TAG}cfg4.txt gpurun_out/${TAG}_timeline_cfg4.txt

@@ -176,6 +176,11 @@ static int read_data(t_data *in, const char *filein, int bin, int verbose)
 		in->time[i - nskip] = sac_reference_time(&h); /* (addition: the reference leaves time[] zero for SAC lists) */
 	}
 	const unsigned kept = nfiles - nskip;
+	/* one line about what the reference's way of skipping leaves behind (the outputs are the reference's either way) */
+	if (nskip)
+		printf("ts_pws: %u of %u traces skipped (dt / b mismatch): the stack keeps %u rows like the reference's reader (ts_pws1f.c:680-708) -- %u accepted "
+		       "traces in front, the rest as the skipping left them (zero rows, or a mismatched LAST trace still in its slot); ls is divided by %u\n",
+		       nskip, nfiles, nfiles, kept, nfiles);
 	for (unsigned i = 0; i < nfiles; i++) free(files[i]);
 	free(files);
 	for (unsigned i = 0; i < kept; i++) {

@@ -717,8 +717,9 @@ static int spec_build(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, S
 	// scale groups: groups of at most 16 scales (a wave's accumulators for two trace blocks: 128 VGPRs), padded to 8 or 16 slots (a 1-KB
 	// block of a group's table stream holds 8 or 4 steps); the groups of a class share a workgroup (k_spec_fold)
 	if (nsc > 128) return fail(TSPWS_E_ARG, "spectral: more than 128 scales in the spectral set");
-	// (8 or 16 slots per group: whichever pads less -- 18 scales: 3 x 8 = 24 slots against 2 x 16 = 32; 45 scales: 48 either way -> 16)
-	unsigned nsw = (((nsc + 7) / 8) * 8 < ((nsc + 15) / 16) * 16 && nsc <= 64) ? 8u : 16u;
+	// (8 slots per group only where that saves a quarter of the slots -- 18 scales: 3 x 8 = 24 against 2 x 16 = 32; 40 scales: 5 x 8 = 40
+	// against 48, but five groups of one wave each lose more than the eight idle slots cost: 0.67 vs 0.42 ms on cfg2)
+	unsigned nsw = (((nsc + 7) / 8) * 8 * 4 <= ((nsc + 15) / 16) * 16 * 3 && nsc <= 64) ? 8u : 16u;
 	if (const char *e = sweep_env("TSPWS_SPEC_NSW")) nsw = atoi(e) <= 8 ? 8u : 16u; // sweeps
 	if (nsc > 8 * nsw) nsw = 16;
 	const unsigned ngroups = (nsc + nsw - 1) / nsw;
