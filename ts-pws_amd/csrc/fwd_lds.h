@@ -80,6 +80,11 @@
 #define FL_X_ALLOC_(QT) (FL_MAX2(FL_MAX2(FL_XROWS_(QT) * 64, FL_XSMALL_(QT) * FL_XPAD), FL_WAVES * FL_SCR) + FL_XSLACK_(QT))
 #define FL_LDS_BYTES_(QT) (FL_TAPS_BYTES_(QT) + FL_X_ALLOC_(QT) * 8)
 static_assert(FL_LDS_BYTES_(32) * 2 <= 160 * 1024, "two workgroups of the QT = 32 kernel must fit the 160 KB of a CU");
+// Every row that is CONSUMED lies inside the image: the last wave's 16-output window ends at row 16 (FL_WAVES - 1) + QT + 14 (k_fwd_lds, wide
+// form).  Only the look-ahead of the LAST batch (operands requested before the loop knows it has ended, never used) may read past the
+// allocation -- inside the slack for QT = 24, beyond the workgroup's LDS for QT = 32, where the hardware returns zeros.
+static_assert(16 * (FL_WAVES - 1) + 24 + 14 < FL_XROWS_(24) && 16 * (FL_WAVES - 1) + 32 + 14 < FL_XROWS_(32), "a consumed window row would lie outside the staged image");
+static_assert(FL_XROWS_(24) * 64 <= FL_X_ALLOC_(24) - FL_XSLACK_(24) && FL_XROWS_(32) * 64 <= FL_X_ALLOC_(32) - FL_XSLACK_(32), "the staged image must fit its allocation");
 
 #ifndef FL_TIMING
 #define FL_TIMING 0                             /* 1: per-phase s_memtime totals per LOGD class (tools/fwd_timing.py) */

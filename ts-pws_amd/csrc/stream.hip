@@ -448,14 +448,15 @@ int tspws_run_chunks(tspws_hip_plan *p, const float *d_x, size_t ld, size_t N, c
 	return tspws_chunks_launch(p, d_x, ld, N, chunks, row_first, rows, d_P, ldP, st, row_begin, row_end);
 }
 
-// Device copy of a chunk table into the plan's table block (see chunk_tables); `fresh` false: the caller knows the block still
-// holds this very table (masked replicas with a repeated selection: plan->jk_gen) and only the stream ordering is needed.
+// Device copy of a chunk table into the plan's table block SCR_TAB (see chunk_tables).  cached: the plan's own group table (uploaded once,
+// later calls only order their stream behind that copy); any other table is uploaded every time.  Either way SCR_TAB no longer holds
+// whatever a masked-replica call may have left there, so that call's generation mark is reset (its own tables live in SCR_JKTAB).
 int tspws_chunks_upload(tspws_hip_plan *p, const std::vector<Chunk> &chunks, const std::vector<unsigned> &row_first, unsigned rows, hipStream_t st,
                         bool cached)
 {
 	Chunk *d_chunks = nullptr;
 	unsigned *d_rf = nullptr;
-	if (!cached) p->jk_gen = 0; // whatever masked-replica table the block held is gone
+	p->jk_gen = 0;
 	return chunk_tables(p, chunks, row_first, rows, st, cached, &d_chunks, &d_rf);
 }
 
