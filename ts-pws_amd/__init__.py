@@ -549,14 +549,18 @@ def _finish_shard(plan, mtr_global, group=None):
     # theirs, so the ranks cannot diverge into different collective sequences.
     pr = getattr(plan, "params", None)
     frame = (pr.type, pr.J, pr.V, pr.s0, pr.b0, pr.w0, int(pr.uni), pr.Kmax) if pr is not None else (id(plan),)
-    # keyed on the process-group OBJECT (group None = the current default group, a new object after every init_process_group), and the
-    # entry keeps a reference to it: the id of a destroyed group cannot be reused by a later one while this entry exists, so a rank never
-    # skips the agreement collective that a peer with a fresh process still issues
-    grp = group if group is not None else dist.group.WORLD
-    key = (id(grp), world, dist.get_rank(group), mtr_global, getattr(plan, "N", 0), frame, os.environ.get("TSPWS_SHARD_FINISH", "1"))
-    hit = _SHARD_AGREED.get(key)
-    if hit is not None and hit[0] is grp:
-        return hit[1]
+    # keyed on the process group AND on torch's count of groups created so far (it grows with every init_process_group / new_group, on
+    # every rank alike): after destroy + init the id of the old group object may be reused, but the count has moved on, so all ranks miss
+    # together and repeat the agreement collective -- no rank skips a collective that a peer still issues.  (No reference to the group is
+    # kept: a process group held by a module-level table is torn down at interpreter exit with its threads still running.)
+    try:
+        gen = dist.distributed_c10d._world.group_count
+    except Exception:
+        gen = None
+    key = (id(group) if group is not None else None, gen, world, dist.get_rank(group), mtr_global, getattr(plan, "N", 0), frame,
+           os.environ.get("TSPWS_SHARD_FINISH", "1"))
+    if gen is not None and key in _SHARD_AGREED:
+        return _SHARD_AGREED[key]
     mine = None
     if os.environ.get("TSPWS_SHARD_FINISH", "1") != "0" and callable(getattr(plan, "finish_shard", None)):
         mine = plan.finish_shard(mtr_global, dist.get_rank(group), world)
@@ -566,7 +570,7 @@ def _finish_shard(plan, mtr_global, group=None):
     flag = torch.tensor([1 if mine is not None else 0], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     agreed = mine if int(flag.item()) == 1 else None
-    _SHARD_AGREED[key] = (grp, agreed)
+    _SHARD_AGREED[key] = agreed
     return agreed
 
 
