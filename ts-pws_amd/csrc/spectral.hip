@@ -478,6 +478,93 @@ __global__ void __launch_bounds__(512) k_spec_fold(const double2 *__restrict__ X
 		}
 }
 
+// ---- multiply-and-fold on the FP64 matrix pipe --------------------------------------------------------------------------------------------
+// G_s[q] = sum_j X[q + j N_s] H_s[q + j N_s] for 64 traces and 16 scales at a time IS a complex matrix product with the aliases j as the
+// contraction index: (traces x steps) . (steps x scales).  v_mfma_f64_16x16x4_f64 takes a 16 x 4 tile of X (lane = (trace i, step k)) and a
+// 4 x 16 tile of H (lane = (step k, scale j)) -- every lane loads ONE value of each, nothing is broadcast, so there is no SGPR / LDS operand
+// path to feed at all -- and leaves a 16 x 16 tile of sums in four registers per lane (register q: trace lane / 16 + 4 q of scale lane % 16).
+// Four MFMAs per tile (re / im), 64 cycles each on gfx950: the FP64 matrix rate equals the vector rate, but ONE wave per SIMD sustains
+// ~95 % of it (the vector form of this kernel: 45-50 %).  wave = (class r, group of 16 scales, trace block); steps in the same bit-reversed
+// order as above, four at a time (every spectral scale has D >= 8: a bin can only complete with the last step of an aligned group of four).
+typedef double spec_v4d __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_spec_fold_mfma(const double2 *__restrict__ Xh, size_t xrows, const double2 *__restrict__ tab, const SpecSlot *__restrict__ slots,
+                                                        unsigned R, unsigned logsteps, unsigned N, unsigned nblk, double2 *__restrict__ G, size_t grows)
+{
+	constexpr int NS = 16;
+	const unsigned lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const unsigned r = blockIdx.x, g = blockIdx.y, tb = blockIdx.z * 4 + wv;
+	if (tb >= nblk) return;
+	const unsigned nsteps = 1u << logsteps, M = N >> 1;
+	const unsigned li = lane & 15, lk = lane >> 4;  // A: (trace li of a tile, step lk); B: (step lk, scale li); C: traces 4 lk .. + 3 of scale li
+	const double2 *__restrict__ hp = tab + ((size_t)g * R + r) * nsteps * NS + li; // table stream: step c, slot s at [c NS + s]
+	const SpecSlot my = slots[(size_t)g * NS + li]; // this lane's scale
+	const unsigned mask0 = (1u << slots[(size_t)g * NS].ld) - 1u; // the finest scale of the group: nothing completes before it does
+	const double2 *xc = Xh + (size_t)tb * xrows * 64 + li;
+	double2 *gc = G + (size_t)tb * grows * 64 + lk; // (result register q of a lane: trace lk + 4 q of the tile -- tools/probes/mfma_f64_layout.hip)
+	spec_v4d cre[4], cim[4];
+#pragma unroll
+	for (int t = 0; t < 4; t++) { cre[t] = (spec_v4d){0, 0, 0, 0}; cim[t] = (spec_v4d){0, 0, 0, 0}; }
+	// operands of four steps: the rows are requested RAW; the conjugation of a mirrored row (sign bit of the imaginary part) is applied
+	// when the values move into the operand registers, after the MFMAs of the block in front -- applied at the load it made the compiler
+	// wait for the next block's rows before this block's MFMAs
+	auto request = [&](const unsigned c0, double2 (&xr)[4], double2 &hr, int &flip) {
+		const unsigned c = c0 + lk;
+		const unsigned ib = logsteps ? (__brev(c) >> (32 - logsteps)) : 0u;
+		const unsigned f = r + R * ib;
+		const bool cj = f > M;
+		const double2 *row = xc + (size_t)(cj ? N - f : f) * 64;
+		flip = cj ? (int)0x80000000 : 0;
+#pragma unroll
+		for (int t = 0; t < 4; t++) xr[t] = row[16 * t];
+		hr = hp[(size_t)c * NS];
+	};
+	double2 xa[4], xn[4], hb, hn;
+	int fa, fn = 0;
+	request(0, xa, hb, fa);
+#pragma unroll
+	for (int t = 0; t < 4; t++) xa[t].y = __hiloint2double(__double2hiint(xa[t].y) ^ fa, __double2loint(xa[t].y));
+	for (unsigned c0 = 0; c0 < nsteps; c0 += 4) {
+		request(c0 + 4 < nsteps ? c0 + 4 : 0u, xn, hn, fn); // (after the last block: a harmless re-request of the first -- no branch around the loads)
+		__builtin_amdgcn_sched_barrier(0);
+		// (eight independent accumulators between two MFMAs on the same one)
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			cre[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t].x, hb.x, cre[t], 0, 0, 0);
+			cim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t].x, hb.y, cim[t], 0, 0, 0);
+		}
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			cre[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[t].y, hb.y, cre[t], 0, 0, 0);
+			cim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t].y, hb.x, cim[t], 0, 0, 0);
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		const unsigned c = c0 + 3;
+		if (((c + 1) & mask0) == 0) { // (wave-uniform) some scale of the group completes a bin: the lanes of those scales store and start over
+			const bool done = my.ld < 31u && ((c + 1) & ((1u << my.ld) - 1u)) == 0;
+			if (done) {
+				const unsigned ilo = my.lb ? (__brev(c >> my.ld) >> (32 - my.lb)) : 0u;
+				double2 *dst = gc + (my.goff + r + (size_t)R * ilo) * 64;
+#pragma unroll
+				for (int t = 0; t < 4; t++) {
+#pragma unroll
+					for (int q = 0; q < 4; q++) dst[16 * t + 4 * q] = make_double2(cre[t][q], cim[t][q]);
+					cre[t] = (spec_v4d){0, 0, 0, 0}; cim[t] = (spec_v4d){0, 0, 0, 0};
+				}
+			}
+		}
+#pragma unroll
+		for (int t = 0; t < 4; t++) xa[t] = make_double2(xn[t].x, __hiloint2double(__double2hiint(xn[t].y) ^ fn, __double2loint(xn[t].y)));
+		hb = hn;
+	}
+	if (my.ld == 31u && my.lb != 31u) { // partial sums of the classes (lb == 31: an idle pad slot)
+		double2 *dst = gc + (my.goff + r) * 64;
+#pragma unroll
+		for (int t = 0; t < 4; t++)
+#pragma unroll
+			for (int q = 0; q < 4; q++) dst[16 * t + 4 * q] = make_double2(cre[t][q], cim[t][q]);
+	}
+}
+
 // ---- inverse transforms of the folded spectra + stacks -----------------------------------------------------------------------------
 // A segment = one pass of one scale.  Passes before the last write the other ping-pong buffer; the last pass conjugates
 // (Y = conj r), phase-normalises and adds the block's 64 traces into the block's ST / PS planes (COEF: writes the traces' own
@@ -719,7 +806,7 @@ static int spec_build(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, S
 	if (nsc > 128) return fail(TSPWS_E_ARG, "spectral: more than 128 scales in the spectral set");
 	// (8 slots per group only where that saves a quarter of the slots -- 18 scales: 3 x 8 = 24 against 2 x 16 = 32; 40 scales: 5 x 8 = 40
 	// against 48, but five groups of one wave each lose more than the eight idle slots cost: 0.67 vs 0.42 ms on cfg2)
-	unsigned nsw = (((nsc + 7) / 8) * 8 * 4 <= ((nsc + 15) / 16) * 16 * 3 && nsc <= 64) ? 8u : 16u;
+	unsigned nsw = 16; // (the matrix-pipe fold takes tiles of 16 scales; the vector-FMA form's 8-slot groups: sweeps only)
 	if (const char *e = sweep_env("TSPWS_SPEC_NSW")) nsw = atoi(e) <= 8 ? 8u : 16u; // sweeps
 	if (nsc > 8 * nsw) nsw = 16;
 	const unsigned ngroups = (nsc + nsw - 1) / nsw;
@@ -931,7 +1018,11 @@ static int spectral_run(tspws_hip_plan *p, SpecDecomp *dc, const TIn *xT, unsign
 	}
 	const double2 *Xh = cur;
 	// multiply-and-fold
-	{
+	static const bool fold_lds = sweep_env("TSPWS_SPEC_FOLD") && !strcmp(sweep_env("TSPWS_SPEC_FOLD"), "lds"); // A/B: the vector-FMA form
+	if (sp->NS == 16 && !fold_lds) {
+		hipLaunchKernelGGL(k_spec_fold_mfma, dim3(sp->R, sp->ngroups, (nblk + 3) / 4), dim3(256), 0, st, Xh, xrows, (const double2 *)sp->d_tab, (const SpecSlot *)sp->d_slots, sp->R,
+		                   sp->logsteps, N, nblk, G, sp->grows);
+	} else {
 		static int ntb = -1;
 		if (ntb < 0) { const char *e = sweep_env("TSPWS_SPEC_NTB"); ntb = (e && atoi(e) == 1) ? 1 : 2; } // sweeps
 		const unsigned NTB = (unsigned)ntb;
