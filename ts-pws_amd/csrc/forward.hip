@@ -280,7 +280,12 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINN
 
 int tspws_build_tl_spectral(tspws_hip_plan *p, unsigned s_first, TlTable &T)
 {
-	return build_tl_forward(p, FWD_STEPS_TL, TL_MINNS0, 96, T, s_first);
+	// residue steps per workgroup of the finer octaves: SHORT workgroups (12; the FIR-only decomposition takes 96) -- the spectral chain runs
+	// beside this kernel on the side stream and gets the slots they free (cfg2 1.80 -> 1.68 ms, 1024 x 32768 default frame 1.56 -> 1.42; 8: same,
+	// 32: 1.77 / 1.48, 192: 2.11 / 1.71; outputs bit-identical)
+	unsigned steps = 12;
+	if (const char *e = sweep_env("TSPWS_SPEC_TLSTEPS")) steps = (unsigned)std::max(1, atoi(e)); // sweeps: residue steps per workgroup of the finer octaves
+	return build_tl_forward(p, FWD_STEPS_TL, TL_MINNS0, steps, T, s_first);
 }
 
 // ------------------------------------------------------------------------------------------
