@@ -116,8 +116,8 @@ def test_frames_without_a_spectral_set(lib):
 
 
 def test_engine_choice_rule(lib):
-    """Default rule (no TSPWS_ENGINE): batches of the many-trace size of frames with more than two voices per octave send the octaves
-    with D >= 32 through the spectrum; small batches, two-voice frames and frames without a spectral set stay on the FIR kernels."""
+    """Default rule (no TSPWS_ENGINE): batches of the many-trace size send the octaves with D >= 32 (two-voice frames: D >= 16) through the
+    spectrum; small batches and frames without a spectral set stay on the FIR kernels."""
     if os.environ.get("TSPWS_ENGINE") or os.environ.get("TSPWS_SPEC_NSMAX"):
         pytest.skip("engine pinned by the environment")
     N = 32768
@@ -129,7 +129,9 @@ def test_engine_choice_rule(lib):
     assert lib.tspws_hip_spectral_choice(pl.h, 100) == pl.S          # fewer than 128 traces
     assert lib.tspws_hip_spectral_choice(pl.h, 200) == pl.S          # fewer than 7 M samples
     pm = tspws.Plan(abi.resolve(abi.default_params(type=-3), N), N)
-    assert lib.tspws_hip_spectral_choice(pm.h, 1024) == pm.S         # Mexican hat: two voices per octave
+    fm = abi.OracleFrame.from_params(abi.resolve(abi.default_params(type=-3), N), N)
+    sm = lib.tspws_hip_spectral_choice(pm.h, 1024)                   # Mexican hat (two voices per octave): one octave more, D >= 16
+    assert sm < pm.S and int(fm.D[sm]) == 16 and int(fm.D[sm - 1]) == 8
     po = tspws.Plan(abi.resolve(abi.default_params(), 16501), 16501)
     assert lib.tspws_hip_spectral_choice(po.h, 4096) == po.S         # odd N
 

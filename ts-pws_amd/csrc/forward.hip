@@ -500,8 +500,8 @@ bool tspws_fused_forward(const tspws_hip_plan *p) { return p->n_fusable != 0; }
 // a trace-lane work item shares its staged rows among the voices of an octave.
 // Engine of a many-trace batch: the first scale of the spectral set (S: every scale on the FIR kernels).  TSPWS_ENGINE=fir / spectral
 // pins it (spectral: every batch that has such a set takes the many-trace path, whatever its size).  Default: batches of the many-trace
-// size (>= 128 traces, >= 7 M samples) of frames with more than two voices per octave send the octaves with D >= 32 (at most
-// max(512, N / 32) outputs) through the spectrum -- sweeps over 128 .. 4096 traces x 8192 .. 131072 samples (tools/experiments/
+// size (>= 128 traces, >= 7 M samples) send the octaves with D >= 32 (at most max(512, N / 32) outputs; two-voice frames: D >= 16)
+// through the spectrum -- sweeps over 128 .. 4096 traces x 8192 .. 131072 samples (tools/experiments/
 // r5_spec12.sh, default Morlet): 1024 x 32768 2.73 -> 1.81 ms, 2048 x 16384 2.83 -> 1.74, 512 x 65536 3.05 -> 2.02, 1024 x 131072 10.96 ->
 // 7.63 (N_s <= 4096), 4096 x 8192 2.38 -> 1.65; below that size the FIR kernels win (256 x 8192: 0.31 vs 0.38 ms); outputs
 // bit-identical at every size.  TSPWS_SPEC_NSMAX overrides the octave bound.
@@ -516,8 +516,11 @@ unsigned tspws_spectral_choice(const tspws_hip_plan *p, size_t ntr)
 		if (const char *m = sweep_env("TSPWS_SPEC_NSMAX")) nsmax_env = (unsigned)std::max(2, atoi(m));
 	}
 	if (eng == 1 || tspws_generic_forward() || !ntr) return p->S;
-	if (eng == 0 && !(many_trace_size(p, ntr) && p->V > 2)) return p->S;
-	return tspws_spectral_first_scale(p, nsmax_env ? nsmax_env : std::max(512u, p->N / 32u));
+	if (eng == 0 && !many_trace_size(p, ntr)) return p->S;
+	// (two voices per octave -- the Mexican hat --: the trace-lane kernel is at its weakest there (it shares its staged rows among the voices of
+	// an octave), so one octave more goes through the spectrum: 1024 x 32768 Mexican hat 2.47 ms on the few-trace kernels, 1.56 / 1.52 / 1.54 ms
+	// with N_s <= 1024 / 2048 / 4096; 4096 x 8192 2.72 -> 1.51-1.54; 512 x 65536 2.52 -> 1.73 with N_s <= 4096)
+	return tspws_spectral_first_scale(p, nsmax_env ? nsmax_env : std::max(512u, p->N / (p->V > 2 ? 32u : 16u)));
 }
 
 static int spectral_run_t(tspws_hip_plan *p, SpecDecomp *dc, const float *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st)
