@@ -107,7 +107,7 @@ int  tspws_hip_forward_f32(tspws_hip_plan *plan, const float  *d_x, size_t ntr, 
  * the frame has no such set (N not a power of two >= 1024, odd decimations, ...). */
 unsigned tspws_hip_spectral_first_scale(const tspws_hip_plan *plan, unsigned nsmax);
 /* First scale of the spectral set a single-stage batch of ntr traces gets by the library's own rule (S: FIR kernels only): batches of
- * >= 128 traces and >= 7 M samples of frames with more than two voices per octave send the octaves with D >= 32 through the spectrum;
+ * >= 64 traces and >= 1 M samples (or >= 256 traces) send the octaves with D >= 32 (two-voice frames: D >= 16) through the spectrum;
  * TSPWS_ENGINE=fir / spectral pins the choice. */
 unsigned tspws_hip_spectral_choice(const tspws_hip_plan *plan, size_t ntr);
 int  tspws_hip_forward_spectral_f64(tspws_hip_plan *plan, const double *d_x, size_t ntr, size_t ld, double *d_Y, unsigned nsmax, void *stream);

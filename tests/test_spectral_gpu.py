@@ -116,8 +116,8 @@ def test_frames_without_a_spectral_set(lib):
 
 
 def test_engine_choice_rule(lib):
-    """Default rule (no TSPWS_ENGINE): batches of the many-trace size send the octaves with D >= 32 (two-voice frames: D >= 16) through the
-    spectrum; small batches and frames without a spectral set stay on the FIR kernels."""
+    """Default rule (no TSPWS_ENGINE): batches of >= 64 traces and >= 1 M samples (or >= 256 traces) send the octaves with D >= 32 (two-voice
+    frames: D >= 16) through the spectrum; smaller batches and frames without a spectral set stay on the FIR kernels."""
     if os.environ.get("TSPWS_ENGINE") or os.environ.get("TSPWS_SPEC_NSMAX"):
         pytest.skip("engine pinned by the environment")
     N = 32768
@@ -126,8 +126,11 @@ def test_engine_choice_rule(lib):
     f = abi.OracleFrame.from_params(p, N)
     s = lib.tspws_hip_spectral_choice(pl.h, 1024)
     assert s < pl.S and int(f.D[s]) == 32 and int(f.D[s - 1]) == 16
-    assert lib.tspws_hip_spectral_choice(pl.h, 100) == pl.S          # fewer than 128 traces
-    assert lib.tspws_hip_spectral_choice(pl.h, 200) == pl.S          # fewer than 7 M samples
+    assert lib.tspws_hip_spectral_choice(pl.h, 64) == s              # one full trace block of 2 M samples
+    assert lib.tspws_hip_spectral_choice(pl.h, 48) == pl.S           # fewer than 64 traces
+    ps = tspws.Plan(abi.resolve(abi.default_params(), 4096), 4096)
+    assert lib.tspws_hip_spectral_choice(ps.h, 128) == ps.S          # fewer than 1 M samples and fewer than 256 traces
+    assert lib.tspws_hip_spectral_choice(ps.h, 256) < ps.S
     pm = tspws.Plan(abi.resolve(abi.default_params(type=-3), N), N)
     fm = abi.OracleFrame.from_params(abi.resolve(abi.default_params(type=-3), N), N)
     sm = lib.tspws_hip_spectral_choice(pm.h, 1024)                   # Mexican hat (two voices per octave): one octave more, D >= 16

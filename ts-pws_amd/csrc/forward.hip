@@ -499,13 +499,19 @@ bool tspws_fused_forward(const tspws_hip_plan *p) { return p->n_fusable != 0; }
 // (Mexican hat) stay on the few-trace kernels at every size measured (1024 x 32768: 3.66 vs 4.63; 4096 x 16384: 8.5 vs 9.9) --
 // a trace-lane work item shares its staged rows among the voices of an octave.
 // Engine of a many-trace batch: the first scale of the spectral set (S: every scale on the FIR kernels).  TSPWS_ENGINE=fir / spectral
-// pins it (spectral: every batch that has such a set takes the many-trace path, whatever its size).  Default: batches of the many-trace
-// size (>= 128 traces, >= 7 M samples) send the octaves with D >= 32 (at most max(512, N / 32) outputs; two-voice frames: D >= 16)
+// pins it (spectral: every batch that has such a set takes the many-trace path, whatever its size).  Default: batches of >= 64 traces and
+// >= 1 M samples (or >= 256 traces) send the octaves with D >= 32 (at most max(512, N / 32) outputs; two-voice frames: D >= 16)
 // through the spectrum -- sweeps over 128 .. 4096 traces x 8192 .. 131072 samples (tools/experiments/
 // r5_spec12.sh, default Morlet): 1024 x 32768 2.73 -> 1.81 ms, 2048 x 16384 2.83 -> 1.74, 512 x 65536 3.05 -> 2.02, 1024 x 131072 10.96 ->
 // 7.63 (N_s <= 4096), 4096 x 8192 2.38 -> 1.65; below that size the FIR kernels win (256 x 8192: 0.31 vs 0.38 ms); outputs
 // bit-identical at every size.  TSPWS_SPEC_NSMAX overrides the octave bound.
 static bool many_trace_size(const tspws_hip_plan *p, size_t ntr) { return ntr >= 128 && (double)ntr * (double)p->N >= 7.0 * 1048576.0; }
+// ... and the size from which the spectral engine (with the trace-lane kernel for the finer octaves) beats the few-trace kernels: a full
+// block of 64 traces and >= 1 M samples, or >= 256 traces of any frame that has a spectral set (tools/experiments/r5_thresh.sh, default
+// Morlet, FIR / spectral in ms: 64 x 32768 0.284 / 0.233, 64 x 16384 0.170 / 0.154, 256 x 2048 0.153 / 0.115, 512 x 1024 0.212 / 0.112,
+// 256 x 8192 0.293 / 0.170, 1024 x 4096 0.565 / 0.246; below: 48 x 32768 0.226 / 0.244, 64 x 8192 0.106 / 0.128, 128 x 4096 0.113 / 0.119,
+// 32 x 131072 0.562 / 0.693 -- fewer than 64 traces leave lanes of the trace blocks idle)
+static bool spectral_size(const tspws_hip_plan *p, size_t ntr) { return ntr >= 64 && ((double)ntr * (double)p->N >= 1048576.0 || ntr >= 256); }
 unsigned tspws_spectral_choice(const tspws_hip_plan *p, size_t ntr)
 {
 	static int eng = -1; // 0 auto, 1 fir, 2 spectral
@@ -516,7 +522,7 @@ unsigned tspws_spectral_choice(const tspws_hip_plan *p, size_t ntr)
 		if (const char *m = sweep_env("TSPWS_SPEC_NSMAX")) nsmax_env = (unsigned)std::max(2, atoi(m));
 	}
 	if (eng == 1 || tspws_generic_forward() || !ntr) return p->S;
-	if (eng == 0 && !many_trace_size(p, ntr)) return p->S;
+	if (eng == 0 && !spectral_size(p, ntr)) return p->S;
 	// (two voices per octave -- the Mexican hat --: the trace-lane kernel is at its weakest there (it shares its staged rows among the voices of
 	// an octave), so one octave more goes through the spectrum: 1024 x 32768 Mexican hat 2.47 ms on the few-trace kernels, 1.56 / 1.52 / 1.54 ms
 	// with N_s <= 1024 / 2048 / 4096; 4096 x 8192 2.72 -> 1.51-1.54; 512 x 65536 2.52 -> 1.73 with N_s <= 4096)
