@@ -202,3 +202,38 @@ def test_jackknife_rows_through_the_spectral_engine(lib, kw, mtr, N, n, d):
     np.testing.assert_array_equal(a["jk_mtr"], b["jk_mtr"])
     for c in range(Cn):
         assert abi.relerr(a["jk_ts"][c], b["jk_ts"][c]) < TOL32 and abi.relerr(a["jk_ls"][c], b["jk_ls"][c]) < TOL32, c
+
+
+def test_spectral_engine_over_several_batches(sweeps, torch, monkeypatch):
+    """Large ensembles are walked in batches (transposed copy <= 1 GiB, at most 4096 traces): forced here to 64 / 128 traces per batch
+    (TSPWS_TL_BATCH, sweeps build) on 300 traces -- the later batches add their blocks' planes to the stacks of the first, the last batch is
+    partial; the engine is the default rule's (300 traces: spectral) and the pinned one."""
+    sw, swlib = sweeps
+    mtr, N = 300, 4096
+    X = abi.synth_traces(mtr, N, seed=81)
+    X[17] = 0
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(wu=1.5), X)
+    pl = sw.Plan(sw.resolve(abi.default_params(wu=1.5), N), N)
+    assert swlib.tspws_hip_spectral_choice(pl.h, mtr) < pl.S
+    for b in ("64", "128", None):
+        if b is None:
+            monkeypatch.delenv("TSPWS_TL_BATCH", raising=False)
+        else:
+            monkeypatch.setenv("TSPWS_TL_BATCH", b)
+        ls, ts = pl.stack(torch.as_tensor(X, device="cuda"))
+        torch.cuda.synchronize()
+        assert abi.relerr(ls.cpu().numpy(), want["ls"]) < TOL32 and abi.relerr(ts.cpu().numpy(), want["tsPWS"]) < TOL32, b
+
+
+def test_one_plan_serves_small_and_large_batches(lib, torch):
+    """The fold's class count is sized for the batch: a plan that first sees 3 trace blocks and then 20 (and then 3 again) builds two
+    decompositions of the same spectral set and keeps both."""
+    N = 8192
+    p = abi.default_params()
+    pl = tspws.Plan(tspws.resolve(p, N), N)
+    for mtr, seed in ((160, 1), (1270, 2), (130, 3)):
+        X = abi.synth_traces(mtr, N, seed=90 + seed)
+        ls, ts = pl.stack(torch.as_tensor(X, device="cuda"))
+        torch.cuda.synchronize()
+        want = abi.run_main(abi.oracle().orc_tspws_main, p, X)
+        assert abi.relerr(ls.cpu().numpy(), want["ls"]) < TOL32 and abi.relerr(ts.cpu().numpy(), want["tsPWS"]) < TOL32, mtr
