@@ -103,7 +103,8 @@ __device__ __forceinline__ void fl_lds_barrier()
 #endif
 #if FL_ABLATE
 // bits 0-6: the workgroups of log2(D) class c run (6: D >= 64); for the D >= 64 workgroups: 0x100 lane reduction and partial
-// stores only after the last trace, 0x200 no FMA passes, 0x400 no LDS image store, 0x800 no window prefetch
+// stores only after the last trace, 0x200 no FMA passes, 0x400 no LDS image store, 0x800 no window prefetch; every class: 0x1000 the two
+// barriers only in front of EVEN traces (what a trace pair per thread would share; racy, only the clock counts)
 __device__ unsigned fl_class_mask = 0x7fu;
 #endif
 #if FL_TIMING
@@ -273,6 +274,9 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 
 		for (unsigned qa = 0; qa < d.Q; qa += qt) {
 			const unsigned qn = (d.Q - qa) < qt ? (d.Q - qa) : qt;
+#if FL_ABLATE
+			if (!((fl_class_mask & 0x1000u) && (t & 1)))
+#endif
 			fl_lds_barrier(); // everyone is done reading the previous image (x rows, taps)
 			FL_STAMP(1); // barrier 1 (+ accumulator reset)
 			if (!resident) { stage_taps(qa, qn); load_x(NWT, xv, xt, qa); }
@@ -281,6 +285,9 @@ __device__ __forceinline__ void fwd_lds_body(const TIn *__restrict__ x0, const s
 #endif
 			store_x(xv);
 			FL_STAMP(2); // wait for the prefetched x (vmcnt) + LDS stores
+#if FL_ABLATE
+			if (!((fl_class_mask & 0x1000u) && (t & 1)))
+#endif
 			fl_lds_barrier();
 #if FL_ABLATE
 			if (!(!SMALL && (fl_class_mask & 0x800u)))
