@@ -682,8 +682,10 @@ __global__ void __launch_bounds__(256) k_spec_stack_rows(const SpecRowScale *__r
 	const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const unsigned long long i = (unsigned long long)blockIdx.x * 4 + wv;
 	if (i >= ntot) return;
-	unsigned lo = 0, hi = nrs;
-	while (hi - lo > 1) { const unsigned mid = (lo + hi) >> 1; if (rs[mid].roff <= i) lo = mid; else hi = mid; }
+	// the scale of coefficient i: the last one with roff <= i (rs[0].roff = 0) -- counted by the lanes (a binary search is five DEPENDENT loads;
+	// at most 128 spectral scales)
+	const unsigned long long ro0 = lane < nrs ? rs[lane].roff : ~0ull, ro1 = lane + 64 < nrs ? rs[lane + 64].roff : ~0ull;
+	const unsigned lo = (unsigned)__popcll(__ballot(ro0 <= i)) + (unsigned)__popcll(__ballot(ro1 <= i)) - 1u;
 	const SpecRowScale d = rs[lo];
 	const size_t k = (size_t)(i - d.roff);
 	const double2 *__restrict__ src = d.buf ? b1 : b0;
@@ -1073,40 +1075,62 @@ static int spectral_run(tspws_hip_plan *p, SpecDecomp *dc, const TIn *xT, unsign
 
 // The spectral scales of FEW rows grouped in columns of tps consecutive rows (column c = rows [c tps, (c + 1) tps)): weighted coefficient
 // sets or plane pairs per column (SpecRowsOut); d_x: the rows themselves ([ntr][ld]), transposed here.
+#define SPEC_TR_TILES 4 /* 64-sample tiles per workgroup of the rows transposition */
 template <typename TIn> __global__ void __launch_bounds__(256) k_spec_transpose_rows(const TIn *__restrict__ x, size_t ld, unsigned ntr, unsigned N, unsigned TP,
-                                                                                      TIn *__restrict__ xT, unsigned *__restrict__ amax)
+                                                                                      TIn *__restrict__ xT, unsigned *__restrict__ pmax)
 {
-	// a workgroup transposes 16 tiles of 64 rows x 64 samples and keeps the rows' largest |sample| on the way (the noise floor of the
-	// transforms scales with it): ONE atomic per row and workgroup (one per row and tile was 2048 colliding atomics per row at N = 131072:
-	// 0.9 ms instead of 0.06)
+	// a workgroup transposes SPEC_TR_TILES tiles of 64 rows x 64 samples and keeps the rows' largest |sample| on the way (the noise floor of the
+	// transforms scales with it): written per workgroup to pmax[blockIdx.x][TP], reduced by k_spec_rowmax.  (Atomics on the rows' maxima: one per
+	// row and tile was 2048 colliding atomics per row at N = 131072, 0.9 ms; one per row and 1024 samples still ~0.1 ms of a 0.16-ms kernel that
+	// left three quarters of the CUs' wave slots empty -- 256 workgroups.)
 	__shared__ TIn tile[64][65];
 	const unsigned t0 = blockIdx.y * 64;
 	const unsigned tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 	float m[16];
 #pragma unroll
 	for (int i = 0; i < 16; i++) m[i] = 0.f;
-	for (unsigned it = 0; it < 16; it++) {
-		const unsigned n0 = (blockIdx.x * 16 + it) * 64;
+	for (unsigned it = 0; it < SPEC_TR_TILES; it++) {
+		const unsigned n0 = (blockIdx.x * SPEC_TR_TILES + it) * 64;
 		if (n0 >= N) break;
+		TIn v[16];
 #pragma unroll
 		for (int i = 0; i < 16; i++) {
-			const unsigned r = ty + 4u * (unsigned)i, t = t0 + r, n = n0 + tx;
-			const TIn v = (t < ntr && n < N) ? x[(size_t)t * ld + n] : (TIn)0;
-			tile[r][tx] = v;
-			const float a = fabsf((float)v);
+			const unsigned t = t0 + ty + 4u * (unsigned)i, n = n0 + tx;
+			v[i] = (t < ntr && n < N) ? x[(size_t)t * ld + n] : (TIn)0;
+		}
+		if (it) __syncthreads(); // the previous tile has been read out
+#pragma unroll
+		for (int i = 0; i < 16; i++) {
+			tile[ty + 4 * i][tx] = v[i];
+			const float a = fabsf((float)v[i]);
 			m[i] = (a == a) ? fmaxf(m[i], a) : __int_as_float(0x7f800000);
 		}
 		__syncthreads();
-		for (unsigned r = ty; r < 64; r += 4) { const unsigned n = n0 + r; if (n < N) xT[(size_t)n * TP + t0 + tx] = tile[tx][r]; }
-		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < 16; i++) { const unsigned r = ty + 4u * (unsigned)i, n = n0 + r; if (n < N) xT[(size_t)n * TP + t0 + tx] = tile[tx][r]; }
 	}
 #pragma unroll
 	for (int i = 0; i < 16; i++) {
 		float a = m[i];
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
-		const unsigned t = t0 + ty + 4u * (unsigned)i;
-		if (tx == 0 && t < ntr) atomicMax(amax + t, __float_as_uint(a * 1.0000002f));
+		if (tx == 0) pmax[(size_t)blockIdx.x * TP + t0 + ty + 4u * (unsigned)i] = __float_as_uint(a * 1.0000002f); // (non-negative floats order like their bit patterns)
+	}
+}
+
+// amax[t] = max over the np workgroup rows of pmax[.][t]; grid = TP / 64 blocks of 1024 threads (16 waves share the rows, lane = trace)
+__global__ void __launch_bounds__(1024) k_spec_rowmax(const unsigned *__restrict__ pmax, unsigned np, unsigned TP, unsigned *__restrict__ amax)
+{
+	__shared__ unsigned sm[16][64];
+	const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6, t = blockIdx.x * 64 + lane;
+	unsigned a = 0;
+	for (unsigned g = wv; g < np; g += 16) a = max(a, pmax[(size_t)g * TP + t]);
+	sm[wv][lane] = a;
+	__syncthreads();
+	if (wv == 0) {
+#pragma unroll
+		for (int w = 1; w < 16; w++) a = max(a, sm[w][lane]);
+		amax[t] = a;
 	}
 }
 
@@ -1118,9 +1142,11 @@ static int spectral_rows(tspws_hip_plan *p, SpecDecomp *dc, const TIn *d_x, size
 	int rc;
 	if ((rc = scratch(p, SCR_XT, (size_t)p->N * TP * sizeof(TIn), &v))) return rc;
 	TIn *xT = (TIn *)v;
-	if ((rc = scratch(p, SCR_SPM, (size_t)TP * sizeof(unsigned), &v))) return rc;
-	HIP_TRY(hipMemsetAsync(v, 0, (size_t)TP * sizeof(unsigned), st));
-	hipLaunchKernelGGL((k_spec_transpose_rows<TIn>), dim3((p->N + 1023) / 1024, nblk), dim3(256), 0, st, d_x, ld, ntr, p->N, TP, xT, (unsigned *)v);
+	const unsigned np = (p->N + 64 * SPEC_TR_TILES - 1) / (64 * SPEC_TR_TILES);
+	if ((rc = scratch(p, SCR_SPM, (size_t)TP * (np + 1) * sizeof(unsigned), &v))) return rc;
+	unsigned *amax = (unsigned *)v, *pmax = amax + TP;
+	hipLaunchKernelGGL((k_spec_transpose_rows<TIn>), dim3(np, nblk), dim3(256), 0, st, d_x, ld, ntr, p->N, TP, xT, pmax);
+	hipLaunchKernelGGL(k_spec_rowmax, dim3(nblk), dim3(1024), 0, st, (const unsigned *)pmax, np, TP, amax);
 	return spectral_run<TIn>(p, dc, (const TIn *)xT, TP, ntr, nullptr, nullptr, 0, nullptr, st, &ro, tps, ncol);
 }
 

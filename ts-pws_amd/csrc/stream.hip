@@ -234,16 +234,71 @@ __global__ void __launch_bounds__(256) k_prefix_walk(const float *__restrict__ x
 #define ROWS_WMAX 16
 // WM: columns the instantiation carries running sums for (12: the jackknife n = 10, d = 1 with its plain stack -- 32 registers less than
 // 16, which NL = 16 loads in flight take); NL: independent 16-byte loads in flight per lane
+// The stores of a flush go through LDS to a FIFTH wave of the workgroup (VEC4 form).  gfx950 counts loads and stores in ONE in-order
+// counter (vmcnt), so a wave that stores a group's rows cannot consume any later load before the memory system has acknowledged those stores
+// -- under the read stream that takes 15-25 us per flush: 2 % of the bytes cost the walk 0.14 of its 0.86 ms (tools/read_ceiling.hip:
+// the same walk without the stores 0.72-0.73 ms).  The four loading waves put the finished sums into LDS (W x 1024 doubles) and go on; the
+// writer wave walks the same run descriptors, takes every flush out of LDS and stores it, one contiguous KB per instruction, and waits for
+// nobody's loads.  Two barriers per flush: B "LDS is free again" (the writer has read the previous flush), A "the sums are in LDS".
+#define ROWS_WRITER 64 /* threads of the writer wave behind the 256 loading threads */
+#ifndef ROWS_ABL
+#define ROWS_ABL 0 /* timing ablations (results wrong): 1 the writer stores nothing, 2 no flush at all (no LDS copies, no barriers, no writer) */
+#endif
+typedef double rows_v2d __attribute__((ext_vector_type(2)));
+// a run descriptor into scalar registers (behind the barriers' memory clobbers the compiler reads the list with vector loads: every
+// descriptor field a VGPR, the segment's trace count compared lane by lane)
+__device__ __forceinline__ RunDesc rows_run(const RunDesc *__restrict__ runs, unsigned i)
+{
+	const RunDesc r = runs[i];
+	RunDesc u;
+	u.t0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(r.t0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)r.t0);
+	u.count = (unsigned)__builtin_amdgcn_readfirstlane((int)r.count);
+	u.member = (unsigned)__builtin_amdgcn_readfirstlane((int)r.member);
+	u.flush = (unsigned)__builtin_amdgcn_readfirstlane((int)r.flush);
+	u.frow = (unsigned)__builtin_amdgcn_readfirstlane((int)r.frow);
+	u.pad[0] = u.pad[1] = 0;
+	return u;
+}
+__device__ __forceinline__ void rows_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool VEC4, int WM, int NL>
-__global__ void __launch_bounds__(256) k_rows_walk(const float *__restrict__ x, size_t ld, size_t N, const RunDesc *__restrict__ runs, unsigned qa0,
+__global__ void __launch_bounds__(256 + (VEC4 ? ROWS_WRITER : 0)) k_rows_walk(const float *__restrict__ x, size_t ld, size_t N, const RunDesc *__restrict__ runs, unsigned qa0,
                                                    unsigned qm, unsigned qb1, unsigned W, const unsigned *__restrict__ flush_rows,
                                                    double *__restrict__ rows, const double *__restrict__ carry_in, double *__restrict__ endA,
                                                    double *__restrict__ endB)
 {
+	extern __shared__ __attribute__((aligned(16))) double wl[]; // VEC4: [W][1024] sums on their way to the writer
 	const unsigned seg = blockIdx.y;
 	const unsigned r0 = seg ? qm : qa0, r1 = seg ? qb1 : qm;
-	const size_t col = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-	if (col >= N) return;
+	if (VEC4 && threadIdx.x >= 256) { // ---- the writer wave
+		if (ROWS_ABL == 2) return;
+		const unsigned lane = threadIdx.x - 256;
+		const size_t c0 = (size_t)blockIdx.x * 1024;
+		for (unsigned ri = r0; ri < r1; ri++) {
+			const unsigned fl = runs[ri].flush;
+			if (!fl) continue;
+			unsigned fr = runs[ri].frow;
+			rows_lds_barrier(); // B (the LDS reads of the previous flush have landed: lgkmcnt(0) above)
+			rows_lds_barrier(); // A
+#pragma unroll 1
+			for (unsigned c = 0; c < (unsigned)WM; c++) {
+				if (!((fl >> c) & 1u)) continue;
+				double *dst = rows + (size_t)flush_rows[fr++] * N + c0;
+				const double *srcl = wl + (size_t)c * 1024;
+				double2 v[8];
+#pragma unroll
+				for (int k = 0; k < 8; k++) v[k] = *(const double2 *)(srcl + (k * 64 + lane) * 2);
+				if (ROWS_ABL != 1)
+#pragma unroll
+				for (int k = 0; k < 8; k++) // (N % 4 == 0; non-temporal: the rows leave in the burst instead of dribbling out of L2 between the reads)
+					if (c0 + (size_t)(k * 64 + lane) * 2 < N) __builtin_nontemporal_store((rows_v2d){v[k].x, v[k].y}, (rows_v2d *)(dst + (k * 64 + lane) * 2));
+			}
+		}
+		return;
+	}
+	size_t col = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+	const bool live = col < N; // (VEC4: lanes past the end ride along on column 0 -- they meet the barriers -- and write nothing)
+	if (!live) { if (!VEC4) return; col = 0; }
 	const unsigned rem = (N - col) < 4 ? (unsigned)(N - col) : 4u;
 	double P[WM][4];
 #pragma unroll
@@ -257,45 +312,21 @@ __global__ void __launch_bounds__(256) k_rows_walk(const float *__restrict__ x, 
 		}
 	}
 	typedef float v4f __attribute__((ext_vector_type(4)));
-	for (unsigned ri = r0; ri < r1; ri++) {
-		const RunDesc rd = runs[ri];
-		const float *src = x + rd.t0 * ld + col;
-		double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-		if (VEC4) { // the plain pass's loop: eight independent 16-byte non-temporal loads in flight, then their additions
-			unsigned t = 0;
-			for (; t + NL <= rd.count; t += NL) {
-				v4f v[NL];
-#pragma unroll
-				for (int j = 0; j < NL; j++) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)(t + j) * ld));
-#pragma unroll
-				for (int j = 0; j < NL; j++) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
-			}
-			if (t < rd.count) { // the remainder as one batch: rows past the end re-read the last row and are not added
-				const unsigned nv = rd.count - t, last = rd.count - 1u;
-				v4f v[NL];
-#pragma unroll
-				for (int j = 0; j < NL; j++) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)(t + (unsigned)j < rd.count ? t + (unsigned)j : last) * ld));
-#pragma unroll
-				for (int j = 0; j < NL; j++)
-					if ((unsigned)j < nv) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
-			}
-		} else {
-			for (unsigned t = 0; t < rd.count; t++) {
-				const float *r = src + (size_t)t * ld;
-				a0 += (double)r[0];
-				if (rem > 1) a1 += (double)r[1];
-				if (rem > 2) a2 += (double)r[2];
-				if (rem > 3) a3 += (double)r[3];
-			}
-		}
+	double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+	// the end of a run: its sum goes to the columns it belongs to; a column whose group ends there hands its row to the writer and starts over
+	auto run_end = [&](const RunDesc &rd) {
 		unsigned fr = rd.frow;
+		if (VEC4 && rd.flush && ROWS_ABL != 2) rows_lds_barrier(); // B: the writer has taken the previous flush out of LDS
 #pragma unroll
 		for (int c = 0; c < WM; c++) {
 			if ((rd.member >> c) & 1u) { P[c][0] += a0; P[c][1] += a1; P[c][2] += a2; P[c][3] += a3; } // (wave-uniform)
 			if ((rd.flush >> c) & 1u) {
-				double *dst = rows + (size_t)flush_rows[fr++] * N + col;
-				if (VEC4) { *(double2 *)dst = make_double2(P[c][0], P[c][1]); *(double2 *)(dst + 2) = make_double2(P[c][2], P[c][3]); }
-				else {
+				if (VEC4 && ROWS_ABL == 2) { }
+				else if (VEC4) {
+					double *dl = wl + (size_t)c * 1024 + threadIdx.x * 4;
+					*(double2 *)dl = make_double2(P[c][0], P[c][1]); *(double2 *)(dl + 2) = make_double2(P[c][2], P[c][3]);
+				} else {
+					double *dst = rows + (size_t)flush_rows[fr++] * N + col;
 #pragma unroll
 					for (int k = 0; k < 4; k++) if ((unsigned)k < rem) dst[k] = P[c][k];
 				}
@@ -303,9 +334,78 @@ __global__ void __launch_bounds__(256) k_rows_walk(const float *__restrict__ x, 
 				for (int k = 0; k < 4; k++) P[c][k] = 0;
 			}
 		}
+		if (VEC4 && rd.flush && ROWS_ABL != 2) rows_lds_barrier(); // A: the sums are in LDS
+		a0 = 0; a1 = 0; a2 = 0; a3 = 0;
+	};
+	if (VEC4) {
+		// The runs of a segment are consecutive traces, so the loads need not care where a run ends: ONE stream of batches of NL rows over
+		// the whole segment (NL independent 16-byte non-temporal loads in flight, then their additions -- the plain pass's loop), a run's end
+		// handled inside the batch that holds its last rows and the next run's first, the next run's descriptor requested a run ahead.  (Rounds 4-5: a load loop per run -- every run end, once per
+		// ~30 traces at cfg4, re-read a partial batch and waited for the next descriptor with nothing in flight: 0.80 ms without any flush
+		// against 0.73 of the same walk in one run, tools/read_ceiling.hip.)  The additions keep their order, the rows their last bit.
+		if (r0 < r1) {
+			const RunDesc first = rows_run(runs, r0), lastd = rows_run(runs, r1 - 1);
+			const unsigned long long total = lastd.t0 + lastd.count - first.t0; // traces of the segment
+			const float *src = x + first.t0 * ld + col;
+			unsigned ri = r0;
+			RunDesc rd = first, rn = rows_run(runs, r0 + 1 < r1 ? r0 + 1 : r0);
+			unsigned left = rd.count;
+			unsigned long long t = 0;
+			bool over = false;
+			while (!over && t < total) {
+				// whole batches inside the current run: the plain pass's loop, nothing else in it
+				for (; left >= (unsigned)NL; left -= NL, t += NL) {
+					v4f v[NL];
+#pragma unroll
+					for (int j = 0; j < NL; j++) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)(t + (unsigned)j) * ld));
+#pragma unroll
+					for (int j = 0; j < NL; j++) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
+				}
+				// the batch with the run's last rows (< NL, possibly none) and the first rows of what follows: rows [j0, j1) of the batch belong
+				// to the current run, the others add +0 (selects); once per run
+				v4f v[NL];
+#pragma unroll
+				for (int j = 0; j < NL; j++) { // (past the end of the segment: the last row again, not added)
+					const unsigned long long tj = t + (unsigned)j < total ? t + (unsigned)j : total - 1;
+					v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)tj * ld));
+				}
+				const unsigned nb = total - t < (unsigned long long)NL ? (unsigned)(total - t) : (unsigned)NL;
+				unsigned j0 = 0;
+#pragma unroll 1
+				do {
+					const unsigned n = left < nb - j0 ? left : nb - j0, j1 = j0 + n;
+#pragma unroll
+					for (int j = 0; j < NL; j++) {
+						const bool in = (unsigned)j >= j0 && (unsigned)j < j1;
+						a0 += in ? (double)v[j].x : 0.0; a1 += in ? (double)v[j].y : 0.0; a2 += in ? (double)v[j].z : 0.0; a3 += in ? (double)v[j].w : 0.0;
+					}
+					left -= n; j0 = j1;
+					if (left == 0) {
+						run_end(rd);
+						if (++ri >= r1) { over = true; break; } // (the runs tile the segment: nothing is left when the last one ends)
+						rd = rn; left = rd.count;
+						rn = rows_run(runs, ri + 1 < r1 ? ri + 1 : ri);
+					}
+				} while (j0 < nb);
+				t += nb;
+			}
+		}
+	} else {
+		for (unsigned ri = r0; ri < r1; ri++) {
+			const RunDesc rd = runs[ri];
+			const float *src = x + rd.t0 * ld + col;
+			for (unsigned t = 0; t < rd.count; t++) {
+				const float *r = src + (size_t)t * ld;
+				a0 += (double)r[0];
+				if (rem > 1) a1 += (double)r[1];
+				if (rem > 2) a2 += (double)r[2];
+				if (rem > 3) a3 += (double)r[3];
+			}
+			run_end(rd);
+		}
 	}
 	double *end = seg ? endB : endA; // the live sums of the segment
-	if (end) {
+	if (end && live) {
 #pragma unroll
 		for (int c = 0; c < WM; c++)
 			if ((unsigned)c < W) {
@@ -346,7 +446,12 @@ int tspws_rows_walk_launch(const float *d_x, size_t ld, size_t N, const RunDesc 
 	if (nl < 0) { const char *e = sweep_env("TSPWS_WALK_NL"); nl = e ? atoi(e) : 8; } // (cfg4: 0.888 ms with 8, 0.903 with 16; the 16-column form: 0.909)
 	const dim3 g2(grid, two ? 2 : 1);
 	const double *cin = carry_in ? carry : nullptr;
-#define ROWS_WALK(V, WMV, NLV) hipLaunchKernelGGL((k_rows_walk<V, WMV, NLV>), g2, dim3(256), 0, st, d_x, ld, N, d_runs, q0, qm, q1, W, d_flush_rows, d_rows, cin, endA, endB)
+	// (the VEC4 form: 256 loading threads + the writer wave, W x 8 KB of LDS for the sums on their way out -- 128 KB at 16 columns)
+#define ROWS_WALK(V, WMV, NLV) do { \
+		const size_t lds = (V) ? (size_t)(WMV) * 1024 * sizeof(double) : 0; \
+		if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_rows_walk<V, WMV, NLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); /* (per device: every launch) */ \
+		hipLaunchKernelGGL((k_rows_walk<V, WMV, NLV>), g2, dim3(256 + ((V) ? ROWS_WRITER : 0)), lds, st, d_x, ld, N, d_runs, q0, qm, q1, W, d_flush_rows, d_rows, cin, endA, endB); \
+	} while (0)
 	if (!vec) ROWS_WALK(false, 16, 8);
 	else if (W <= 12 && nl == 16) ROWS_WALK(true, 12, 16);
 	else if (W <= 12) ROWS_WALK(true, 12, 8);
