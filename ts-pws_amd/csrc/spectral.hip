@@ -491,6 +491,7 @@ __global__ void __launch_bounds__(256) k_spec_fold_mfma(const double2 *__restric
                                                         unsigned R, unsigned logsteps, unsigned N, unsigned nblk, double2 *__restrict__ G, size_t grows)
 {
 	constexpr int NS = 16;
+	__shared__ double tile[4][4][2][64]; // per wave: finished bins on their way out, four scales at a time ([re | im][trace])
 	const unsigned lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const unsigned r = blockIdx.x, g = blockIdx.y, tb = blockIdx.z * 4 + wv;
 	if (tb >= nblk) return;
@@ -539,17 +540,38 @@ __global__ void __launch_bounds__(256) k_spec_fold_mfma(const double2 *__restric
 		}
 		__builtin_amdgcn_sched_barrier(0);
 		const unsigned c = c0 + 3;
-		if (((c + 1) & mask0) == 0) { // (wave-uniform) some scale of the group completes a bin: the lanes of those scales store and start over
+		if (((c + 1) & mask0) == 0) { // (wave-uniform) some scale of the group completes a bin: the lanes of those scales hand it over and start over
+			// A finished bin of a scale = 64 traces x 16 bytes = one 1-KB row of G, but the matrix pipe leaves it in 4 lanes x 16 registers: stored from
+			// there it is 16 store instructions of 64-byte pieces per completion, whatever the number of scales that complete -- a thousand store
+			// instructions per wave at N = 131072, and the loads of the next steps wait behind them (one in-order counter for loads and stores).  Through
+			// the wave's LDS tile the row goes out as ONE instruction per completed scale.
 			const bool done = my.ld < 31u && ((c + 1) & ((1u << my.ld) - 1u)) == 0;
-			if (done) {
-				const unsigned ilo = my.lb ? (__brev(c >> my.ld) >> (32 - my.lb)) : 0u;
-				double2 *dst = gc + (my.goff + r + (size_t)R * ilo) * 64;
+			unsigned m = (unsigned)(__ballot(done) & 0xffffull); // (lanes 0 .. 15: lk = 0, one per scale)
+			const unsigned rank = (unsigned)__popc(m & ((1u << li) - 1u)); // of this lane's scale among the completing ones
+#pragma unroll 1
+			for (unsigned base = 0; m; base += 4) { // four completing scales at a time (4 KB of LDS per wave)
+				if (done && rank - base < 4u) { // (real and imaginary parts apart: pairs would have to be gathered into register quads first -- 64 moves and registers)
+					double *tr = tile[wv][rank - base][0], *ti = tile[wv][rank - base][1];
+					const unsigned sw = (rank - base) << 3; // (swizzled: the four rows lie 1 KB apart, i.e. on the same banks)
 #pragma unroll
-				for (int t = 0; t < 4; t++) {
+					for (int t = 0; t < 4; t++)
 #pragma unroll
-					for (int q = 0; q < 4; q++) dst[16 * t + 4 * q] = make_double2(cre[t][q], cim[t][q]);
-					cre[t] = (spec_v4d){0, 0, 0, 0}; cim[t] = (spec_v4d){0, 0, 0, 0};
+						for (int q = 0; q < 4; q++) { tr[(unsigned)(16 * t + 4 * q + (int)lk) ^ sw] = cre[t][q]; ti[(unsigned)(16 * t + 4 * q + (int)lk) ^ sw] = cim[t][q]; }
 				}
+#pragma unroll 1
+				for (unsigned k = 0; k < 4 && m; k++) {
+					const unsigned sidx = (unsigned)__builtin_ctz(m);
+					m &= m - 1u;
+					const unsigned sld = (unsigned)__builtin_amdgcn_readlane((int)my.ld, (int)sidx), slb = (unsigned)__builtin_amdgcn_readlane((int)my.lb, (int)sidx);
+					const unsigned long long sgo = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(my.goff >> 32), (int)sidx) << 32) |
+					                               (unsigned)__builtin_amdgcn_readlane((int)(unsigned)my.goff, (int)sidx);
+					const unsigned ilo = slb ? (__brev(c >> sld) >> (32 - slb)) : 0u;
+					G[((size_t)tb * grows + sgo + r + (size_t)R * ilo) * 64 + lane] = make_double2(tile[wv][k][0][lane ^ (k << 3)], tile[wv][k][1][lane ^ (k << 3)]);
+				}
+			}
+			if (done) {
+#pragma unroll
+				for (int t = 0; t < 4; t++) { cre[t] = (spec_v4d){0, 0, 0, 0}; cim[t] = (spec_v4d){0, 0, 0, 0}; }
 			}
 		}
 #pragma unroll
