@@ -361,6 +361,7 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 					}
 					if ((rc = tspws_spectral_rows_f64(p, dc, (const double *)d_x, ld, (unsigned)ntr, fz->tps, *fz, sx))) return rc;
 					fz->spec_first = sf;
+					if (fz->ev_mid && sx == st) { HIP_TRY(hipEventRecord(fz->ev_mid, st)); fz->mid_recorded = true; }
 					if (sf == 0) { fz->applied = true; return 0; } // (every scale went that way)
 					rg.s0 = 0; rg.s1 = sf;
 					spec_join = sx != st;

@@ -592,6 +592,7 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	if (fin_env == -2) { const char *e = sweep_env("TSPWS_JK_FINAL"); fin_env = e ? atoi(e) : -1; }
 	const bool fin_in_kernel = fin_env < 0 ? mp.nstage == 1 : fin_env != 0;
 	unsigned last_spec_first = pl->S; // scales [.., S) of the last stage were completed by the spectral engine (forward.hip)
+	bool lin_mid = false;             // ... and its chain recorded ev_mid behind itself
 	for (unsigned sg = 0; sg < mp.nstage; sg++) {
 		// HBM-bound half of the stage on the caller's stream: its rows from its traces
 		if ((rc = masked_stream_stage(pl, mp, dv, d_x, ld, d_rows, sg, st))) return rc;
@@ -611,9 +612,14 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 			f.keep_slice = with_stack ? (int)C : -1; f.keepST = (double2 *)OUT + (size_t)W * nc;
 			fz.allow_spec = true; // (the far-decimated octaves of these ng W rows may go through the spectral engine: forward.hip decides)
 		}
+		if (fuse && C && sg + 1 == mp.nstage) { // (the linear stacks of the replicas may start behind the spectral chain, beside the FIR kernels)
+			if (!pl->ev_mid) HIP_TRY(hipEventCreateWithFlags(&pl->ev_mid, hipEventDisableTiming | hipEventDisableSystemFence));
+			fz.ev_mid = pl->ev_mid;
+		}
 		if ((rc = tspws_forward_parts_f64(pl, d_rows + (size_t)r0 * N, r1 - r0, N, part + (size_t)r0 * pl->npart, pl->xf, fuse ? &fz : nullptr, ScaleRange()))) return rc;
 		if (fuse) stage_spec_first = fz.spec_first;
 		last_spec_first = stage_spec_first;
+		lin_mid = fuse && fz.mid_recorded;
 	}
 	HIP_TRY(hipEventRecord(pl->stage_ev[mp.nstage], pl->xf));
 	// time-domain linear stacks of the replicas (:799-811) while the last transforms run -- unless those start with the spectral chain's
@@ -621,8 +627,12 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	// 0.03 + 0.06 (cfg4), so the linear stacks then wait for the transforms
 	const bool lin_first = last_spec_first >= pl->S;
 	if (C && lin_first) hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, W, mp.gps);
+	else if (C && lin_mid) { // behind the chain, beside k_fwd_lds (FP64-bound; the linear stacks are 0.02 ms of HBM reads)
+		HIP_TRY(hipStreamWaitEvent(st, pl->ev_mid, 0));
+		hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, W, mp.gps);
+	}
 	HIP_TRY(hipStreamWaitEvent(st, pl->stage_ev[mp.nstage], 0));
-	if (C && !lin_first) hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, W, mp.gps);
+	if (C && !lin_first && !lin_mid) hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, W, mp.gps);
 	// stacks of every column: its plane pairs in stage order + its split partials in group order; weights by the same launch
 	// (K = KM, M = the column's traces)
 	WeightArgs wa;

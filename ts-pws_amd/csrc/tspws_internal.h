@@ -134,6 +134,10 @@ struct FuseOut {
 	// sets / plane pairs of every slice written), whatever their fuse_ok / nsplit say
 	bool allow_spec = false;
 	unsigned spec_first = ~0u;
+	// recorded on the forward stream behind the spectral chain (if one ran there) and in front of the FIR kernels of the finer octaves: work
+	// that only must not run beside the chain's transposition can start here (resample.hip: the replicas' linear stacks)
+	hipEvent_t ev_mid = nullptr;
+	bool mid_recorded = false;
 };
 
 // Phase weighting of one coefficient (tspws_biased :909-943, tspws_unbiased :965-984).
@@ -213,6 +217,7 @@ struct tspws_hip_plan {
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	hipStream_t xs = nullptr;          // ... and the spectral chain of a few-row launch beside both (forward.hip)
 	hipEvent_t ev_xs0 = nullptr, ev_xs1 = nullptr;
+	hipEvent_t ev_mid = nullptr;         // behind the spectral chain of the masked call's last stage (FuseOut::ev_mid)
 	// optional timing inside tspws_hip_stack (bench.py): three events per call -- start, end of the streaming stage, end
 	// Events that ride on kernel launches instead of being recorded as packets of their own (hipExtLaunchKernelGGL: the launch's
 	// start / completion signal IS the event; tools/probes/xstream_probe.hip: the next kernel of the stream follows 2.5 us after
