@@ -519,24 +519,28 @@ __global__ void __launch_bounds__(256) k_spec_fold_mfma(const double2 *__restric
 		for (int t = 0; t < 4; t++) xr[t] = row[16 * t];
 		hr = hp[(size_t)c * NS];
 	};
-	double2 xa[4], xn[4], hb, hn;
-	int fa, fn = 0;
-	request(0, xa, hb, fa);
+	// Three operand sets in rotation (the loop body three times, no register moves: a copy of a set in flight would wait for it): the rows of
+	// the block after next are requested before this block's MFMAs.  With one set ahead a wave had ~500 cycles of MFMAs to cover a round trip of
+	// several thousand; with few trace blocks (rows in columns: two) the kernel is one wave lifetime long and that round trip is all it waits for.
+	struct Ops { double2 x[4]; double2 h; int f; };
+	Ops oa, ob, oc;
+	request(0, oa.x, oa.h, oa.f);
+	request(4 < nsteps ? 4u : 0u, ob.x, ob.h, ob.f);
+	auto block = [&](Ops &cur, Ops &far, const unsigned c0) {
+		request(c0 + 8 < nsteps ? c0 + 8 : 0u, far.x, far.h, far.f); // (past the last block: a harmless re-request of the first -- no branch around the loads)
 #pragma unroll
-	for (int t = 0; t < 4; t++) xa[t].y = __hiloint2double(__double2hiint(xa[t].y) ^ fa, __double2loint(xa[t].y));
-	for (unsigned c0 = 0; c0 < nsteps; c0 += 4) {
-		request(c0 + 4 < nsteps ? c0 + 4 : 0u, xn, hn, fn); // (after the last block: a harmless re-request of the first -- no branch around the loads)
+		for (int t = 0; t < 4; t++) cur.x[t].y = __hiloint2double(__double2hiint(cur.x[t].y) ^ cur.f, __double2loint(cur.x[t].y)); // conjugate of a mirrored row
 		__builtin_amdgcn_sched_barrier(0);
 		// (eight independent accumulators between two MFMAs on the same one)
 #pragma unroll
 		for (int t = 0; t < 4; t++) {
-			cre[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t].x, hb.x, cre[t], 0, 0, 0);
-			cim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t].x, hb.y, cim[t], 0, 0, 0);
+			cre[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.x[t].x, cur.h.x, cre[t], 0, 0, 0);
+			cim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.x[t].x, cur.h.y, cim[t], 0, 0, 0);
 		}
 #pragma unroll
 		for (int t = 0; t < 4; t++) {
-			cre[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[t].y, hb.y, cre[t], 0, 0, 0);
-			cim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t].y, hb.x, cim[t], 0, 0, 0);
+			cre[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cur.x[t].y, cur.h.y, cre[t], 0, 0, 0);
+			cim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.x[t].y, cur.h.x, cim[t], 0, 0, 0);
 		}
 		__builtin_amdgcn_sched_barrier(0);
 		const unsigned c = c0 + 3;
@@ -574,9 +578,11 @@ __global__ void __launch_bounds__(256) k_spec_fold_mfma(const double2 *__restric
 				for (int t = 0; t < 4; t++) { cre[t] = (spec_v4d){0, 0, 0, 0}; cim[t] = (spec_v4d){0, 0, 0, 0}; }
 			}
 		}
-#pragma unroll
-		for (int t = 0; t < 4; t++) xa[t] = make_double2(xn[t].x, __hiloint2double(__double2hiint(xn[t].y) ^ fn, __double2loint(xn[t].y)));
-		hb = hn;
+	};
+	for (unsigned c0 = 0;;) {
+		block(oa, oc, c0); if ((c0 += 4) >= nsteps) break;
+		block(ob, oa, c0); if ((c0 += 4) >= nsteps) break;
+		block(oc, ob, c0); if ((c0 += 4) >= nsteps) break;
 	}
 	if (my.ld == 31u && my.lb != 31u) { // partial sums of the classes (lb == 31: an idle pad slot)
 		double2 *dst = gc + (my.goff + r) * 64;
