@@ -488,13 +488,17 @@ __global__ void __launch_bounds__(512) k_spec_fold(const double2 *__restrict__ X
 // order as above, four at a time (every spectral scale has D >= 8: a bin can only complete with the last step of an aligned group of four).
 typedef double spec_v4d __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) k_spec_fold_mfma(const double2 *__restrict__ Xh, size_t xrows, const double2 *__restrict__ tab, const SpecSlot *__restrict__ slots,
-                                                        unsigned R, unsigned logsteps, unsigned N, unsigned nblk, double2 *__restrict__ G, size_t grows)
+                                                        unsigned R, unsigned logsteps, unsigned N, unsigned nblk, unsigned ngroups, double2 *__restrict__ G, size_t grows)
 {
 	constexpr int NS = 16;
 	__shared__ double tile[4][4][2][64]; // per wave: finished bins on their way out, four scales at a time ([re | im][trace])
 	const unsigned lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const unsigned r = blockIdx.x, g = blockIdx.y, tb = blockIdx.z * 4 + wv;
-	if (tb >= nblk) return;
+	// waves of a workgroup: four trace blocks of one scale group -- or, with one / two trace blocks (rows in columns), the blocks of four / two
+	// scale groups: they walk the same rows of the spectra at the same time, so the groups' reads of a row are ONE read from memory (cfg4: 20
+	// scales in two groups, the fold moved 0.74 GB and ran at the caches' rate)
+	const unsigned bpw = nblk >= 3 ? 4u : nblk; // trace blocks per workgroup (gpw = 4 / bpw groups)
+	const unsigned r = blockIdx.x, g = blockIdx.y * (4u / bpw) + wv / bpw, tb = blockIdx.z * 4 + wv % bpw;
+	if (tb >= nblk || g >= ngroups) return;
 	const unsigned nsteps = 1u << logsteps, M = N >> 1;
 	const unsigned li = lane & 15, lk = lane >> 4;  // A: (trace li of a tile, step lk); B: (step lk, scale li); C: traces 4 lk .. + 3 of scale li
 	const double2 *__restrict__ hp = tab + ((size_t)g * R + r) * nsteps * NS + li; // table stream: step c, slot s at [c NS + s]
@@ -1050,8 +1054,9 @@ static int spectral_run(tspws_hip_plan *p, SpecDecomp *dc, const TIn *xT, unsign
 	// multiply-and-fold
 	static const bool fold_lds = sweep_env("TSPWS_SPEC_FOLD") && !strcmp(sweep_env("TSPWS_SPEC_FOLD"), "lds"); // A/B: the vector-FMA form
 	if (sp->NS == 16 && !fold_lds) {
-		hipLaunchKernelGGL(k_spec_fold_mfma, dim3(sp->R, sp->ngroups, (nblk + 3) / 4), dim3(256), 0, st, Xh, xrows, (const double2 *)sp->d_tab, (const SpecSlot *)sp->d_slots, sp->R,
-		                   sp->logsteps, N, nblk, G, sp->grows);
+		const unsigned gpw = nblk >= 3 ? 1u : 4u / nblk; // scale groups per workgroup (k_spec_fold_mfma)
+		hipLaunchKernelGGL(k_spec_fold_mfma, dim3(sp->R, (sp->ngroups + gpw - 1) / gpw, (nblk + 3) / 4), dim3(256), 0, st, Xh, xrows, (const double2 *)sp->d_tab,
+		                   (const SpecSlot *)sp->d_slots, sp->R, sp->logsteps, N, nblk, sp->ngroups, G, sp->grows);
 	} else {
 		static int ntb = -1;
 		if (ntb < 0) { const char *e = sweep_env("TSPWS_SPEC_NTB"); ntb = (e && atoi(e) == 1) ? 1 : 2; } // sweeps
