@@ -361,8 +361,7 @@ __global__ void __launch_bounds__(256 + (VEC4 ? ROWS_WRITER : 0)) k_rows_walk(co
 #pragma unroll
 					for (int j = 0; j < NL; j++) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
 				}
-				// the batch with the run's last rows (< NL, possibly none) and the first rows of what follows: rows [j0, j1) of the batch belong
-				// to the current run, the others add +0 (selects); once per run
+				// the batch with the run's last rows (< NL, possibly none) and the first rows of what follows: once per run
 				v4f v[NL];
 #pragma unroll
 				for (int j = 0; j < NL; j++) { // (past the end of the segment: the last row again, not added)
@@ -375,9 +374,9 @@ __global__ void __launch_bounds__(256 + (VEC4 ? ROWS_WRITER : 0)) k_rows_walk(co
 				do {
 					const unsigned n = left < nb - j0 ? left : nb - j0, j1 = j0 + n;
 #pragma unroll
-					for (int j = 0; j < NL; j++) {
-						const bool in = (unsigned)j >= j0 && (unsigned)j < j1;
-						a0 += in ? (double)v[j].x : 0.0; a1 += in ? (double)v[j].y : 0.0; a2 += in ? (double)v[j].z : 0.0; a3 += in ? (double)v[j].w : 0.0;
+					for (int j = 0; j < NL; j++) { // rows [j0, j1) of the batch belong to the current run (uniform branches: with selects every row costs
+						// a convert, two selects and an add per round of this loop, and with one wave per SIMD nothing hides them)
+						if (__builtin_amdgcn_readfirstlane((int)((unsigned)j >= j0 && (unsigned)j < j1))) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
 					}
 					left -= n; j0 = j1;
 					if (left == 0) {
