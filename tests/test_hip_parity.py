@@ -1235,3 +1235,43 @@ def test_sharded_jackknife_three_processes_over_gloo(lib, torch, tmp_path):
         assert abi.relerr(got["ls"], want["ls"]) < TOL32 and abi.relerr(got["ts"], want["tsPWS"]) < TOL32
         for c in range(len(want["jk_mtr"])):
             assert abi.relerr(got["jl"][c], want["jk_ls"][c]) < TOL32 and abi.relerr(got["jt"][c], want["jk_ts"][c]) < TOL32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,mtr,Cn,K,pflip", [
+    (2052, 157, 3, 5, 0.5),      # 4 | N, not 1024 | N: the last column block has ONE live thread; runs of 1-3 traces: several run ends per batch of 8 rows
+    (1028, 90, 14, 4, 0.3),      # 14 replicas: the 16-column instantiation of the walk (128 KB of LDS for the writer wave)
+    (4096, 300, 10, 10, 0.02),   # long runs with a few short ones in between
+    (3000, 131, 5, 7, 0.5),      # N % 4 == 0, ragged; Kmax does not divide anything
+    (1501, 77, 4, 3, 0.4),       # odd N: the scalar form of the walk (no writer wave)
+])
+def test_one_pass_rows_of_arbitrary_selections(lib, torch, N, mtr, Cn, K, pflip):
+    """The rows of the one-pass walk (k_rows_walk: running sums per column, flushes through LDS to the writer wave, one load stream over the
+    run ends) for ARBITRARY selections -- not only the jackknife's day bins -- against sums formed here: row (c, g) = the traces k of replica c
+    with floor(k_sel K / K_c) = g (ts_pws1f_lib.c:766), the plain groups min(floor(i K / mtr), K - 1) (:876)."""
+    p = tspws.resolve(abi.default_params(Kmax=K, unbiased=1, jackknife_n=6, jackknife_d=1), N)
+    pl = tspws.Plan(p, N)
+    X = abi.synth_traces(mtr, N, seed=31 + Cn)
+    rng = np.random.default_rng(100 + N)
+    sel = np.ones((Cn, mtr), np.int8)
+    for c in range(Cn):  # a 0/1 sequence that flips with probability pflip per trace
+        flips = rng.random(mtr) < pflip
+        sel[c] = (np.cumsum(flips) + c) % 2
+    sel[0, :] = 1 if Cn > 1 else sel[0]  # one replica that keeps every trace
+    Xd = torch.as_tensor(X, device="cuda")
+    pl.jackknife_local(Xd, 0, mtr, sel)
+    torch.cuda.synchronize()
+    rows = pl.jackknife_buffer(Cn).cpu().numpy().reshape(Cn, K, N)
+    main = pl.reduce_buffer(mtr).cpu().numpy().reshape(K, N)
+    X64 = X.astype(np.float64)
+    want_main = np.zeros((K, N))
+    for i in range(mtr):
+        want_main[min(i * K // mtr, K - 1)] += X64[i]
+    scale = np.abs(want_main).max()
+    assert np.abs(main - want_main).max() <= 1e-12 * scale
+    for c in range(Cn):
+        idx = np.flatnonzero(sel[c] == 1)
+        want = np.zeros((K, N))
+        for k, i in enumerate(idx):
+            want[min(k * K // max(len(idx), 1), K - 1)] += X64[i]
+        assert np.abs(rows[c] - want).max() <= 1e-12 * scale, c
