@@ -343,25 +343,34 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 					SpecDecomp *dc = nullptr;
 					int rc;
 					if ((rc = tspws_spectral_decomp(p, sf, (unsigned)((ntr + 63) / 64), &dc, true))) return rc;
-					// the spectral chain (transposition, transforms through HBM: bandwidth-bound) on its own stream beside the FIR kernels of the
-					// finer octaves (FP64-bound) -- joined before this function returns
-					// (measured on cfg4, 110 rows: side by side the two take 1.70 ms -- the chain's LDS users leave room for ONE 80-KB workgroup of
-					// k_fwd_lds per CU, its transposition starves --, one after the other 1.05 ms, the FIR kernels alone 1.20: serial by default)
-					static const bool serial = sweep_env("TSPWS_SPEC_PARALLEL") == nullptr;
+					// the spectral chain (transforms through HBM: bandwidth-bound) on its own stream beside the FIR kernels of the finer octaves
+					// (FP64-bound), joined before this function returns.  The FIR kernels start BEHIND the chain's transposition: k_fwd_lds takes
+					// all of a CU's LDS (two 80-KB workgroups), and a transposition that has to wait for its 33 KB starves (mid-round, with the
+					// 0.16-ms transposition and the FIR kernels launched first, the pair took 1.70 ms side by side against 1.05 one after the
+					// other); the chain's other kernels need no LDS to speak of and fill the register space the FIR kernels leave.  cfg4 with
+					// the end-of-round kernels: 2.11 ms serial, 2.05 side by side with the FIR kernels first, 2.0x in this order
+					// (tools/experiments/r5_rows_parallel.sh; TSPWS_SPEC_PARALLEL=0, sweeps build: serial).
+					static const bool serial = sweep_env("TSPWS_SPEC_PARALLEL") && !strcmp(sweep_env("TSPWS_SPEC_PARALLEL"), "0");
 					hipStream_t sx = st;
+					hipEvent_t behind_tr = nullptr;
 					if (!serial && sf > 0) {
 						const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
 						if (!p->xs) HIP_TRY(hipStreamCreateWithFlags(&p->xs, hipStreamNonBlocking));
 						if (!p->ev_xs0) HIP_TRY(hipEventCreateWithFlags(&p->ev_xs0, evf));
 						if (!p->ev_xs1) HIP_TRY(hipEventCreateWithFlags(&p->ev_xs1, evf));
+						if (!p->ev_xs2) HIP_TRY(hipEventCreateWithFlags(&p->ev_xs2, evf));
 						hipEvent_t ready = p->le.ready;
 						if (!ready) { ready = p->ev_xs0; HIP_TRY(hipEventRecord(ready, st)); }
 						HIP_TRY(hipStreamWaitEvent(p->xs, ready, 0));
 						sx = p->xs;
+						behind_tr = fz->ev_mid ? fz->ev_mid : p->ev_xs2;
 					}
-					if ((rc = tspws_spectral_rows_f64(p, dc, (const double *)d_x, ld, (unsigned)ntr, fz->tps, *fz, sx))) return rc;
+					if ((rc = tspws_spectral_rows_f64(p, dc, (const double *)d_x, ld, (unsigned)ntr, fz->tps, *fz, sx, behind_tr))) return rc;
 					fz->spec_first = sf;
-					if (fz->ev_mid && sx == st) { HIP_TRY(hipEventRecord(fz->ev_mid, st)); fz->mid_recorded = true; }
+					if (behind_tr) { // side by side: the FIR kernels (and the caller's readers of the rows: ev_mid) wait for the transposition only
+						HIP_TRY(hipStreamWaitEvent(st, behind_tr, 0));
+						fz->mid_recorded = behind_tr == fz->ev_mid;
+					} else if (fz->ev_mid) { HIP_TRY(hipEventRecord(fz->ev_mid, st)); fz->mid_recorded = true; } // serial: behind the whole chain
 					if (sf == 0) { fz->applied = true; return 0; } // (every scale went that way)
 					rg.s0 = 0; rg.s1 = sf;
 					spec_join = sx != st;

@@ -657,7 +657,7 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 			f.keep_slice = with_stack ? (int)C : -1; f.keepST = (double2 *)OUT + (size_t)W * nc;
 			fz.allow_spec = true; // (the far-decimated octaves of these ng W rows may go through the spectral engine: forward.hip decides)
 		}
-		if (fuse && C && sg + 1 == mp.nstage) { // (the linear stacks of the replicas may start behind the spectral chain, beside the FIR kernels)
+		if (fuse && C && sg + 1 == mp.nstage) { // (the linear stacks of the replicas may start behind the spectral chain's transposition, beside the transforms)
 			if (!pl->ev_mid) HIP_TRY(hipEventCreateWithFlags(&pl->ev_mid, hipEventDisableTiming | hipEventDisableSystemFence));
 			fz.ev_mid = pl->ev_mid;
 		}
@@ -672,7 +672,7 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	// 0.03 + 0.06 (cfg4), so the linear stacks then wait for the transforms
 	const bool lin_first = last_spec_first >= pl->S;
 	if (C && lin_first) hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, W, mp.gps);
-	else if (C && lin_mid) { // behind the chain, beside k_fwd_lds (FP64-bound; the linear stacks are 0.02 ms of HBM reads)
+	else if (C && lin_mid) { // behind the chain's transposition (or, one after the other, behind the chain), beside the transforms: 0.02 ms of HBM reads
 		HIP_TRY(hipStreamWaitEvent(st, pl->ev_mid, 0));
 		hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, W, mp.gps);
 	}

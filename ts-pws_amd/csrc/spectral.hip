@@ -1168,7 +1168,8 @@ __global__ void __launch_bounds__(1024) k_spec_rowmax(const unsigned *__restrict
 }
 
 template <typename TIn>
-static int spectral_rows(tspws_hip_plan *p, SpecDecomp *dc, const TIn *d_x, size_t ld, unsigned ntr, unsigned tps, const SpecRowsOut &ro, hipStream_t st)
+static int spectral_rows(tspws_hip_plan *p, SpecDecomp *dc, const TIn *d_x, size_t ld, unsigned ntr, unsigned tps, const SpecRowsOut &ro, hipStream_t st,
+                         hipEvent_t after_transposition)
 {
 	const unsigned nblk = (ntr + 63) / 64, TP = nblk * 64, ncol = (ntr + tps - 1) / tps;
 	void *v;
@@ -1180,17 +1181,19 @@ static int spectral_rows(tspws_hip_plan *p, SpecDecomp *dc, const TIn *d_x, size
 	unsigned *amax = (unsigned *)v, *pmax = amax + TP;
 	hipLaunchKernelGGL((k_spec_transpose_rows<TIn>), dim3(np, nblk), dim3(256), 0, st, d_x, ld, ntr, p->N, TP, xT, pmax);
 	hipLaunchKernelGGL(k_spec_rowmax, dim3(nblk), dim3(1024), 0, st, (const unsigned *)pmax, np, TP, amax);
+	if (after_transposition) HIP_TRY(hipEventRecord(after_transposition, st)); // (the rows themselves are not read again by this chain)
 	return spectral_run<TIn>(p, dc, (const TIn *)xT, TP, ntr, nullptr, nullptr, 0, nullptr, st, &ro, tps, ncol);
 }
 
-int tspws_spectral_rows_f64(tspws_hip_plan *p, SpecDecomp *dc, const double *d_x, size_t ld, unsigned ntr, unsigned tps, const FuseOut &fz, hipStream_t st)
+int tspws_spectral_rows_f64(tspws_hip_plan *p, SpecDecomp *dc, const double *d_x, size_t ld, unsigned ntr, unsigned tps, const FuseOut &fz, hipStream_t st,
+                            hipEvent_t after_transposition)
 {
 	SpecRowsOut ro;
 	memset(&ro, 0, sizeof ro);
 	const FuseFinal &f = fz.fin;
 	if (f.OUT) { ro.OUT = f.OUT; ro.out_stride = f.out_stride; ro.Mv = f.Mv; ro.M = f.M; ro.K = f.K; ro.wu = f.wu; ro.mode = f.mode; ro.keep = f.keep_slice; ro.keepST = f.keepST; }
 	else { ro.accST = fz.accST; ro.accPS = fz.accPS; ro.stride = fz.stride; ro.keep = -1; }
-	return spectral_rows<double>(p, dc, d_x, ld, ntr, tps, ro, st);
+	return spectral_rows<double>(p, dc, d_x, ld, ntr, tps, ro, st, after_transposition);
 }
 
 int tspws_spectral_run_f32(tspws_hip_plan *p, SpecDecomp *dc, const float *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st)

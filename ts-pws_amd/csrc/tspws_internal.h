@@ -134,8 +134,8 @@ struct FuseOut {
 	// sets / plane pairs of every slice written), whatever their fuse_ok / nsplit say
 	bool allow_spec = false;
 	unsigned spec_first = ~0u;
-	// recorded on the forward stream behind the spectral chain (if one ran there) and in front of the FIR kernels of the finer octaves: work
-	// that only must not run beside the chain's transposition can start here (resample.hip: the replicas' linear stacks)
+	// recorded behind the transposition of the spectral chain (side by side with the FIR kernels: the default) or behind the whole chain (one after
+	// the other): work that only must not run beside that transposition can start here (resample.hip: the replicas' linear stacks)
 	hipEvent_t ev_mid = nullptr;
 	bool mid_recorded = false;
 };
@@ -216,7 +216,7 @@ struct tspws_hip_plan {
 	hipStream_t side = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	hipStream_t xs = nullptr;          // ... and the spectral chain of a few-row launch beside both (forward.hip)
-	hipEvent_t ev_xs0 = nullptr, ev_xs1 = nullptr;
+	hipEvent_t ev_xs0 = nullptr, ev_xs1 = nullptr, ev_xs2 = nullptr;
 	hipEvent_t ev_mid = nullptr;         // behind the spectral chain of the masked call's last stage (FuseOut::ev_mid)
 	// optional timing inside tspws_hip_stack (bench.py): three events per call -- start, end of the streaming stage, end
 	// Events that ride on kernel launches instead of being recorded as packets of their own (hipExtLaunchKernelGGL: the launch's
@@ -349,7 +349,8 @@ bool tspws_generic_forward();
 // spectral.hip: the far-decimated octaves of a many-trace batch through the traces' spectra
 unsigned tspws_spectral_first_scale(const tspws_hip_plan *p, unsigned nsmax); // first scale of the spectral set for octaves of <= nsmax outputs (S: none)
 int  tspws_spectral_decomp(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, SpecDecomp **out, bool few = false);
-int  tspws_spectral_rows_f64(tspws_hip_plan *p, SpecDecomp *dc, const double *d_x, size_t ld, unsigned ntr, unsigned tps, const FuseOut &fz, hipStream_t st); // few rows in columns
+int  tspws_spectral_rows_f64(tspws_hip_plan *p, SpecDecomp *dc, const double *d_x, size_t ld, unsigned ntr, unsigned tps, const FuseOut &fz, hipStream_t st,
+                             hipEvent_t after_transposition = nullptr); // few rows in columns
 int  tspws_build_tl_spectral(tspws_hip_plan *p, unsigned s_first, TlTable &T); // (forward.hip) scale table + trace-lane items of that decomposition
 int  tspws_spectral_run_f32(tspws_hip_plan *p, SpecDecomp *dc, const float *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st);
 int  tspws_spectral_run_f64(tspws_hip_plan *p, SpecDecomp *dc, const double *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st);
