@@ -355,7 +355,14 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 					hipEvent_t behind_tr = nullptr;
 					if (!serial && sf > 0) {
 						const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
-						if (!p->xs) HIP_TRY(hipStreamCreateWithFlags(&p->xs, hipStreamNonBlocking));
+						if (!p->xs) {
+							int plo = 0, phi = 0;
+							HIP_TRY(hipDeviceGetStreamPriorityRange(&plo, &phi)); // (plo = least urgent)
+							// the chain's stream is the most urgent one: its short workgroups take the slots the long FIR workgroups free (cfg4 2.05-2.08 ->
+							// 2.02-2.04 ms; least urgent 2.10-2.14; tools/experiments/r5_xs_prio.sh).  TSPWS_XS_PRIO (sweeps): 0 plain, -1 least urgent
+							const char *e = sweep_env("TSPWS_XS_PRIO");
+							HIP_TRY(hipStreamCreateWithPriority(&p->xs, hipStreamNonBlocking, e ? (atoi(e) > 0 ? phi : atoi(e) < 0 ? plo : 0) : phi));
+						}
 						if (!p->ev_xs0) HIP_TRY(hipEventCreateWithFlags(&p->ev_xs0, evf));
 						if (!p->ev_xs1) HIP_TRY(hipEventCreateWithFlags(&p->ev_xs1, evf));
 						if (!p->ev_xs2) HIP_TRY(hipEventCreateWithFlags(&p->ev_xs2, evf));
