@@ -348,8 +348,8 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 					// all of a CU's LDS (two 80-KB workgroups), and a transposition that has to wait for its 33 KB starves (mid-round, with the
 					// 0.16-ms transposition and the FIR kernels launched first, the pair took 1.70 ms side by side against 1.05 one after the
 					// other); the chain's other kernels need no LDS to speak of and fill the register space the FIR kernels leave.  cfg4 with
-					// the end-of-round kernels: 2.11 ms serial, 2.05 side by side with the FIR kernels first, 2.0x in this order
-					// (tools/experiments/r5_rows_parallel.sh; TSPWS_SPEC_PARALLEL=0, sweeps build: serial).
+					// the end-of-round kernels on one box: 2.08-2.11 ms one after the other, 2.05 side by side with the FIR kernels first,
+					// 2.03-2.04 in this order (tools/experiments/r5_rows_parallel.sh; TSPWS_SPEC_PARALLEL=0, sweeps build: one after the other).
 					static const bool serial = sweep_env("TSPWS_SPEC_PARALLEL") && !strcmp(sweep_env("TSPWS_SPEC_PARALLEL"), "0");
 					hipStream_t sx = st;
 					hipEvent_t behind_tr = nullptr;
