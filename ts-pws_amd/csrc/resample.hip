@@ -661,7 +661,10 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 			if (!pl->ev_mid) HIP_TRY(hipEventCreateWithFlags(&pl->ev_mid, hipEventDisableTiming | hipEventDisableSystemFence));
 			fz.ev_mid = pl->ev_mid;
 		}
-		if ((rc = tspws_forward_parts_f64(pl, d_rows + (size_t)r0 * N, r1 - r0, N, part + (size_t)r0 * pl->npart, pl->xf, fuse ? &fz : nullptr, ScaleRange()))) return rc;
+		pl->le.ready = pl->stage_ev[sg]; // the producer's own event: the forward launch's other streams wait for it directly, not for a re-record on xf
+		rc = tspws_forward_parts_f64(pl, d_rows + (size_t)r0 * N, r1 - r0, N, part + (size_t)r0 * pl->npart, pl->xf, fuse ? &fz : nullptr, ScaleRange());
+		pl->le.ready = nullptr;
+		if (rc) return rc;
 		if (fuse) stage_spec_first = fz.spec_first;
 		last_spec_first = stage_spec_first;
 		lin_mid = fuse && fz.mid_recorded;
