@@ -324,6 +324,7 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 {
 	if (fz) { fz->applied = false; fz->spec_first = p->S; }
 	bool spec_join = false;
+	hipStream_t fir = st; // stream of the FIR kernels (the caller's, unless a spectral chain of few rows keeps that one: below)
 	// Few rows in columns (the K partial stacks of every jackknife replica, resample.hip) whose weighted sets the forward launch completes
 	// itself: from FEW_SPEC_MIN rows on, the octaves with D >= 8 go through the spectral engine (lanes = rows; per-column stacks by
 	// k_spec_stack_rows) and the FIR kernels below keep the finer ones.  cfg4 (110 rows of 131072 samples, Mexican hat): forward stage
@@ -351,43 +352,40 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 					// the end-of-round kernels on one box: 2.08-2.11 ms one after the other, 2.05 side by side with the FIR kernels first,
 					// 2.03-2.04 in this order (tools/experiments/r5_rows_parallel.sh; TSPWS_SPEC_PARALLEL=0, sweeps build: one after the other).
 					static const bool serial = sweep_env("TSPWS_SPEC_PARALLEL") && !strcmp(sweep_env("TSPWS_SPEC_PARALLEL"), "0");
-					hipStream_t sx = st;
 					hipEvent_t behind_tr = nullptr;
 					if (!serial && sf > 0) {
+						// The CHAIN stays on the caller's stream (it is the longer branch, and every hand-over to another stream costs ~20 us before
+						// the first kernel there starts); the FIR kernels go to a second stream of the LEAST priority: the chain's short workgroups
+						// take the slots the long FIR workgroups free (chain more urgent than FIR: cfg4 -0.03 ms; the other way round +0.06;
+						// tools/experiments/r5_xs_prio.sh).  TSPWS_XS_PRIO (sweeps): 0 plain, 1 most urgent
 						const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
 						if (!p->xs) {
 							int plo = 0, phi = 0;
 							HIP_TRY(hipDeviceGetStreamPriorityRange(&plo, &phi)); // (plo = least urgent)
-							// the chain's stream is the most urgent one: its short workgroups take the slots the long FIR workgroups free (cfg4 2.05-2.08 ->
-							// 2.02-2.04 ms; least urgent 2.10-2.14; tools/experiments/r5_xs_prio.sh).  TSPWS_XS_PRIO (sweeps): 0 plain, -1 least urgent
 							const char *e = sweep_env("TSPWS_XS_PRIO");
-							HIP_TRY(hipStreamCreateWithPriority(&p->xs, hipStreamNonBlocking, e ? (atoi(e) > 0 ? phi : atoi(e) < 0 ? plo : 0) : phi));
+							HIP_TRY(hipStreamCreateWithPriority(&p->xs, hipStreamNonBlocking, e ? (atoi(e) > 0 ? phi : atoi(e) < 0 ? plo : 0) : plo));
 						}
-						if (!p->ev_xs0) HIP_TRY(hipEventCreateWithFlags(&p->ev_xs0, evf));
 						if (!p->ev_xs1) HIP_TRY(hipEventCreateWithFlags(&p->ev_xs1, evf));
 						if (!p->ev_xs2) HIP_TRY(hipEventCreateWithFlags(&p->ev_xs2, evf));
-						hipEvent_t ready = p->le.ready;
-						if (!ready) { ready = p->ev_xs0; HIP_TRY(hipEventRecord(ready, st)); }
-						HIP_TRY(hipStreamWaitEvent(p->xs, ready, 0));
-						sx = p->xs;
 						behind_tr = fz->ev_mid ? fz->ev_mid : p->ev_xs2;
 					}
-					if ((rc = tspws_spectral_rows_f64(p, dc, (const double *)d_x, ld, (unsigned)ntr, fz->tps, *fz, sx, behind_tr))) return rc;
+					if ((rc = tspws_spectral_rows_f64(p, dc, (const double *)d_x, ld, (unsigned)ntr, fz->tps, *fz, st, behind_tr))) return rc;
 					fz->spec_first = sf;
 					if (behind_tr) { // side by side: the FIR kernels (and the caller's readers of the rows: ev_mid) wait for the transposition only
-						HIP_TRY(hipStreamWaitEvent(st, behind_tr, 0));
+						HIP_TRY(hipStreamWaitEvent(p->xs, behind_tr, 0));
 						fz->mid_recorded = behind_tr == fz->ev_mid;
-					} else if (fz->ev_mid) { HIP_TRY(hipEventRecord(fz->ev_mid, st)); fz->mid_recorded = true; } // serial: behind the whole chain
+						fir = p->xs;
+					} else if (fz->ev_mid) { HIP_TRY(hipEventRecord(fz->ev_mid, st)); fz->mid_recorded = true; } // one after the other: behind the whole chain
 					if (sf == 0) { fz->applied = true; return 0; } // (every scale went that way)
 					rg.s0 = 0; rg.s1 = sf;
-					spec_join = sx != st;
+					spec_join = fir != st;
 				}
 			}
 		}
 	}
 	const LaunchRange lr = launch_range(p, rg);
 	const bool has_lds = lr.lds1 > lr.lds0, has_poly = lr.wav1 > lr.wav0;
-	hipStream_t sp = st; // stream of the direct kernel
+	hipStream_t sp = fir; // stream of the direct kernel
 #if FL_TIMING || FL_ABLATE
 	static const bool serial = sweep_env("TSPWS_FWD_SERIAL") != nullptr; // debug builds: the two kernels one after the other
 #else
@@ -400,7 +398,7 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 		if (!p->ev_join) HIP_TRY(hipEventCreateWithFlags(&p->ev_join, evf));
 		// fork: the side stream waits for the producer of d_x -- its launch carried the event (plan->le.ready) or a record here
 		hipEvent_t ready = p->le.ready;
-		if (!ready) { ready = p->ev_fork; HIP_TRY(hipEventRecord(ready, st)); }
+		if (!ready || fir != st) { ready = p->ev_fork; HIP_TRY(hipEventRecord(ready, fir)); }
 		HIP_TRY(hipStreamWaitEvent(p->side, ready, 0));
 		sp = p->side;
 	}
@@ -434,7 +432,7 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 			const size_t astr = fuse ? fz->stride : 0;
 			FuseFinal ff;
 			if (fuse && fz->fin.OUT && t0 == 0 && ntr <= per_launch) ff = fz->fin; // (slice indices of the final step are the launch's own: one launch)
-#define FL_LAUNCH(F, QT) hipLaunchKernelGGL((k_fwd_lds<TIn, F, QT>), grid, dim3(FL_NT), FL_LDS_BYTES_(QT), st, d_x + t0 * ld, ld, nt, tps, p->N, p->d_sc, p->S, \
+#define FL_LAUNCH(F, QT) hipLaunchKernelGGL((k_fwd_lds<TIn, F, QT>), grid, dim3(FL_NT), FL_LDS_BYTES_(QT), fir, d_x + t0 * ld, ld, nt, tps, p->N, p->d_sc, p->S, \
 			                            p->d_w, d_part + t0 * p->npart, p->npart, aS, aP, astr, lr.lds0, ff)
 			if (p->lds_qt == 32) { if (fuse) FL_LAUNCH(true, 32); else FL_LAUNCH(false, 32); }
 			else { if (fuse) FL_LAUNCH(true, 24); else FL_LAUNCH(false, 24); }
@@ -442,9 +440,9 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 		}
 		if (fuse) fz->applied = true;
 	}
-	if (sp != st) {
+	if (sp != fir) {
 		HIP_TRY(hipEventRecord(p->ev_join, sp));
-		HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
+		HIP_TRY(hipStreamWaitEvent(fir, p->ev_join, 0));
 	}
 	if (spec_join) {
 		HIP_TRY(hipEventRecord(p->ev_xs1, p->xs));

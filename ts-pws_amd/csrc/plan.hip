@@ -230,6 +230,7 @@ extern "C" void tspws_hip_plan_destroy(tspws_hip_plan *p)
 	if (p->ev_xs1) (void)hipEventDestroy(p->ev_xs1);
 	if (p->ev_xs2) (void)hipEventDestroy(p->ev_xs2);
 	if (p->ev_mid) (void)hipEventDestroy(p->ev_mid);
+	if (p->ev_lin) (void)hipEventDestroy(p->ev_lin);
 	if (p->xf) (void)hipStreamDestroy(p->xf);
 	for (hipEvent_t e : p->stage_ev) (void)hipEventDestroy(e);
 	if (p->d_oc) (void)hipFree(p->d_oc);

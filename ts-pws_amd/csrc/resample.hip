@@ -638,13 +638,16 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	const bool fin_in_kernel = fin_env < 0 ? mp.nstage == 1 : fin_env != 0;
 	unsigned last_spec_first = pl->S; // scales [.., S) of the last stage were completed by the spectral engine (forward.hip)
 	bool lin_mid = false;             // ... and its chain recorded ev_mid behind itself
+	// stream of the transforms: the second stream, so that a stage's transforms run beside the next stage's walk -- with ONE stage (the default) the
+	// caller's own: nothing runs beside the walk then, and every hand-over to another stream costs ~20 us before the first kernel there starts
+	const hipStream_t fs = mp.nstage == 1 ? st : pl->xf;
 	for (unsigned sg = 0; sg < mp.nstage; sg++) {
 		// HBM-bound half of the stage on the caller's stream: its rows from its traces
 		if ((rc = masked_stream_stage(pl, mp, dv, d_x, ld, d_rows, sg, st))) return rc;
 		const unsigned g0 = sg * mp.gps, ng = std::min(mp.gps, KM - g0), r0 = g0 * W, r1 = r0 + ng * W;
 		HIP_TRY(hipEventRecord(pl->stage_ev[sg], st));
-		// FP64-bound half on the second stream: the stage's rows, one slice of ng rows per column
-		HIP_TRY(hipStreamWaitEvent(pl->xf, pl->stage_ev[sg], 0));
+		// FP64-bound half on the transforms' stream: the stage's rows, one slice of ng rows per column
+		if (fs != st) HIP_TRY(hipStreamWaitEvent(fs, pl->stage_ev[sg], 0));
 		FuseOut fz;
 		if (fuse) { fz.accST = planes + (size_t)sg * W * 2 * nc; fz.accPS = fz.accST + nc; fz.stride = 2 * nc; fz.tps = ng; }
 		unsigned stage_spec_first = pl->S;
@@ -662,24 +665,28 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 			fz.ev_mid = pl->ev_mid;
 		}
 		pl->le.ready = pl->stage_ev[sg]; // the producer's own event: the forward launch's other streams wait for it directly, not for a re-record on xf
-		rc = tspws_forward_parts_f64(pl, d_rows + (size_t)r0 * N, r1 - r0, N, part + (size_t)r0 * pl->npart, pl->xf, fuse ? &fz : nullptr, ScaleRange());
+		rc = tspws_forward_parts_f64(pl, d_rows + (size_t)r0 * N, r1 - r0, N, part + (size_t)r0 * pl->npart, fs, fuse ? &fz : nullptr, ScaleRange());
 		pl->le.ready = nullptr;
 		if (rc) return rc;
 		if (fuse) stage_spec_first = fz.spec_first;
 		last_spec_first = stage_spec_first;
 		lin_mid = fuse && fz.mid_recorded;
 	}
-	HIP_TRY(hipEventRecord(pl->stage_ev[mp.nstage], pl->xf));
+	if (fs != st) HIP_TRY(hipEventRecord(pl->stage_ev[mp.nstage], fs));
 	// time-domain linear stacks of the replicas (:799-811) while the last transforms run -- unless those start with the spectral chain's
 	// transposition of the same rows: two kernels that walk the rows at a 1-MB stride at the same time take 0.57 + 0.93 ms instead of
-	// 0.03 + 0.06 (cfg4), so the linear stacks then wait for the transforms
+	// 0.03 + 0.06 (cfg4), so the linear stacks then wait for that transposition (ev_mid)
 	const bool lin_first = last_spec_first >= pl->S;
-	if (C && lin_first) hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, W, mp.gps);
-	else if (C && lin_mid) { // behind the chain's transposition (or, one after the other, behind the chain), beside the transforms: 0.02 ms of HBM reads
-		HIP_TRY(hipStreamWaitEvent(st, pl->ev_mid, 0));
-		hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, W, mp.gps);
+	bool lin_side = false; // the linear stacks went to the second stream: joined below
+	if (C && lin_first && fs != st) hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, W, mp.gps);
+	else if (C && (lin_mid || lin_first)) { // beside the transforms on the second stream: behind the chain's transposition, or (no chain) behind the walk
+		HIP_TRY(hipStreamWaitEvent(pl->xf, lin_mid ? pl->ev_mid : pl->stage_ev[mp.nstage - 1], 0));
+		hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, pl->xf, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, W, mp.gps);
+		if (!pl->ev_lin) HIP_TRY(hipEventCreateWithFlags(&pl->ev_lin, hipEventDisableTiming | hipEventDisableSystemFence));
+		HIP_TRY(hipEventRecord(pl->ev_lin, pl->xf));
+		lin_side = true;
 	}
-	HIP_TRY(hipStreamWaitEvent(st, pl->stage_ev[mp.nstage], 0));
+	if (fs != st) HIP_TRY(hipStreamWaitEvent(st, pl->stage_ev[mp.nstage], 0));
 	if (C && !lin_first && !lin_mid) hipLaunchKernelGGL(k_jk_linear, dim3(nbx, C), dim3(256), 0, st, (const double *)d_rows, KM, N, (const double *)d_Mv, d_ls_out, W, mp.gps);
 	// stacks of every column: its plane pairs in stage order + its split partials in group order; weights by the same launch
 	// (K = KM, M = the column's traces)
@@ -708,6 +715,7 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	if (C) tspws_epilogue_rows(d_ts_out, xr, N, C, st);
 	if (with_stack && (rc = tspws_hip_epilogue(d_ls, d_ts, xr + (size_t)(C + 1) * N, xr + (size_t)C * N, N, (unsigned)mtr, s))) return rc;
 	for (unsigned c = 0; c < C; c++) h_mtr_out[c] = (unsigned)mp.Kc[c];
+	if (lin_side) HIP_TRY(hipStreamWaitEvent(st, pl->ev_lin, 0)); // (long done)
 	HIP_TRY(hipGetLastError());
 	return cs_done(st); // (the memo's tables may still be on their way; the caller reads h_mtr_out and, usually, the outputs next)
 }

@@ -218,6 +218,7 @@ struct tspws_hip_plan {
 	hipStream_t xs = nullptr;          // ... and the spectral chain of a few-row launch beside both (forward.hip)
 	hipEvent_t ev_xs0 = nullptr, ev_xs1 = nullptr, ev_xs2 = nullptr;
 	hipEvent_t ev_mid = nullptr;         // behind the spectral chain of the masked call's last stage (FuseOut::ev_mid)
+	hipEvent_t ev_lin = nullptr;         // behind the replicas' linear stacks when they run on the second stream
 	// optional timing inside tspws_hip_stack (bench.py): three events per call -- start, end of the streaming stage, end
 	// Events that ride on kernel launches instead of being recorded as packets of their own (hipExtLaunchKernelGGL: the launch's
 	// start / completion signal IS the event; tools/probes/xstream_probe.hip: the next kernel of the stream follows 2.5 us after
