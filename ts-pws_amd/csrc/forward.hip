@@ -355,15 +355,17 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 					hipEvent_t behind_tr = nullptr;
 					if (!serial && sf > 0) {
 						// The CHAIN stays on the caller's stream (it is the longer branch, and every hand-over to another stream costs ~20 us before
-						// the first kernel there starts); the FIR kernels go to a second stream of the LEAST priority: the chain's short workgroups
-						// take the slots the long FIR workgroups free (chain more urgent than FIR: cfg4 -0.03 ms; the other way round +0.06;
-						// tools/experiments/r5_xs_prio.sh).  TSPWS_XS_PRIO (sweeps): 0 plain, 1 most urgent
+						// the first kernel there starts); the FIR kernels go to a second stream of PLAIN priority.  (A least urgent FIR stream gains
+						// another 0.03 ms at cfg4 when the plan is alone in the process -- the chain's short workgroups take the slots the long FIR
+						// workgroups free -- but with the streams of a SECOND plan alive in the process any non-default priority costs 0.4-0.5 ms:
+						// 2.00 / 2.46 ms least urgent, 2.10 / 2.56 most urgent, 2.03 / 2.03 plain, 2.10 / 2.10 one after the other;
+						// tools/experiments/r5_cfg4_robust.sh, 150 calls each.)  TSPWS_XS_PRIO (sweeps): -1 least, 1 most urgent
 						const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
 						if (!p->xs) {
 							int plo = 0, phi = 0;
 							HIP_TRY(hipDeviceGetStreamPriorityRange(&plo, &phi)); // (plo = least urgent)
 							const char *e = sweep_env("TSPWS_XS_PRIO");
-							HIP_TRY(hipStreamCreateWithPriority(&p->xs, hipStreamNonBlocking, e ? (atoi(e) > 0 ? phi : atoi(e) < 0 ? plo : 0) : plo));
+							HIP_TRY(hipStreamCreateWithPriority(&p->xs, hipStreamNonBlocking, e ? (atoi(e) > 0 ? phi : atoi(e) < 0 ? plo : 0) : 0));
 						}
 						if (!p->ev_xs1) HIP_TRY(hipEventCreateWithFlags(&p->ev_xs1, evf));
 						if (!p->ev_xs2) HIP_TRY(hipEventCreateWithFlags(&p->ev_xs2, evf));
