@@ -102,10 +102,15 @@ int  tspws_hip_partial_stacks_range(tspws_hip_plan *plan, const float *d_sigall,
 int  tspws_hip_forward_f64(tspws_hip_plan *plan, const double *d_x, size_t ntr, size_t ld, double *d_Y, void *stream);
 int  tspws_hip_forward_f32(tspws_hip_plan *plan, const float  *d_x, size_t ntr, size_t ld, double *d_Y, void *stream);
 /* The same coefficients through the SPECTRAL engine (csrc/spectral.hip): only the scales of the frame's spectral set for octaves of at
- * most nsmax outputs -- [tspws_hip_spectral_first_scale(plan, nsmax), S) -- are written, the rest of d_Y[ntr][ncoef] is left alone.
- * Exact for those scales because the reference's FIR is circular (cdotx.c:35-72) and their D divides N.  Returns TSPWS_E_ARG when
- * the frame has no such set (N not a power of two >= 1024, odd decimations, ...). */
+ * most nsmax outputs -- [tspws_hip_spectral_first_scale(plan, nsmax), tspws_hip_spectral_end_scale(plan)) -- are written, the rest of
+ * d_Y[ntr][ncoef] is left alone.  Exact for those scales because the reference's FIR is a circular correlation (cdotx.c:35-72): for N a
+ * power of two it is the transform's own (D divides N); for any other N >= 1024 it is evaluated as a linear correlation over a window of
+ * the trace's periodic extension, tspws_hip_spectral_transform_length(plan) >= N + L - 1 samples long -- scales whose filters do not fit
+ * that window lie at and behind tspws_hip_spectral_end_scale (S for most frames).  Returns TSPWS_E_ARG when the frame has no such set
+ * (N < 1024, decimations that are not powers of two >= 8, ...). */
 unsigned tspws_hip_spectral_first_scale(const tspws_hip_plan *plan, unsigned nsmax);
+unsigned tspws_hip_spectral_end_scale(const tspws_hip_plan *plan);
+unsigned tspws_hip_spectral_transform_length(const tspws_hip_plan *plan);
 /* First scale of the spectral set a single-stage batch of ntr traces gets by the library's own rule (S: FIR kernels only): batches of
  * >= 64 traces and >= 1 M samples (or >= 256 traces) send the octaves with D >= 32 (two-voice frames: D >= 16) through the spectrum;
  * TSPWS_ENGINE=fir / spectral pins the choice. */

@@ -52,6 +52,20 @@ check(dict(wu=1.5), 64, 1024, 5)                         # the smallest frame wi
 check(dict(V=7, J=6), 90, 4096, 6)
 check(dict(b0=4.0), 66, 16384, 7)                        # D = 8 .. : every octave spectral when the bound allows
 check(dict(lrm=1, wu=1.0), 257, 2048, 8)                 # five trace blocks, the last one with a single trace
-check(dict(), 40, 3000, 9, holes=False)                  # N not a power of two: no spectral set, the FIR kernels whatever the switch says
+check(dict(), 40, 3000, 9, holes=False)                  # N not a power of two: a window of the periodic extension (partially filled trace block)
+check(dict(), 100, 3000, 11)
+check(dict(type=-3), 70, 5000, 12)                       # Mexican hat, N even but no power of two
+check(dict(w0=2 * np.pi, wu=1.0), 130, 1501, 13)         # odd N: no decimation divides it (seam outputs k = ceil(N / D) - 1)
+check(dict(), 66, 16501, 14)                             # the shipped example's length: five clipped scales stay on the direct kernel
+check(dict(Kmax=70, unbiased=1), 300, 4097, 15)          # two-stage with 70 groups just above a power of two: the window is nearly twice the trace
+# the shipped example's first 32 traces (N = 16501) against the reference's own outputs
+ge = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example32.npz"), allow_pickle=False)
+from test_oracle_vs_golden import _case_params
+for name in ("ex1", "ex2", "ex3", "ex_mexhat"):
+    r = abi.run_main(lib.tspws_main, _case_params(ge, name), ge["traces"], dt=float(ge["dt"]), beg=float(ge["beg"]))
+    e = max(abi.relerr(r["ls"], ge[f"{name}/ls"]), abi.relerr(r["tsPWS"], ge[f"{name}/tsPWS"]))
+    assert r["rc"] == 0 and e < 2e-6, (name, e)
+    worst = max(worst, e)
+    h.update(r["ls"].tobytes()); h.update(r["tsPWS"].tobytes())
 check(dict(Kmax=200, unbiased=1), 600, 2048, 10)         # two-stage with 200 groups: the partial stacks are a many-trace batch (double input)
 print("SPECTRAL_ENGINE", worst, h.hexdigest()[:16])

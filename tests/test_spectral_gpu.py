@@ -1,7 +1,9 @@
 """GPU parity tests of the spectral forward engine (ts-pws_amd/csrc/spectral.hip): the far-decimated octaves of a many-trace batch
 through the traces' spectra instead of per-scale FIR sums.  Exact because the reference's decimating FIR is a circular correlation
-(FWTa/cdotx.c:35-72, driver FWTa/wavelet_v7.c:43-64) and those octaves' D divides N.  Tolerances as in test_hip_parity.py: 1e-11 on
-the FP64 coefficients, 2e-6 on the float32 outputs."""
+(FWTa/cdotx.c:35-72, driver FWTa/wavelet_v7.c:43-64): for N a power of two it is the transform's own (those octaves' D divides N), for
+any other N it is a linear correlation of the trace's periodic extension, evaluated over a power-of-two window of >= N + L - 1 samples
+(outputs k < ceil(N / D), FWTa/wavelet_v7.c:61).  Tolerances as in test_hip_parity.py: 1e-11 on the FP64 coefficients, 2e-6 on the
+float32 outputs."""
 import importlib
 import os
 import subprocess
@@ -48,7 +50,7 @@ def dev_forward_spectral(lib, torch, pl, X, nsmax):
 def test_spectral_coefficients_golden(lib, torch, golden):
     """The reference's own coefficients of one trace (tests/golden/cwt.npz): every scale of the frame's largest spectral set."""
     g = golden["cwt"]
-    seen = 0
+    seen = odd = 0
     for name in sorted({k.split("/")[0] for k in g.files}):
         x = g[f"{name}/x"]
         N = len(x)
@@ -57,38 +59,49 @@ def test_spectral_coefficients_golden(lib, torch, golden):
         p.s0, p.b0, p.w0 = float(g[f"{name}/s0"]), float(g[f"{name}/b0"]), float(g[f"{name}/w0"])
         pl = tspws.Plan(p, N)
         f = abi.OracleFrame.from_params(p, N)
-        sf = lib.tspws_hip_spectral_first_scale(pl.h, 1 << 30)
-        if N & (N - 1):                                  # N = 1501: no decimation divides it
+        sf, se = lib.tspws_hip_spectral_first_scale(pl.h, 1 << 30), lib.tspws_hip_spectral_end_scale(pl.h)
+        NT = lib.tspws_hip_spectral_transform_length(pl.h)
+        if any(int(d) & (int(d) - 1) for d in f.D):      # (odd decimations: no spectral set)
             assert sf == pl.S, name
             continue
-        assert sf < pl.S, name
+        assert sf < se <= pl.S, name                     # (N = 1501, odd, no decimation divides it: a window of the periodic extension)
+        assert NT & (NT - 1) == 0 and (NT == N or NT >= N + int(f.L[se - 1]) - 1), (name, NT)
         off = np.concatenate([[0], np.cumsum(f.Ns.astype(np.int64))])
         want = g[f"{name}/Y"]
         for X in (x[None, :].astype(np.float64), x[None, :].astype(np.float32)):
             Y = dev_forward_spectral(lib, torch, pl, np.ascontiguousarray(X), 1 << 30)[0]
-            for s in range(sf, pl.S):
+            for s in range(sf, se):
                 a, b = int(off[s]), int(off[s + 1])
-                assert f.D[s] >= 8 and N % int(f.D[s]) == 0
+                assert f.D[s] >= 8 and (N & (N - 1) or N % int(f.D[s]) == 0)
                 assert abi.relerr(Y[a:b], want[a:b]) < TOL64, (name, s)
         seen += 1
-    assert seen >= 2
+        odd += N & 1
+    assert seen >= 3 and odd >= 1
 
 
 @pytest.mark.parametrize("kw,N,ntr,nsmax", [
     (dict(), 1024, 3, 1 << 20), (dict(), 4096, 70, 256), (dict(), 131072, 2, 1 << 20), (dict(type=-3), 32768, 5, 4096),
     (dict(w0=2 * np.pi), 32768, 7, 1024), (dict(type=-2), 8192, 2, 1 << 20), (dict(b0=4.0), 65536, 2, 2048), (dict(J=3), 2048, 4, 1 << 20),
     (dict(V=7), 4096, 130, 1 << 20), (dict(s0=4.0, J=5), 8192, 65, 1 << 20), (dict(b0=0.25), 16384, 3, 1 << 20),
+    # N not a power of two (the shipped example's 16501 -- five clipped scales stay outside the window --, odd, even, just above / below a power of two)
+    (dict(), 16501, 3, 1 << 20), (dict(), 3000, 70, 1 << 20), (dict(type=-3), 20000, 5, 4096), (dict(w0=2 * np.pi), 1501, 66, 1 << 20),
+    (dict(), 4097, 3, 1 << 20), (dict(V=5, b0=2.0), 8191, 4, 512), (dict(type=-2), 86400, 2, 2048), (dict(J=6), 1025, 130, 1 << 20),
 ])
 def test_spectral_coefficients_vs_oracle(lib, torch, kw, N, ntr, nsmax):
-    """Per-trace coefficients of the spectral set [first, S) for float and double input; one trace carries a stretch of exact zeros."""
+    """Per-trace coefficients of the spectral set [first, end) for float and double input; one trace carries a stretch of exact zeros."""
     p = abi.resolve(abi.default_params(**kw), N)
     f = abi.OracleFrame.from_params(p, N)
     pl = tspws.Plan(p, N)
-    sf = lib.tspws_hip_spectral_first_scale(pl.h, nsmax)
-    assert sf < f.S
-    # the set is a run of whole octaves at the coarse end: D >= 8, a power of two, at most nsmax outputs
-    assert all(int(f.D[s]) >= 8 and int(f.Ns[s]) <= nsmax for s in range(sf, f.S))
-    assert sf == 0 or int(f.D[sf - 1]) < 8 or int(f.Ns[sf - 1]) > nsmax or f.S - sf >= 128 - int(p.V)
+    sf, se = lib.tspws_hip_spectral_first_scale(pl.h, nsmax), lib.tspws_hip_spectral_end_scale(pl.h)
+    NT = lib.tspws_hip_spectral_transform_length(pl.h)
+    assert sf < se <= f.S
+    # the set is a run of octaves at the coarse end of what fits the transform window: D >= 8, a power of two, at most nsmax outputs
+    assert all(int(f.D[s]) >= 8 and int(f.Ns[s]) <= nsmax for s in range(sf, se))
+    assert sf == 0 or int(f.D[sf - 1]) < 8 or int(f.Ns[sf - 1]) > nsmax or se - sf >= 128 - int(p.V)
+    if N & (N - 1):
+        assert NT & (NT - 1) == 0 and all(N + int(f.L[s]) - 1 <= NT for s in range(se)) and (se == f.S or N + int(f.L[se]) - 1 > NT)
+    else:
+        assert NT == N and se == f.S
     X = abi.synth_traces(ntr, N, seed=5)
     X[ntr // 2, N // 3: N // 3 + N // 4] = 0
     off = np.concatenate([[0], np.cumsum(f.Ns.astype(np.int64))])
@@ -96,17 +109,17 @@ def test_spectral_coefficients_vs_oracle(lib, torch, kw, N, ntr, nsmax):
     Y32 = dev_forward_spectral(lib, torch, pl, X, nsmax)
     for t in sorted({0, ntr // 2, ntr - 1}):
         Yo = f.forward(X[t].astype(np.float64))
-        for s in range(sf, f.S):
+        for s in range(sf, se):
             a, b = int(off[s]), int(off[s + 1])
             assert abi.relerr(Y64[t][a:b], Yo[a:b]) < TOL64, (t, s)
             assert abi.relerr(Y32[t][a:b], Yo[a:b]) < TOL64, (t, s)
-        assert not Y64[t][:int(off[sf])].any()           # the other scales are left alone
+        assert not Y64[t][:int(off[sf])].any() and not Y64[t][int(off[se]):].any()   # the other scales are left alone
 
 
 def test_frames_without_a_spectral_set(lib):
-    """Odd N, N not a power of two, N < 1024, decimations 3 * 2^j: TSPWS_E_ARG from the per-trace entry, first scale == S."""
+    """N < 1024, decimations 3 * 2^j or 5 * 2^j, a frame that ends before D = 8: TSPWS_E_ARG from the per-trace entry, first scale == S."""
     import torch
-    for kw, N in [(dict(), 16501), (dict(), 3000), (dict(), 512), (dict(b0=3.0), 49152)]:
+    for kw, N in [(dict(), 512), (dict(), 1000), (dict(b0=3.0), 49152), (dict(b0=5.0, J=7), 20480), (dict(J=2), 5000)]:
         p = abi.resolve(abi.default_params(**kw), N)
         pl = tspws.Plan(p, N)
         assert lib.tspws_hip_spectral_first_scale(pl.h, 1 << 30) == pl.S
@@ -136,7 +149,11 @@ def test_engine_choice_rule(lib):
     sm = lib.tspws_hip_spectral_choice(pm.h, 1024)                   # Mexican hat (two voices per octave): one octave more, D >= 16
     assert sm < pm.S and int(fm.D[sm]) == 16 and int(fm.D[sm - 1]) == 8
     po = tspws.Plan(abi.resolve(abi.default_params(), 16501), 16501)
-    assert lib.tspws_hip_spectral_choice(po.h, 4096) == po.S         # odd N
+    fo = abi.OracleFrame.from_params(abi.resolve(abi.default_params(), 16501), 16501)
+    so = lib.tspws_hip_spectral_choice(po.h, 499)                    # the shipped example's shape: odd N, the same octave bound
+    assert so < po.S and int(fo.D[so]) == 32 and int(fo.D[so - 1]) == 16
+    assert lib.tspws_hip_spectral_choice(po.h, 32) == po.S
+    assert lib.tspws_hip_spectral_end_scale(po.h) == po.S - 5 and lib.tspws_hip_spectral_transform_length(po.h) == 32768   # (the five clipped scales)
 
 
 def _child(env):

@@ -90,6 +90,8 @@ SYMBOLS = {
     "tspws_hip_forward_f64": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "tspws_hip_forward_f32": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "tspws_hip_spectral_first_scale": (_u, [_vp, _u]),
+    "tspws_hip_spectral_end_scale": (_u, [_vp]),
+    "tspws_hip_spectral_transform_length": (_u, [_vp]),
     "tspws_hip_spectral_choice": (_u, [_vp, _sz]),
     "tspws_hip_forward_spectral_f64": (_i, [_vp, _vp, _sz, _sz, _vp, _u, _vp]),
     "tspws_hip_forward_spectral_f32": (_i, [_vp, _vp, _sz, _sz, _vp, _u, _vp]),

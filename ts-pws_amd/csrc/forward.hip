@@ -93,7 +93,21 @@ static int forward_generic(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t
 #include "fwd_poly.h"
 #include "fwd_lds.h"
 #include "fwd_tl.h"
+#include "fwd_gemm.h"
 #include "spectral.h"
+
+// TSPWS_ENGINE pins the forward engine of many-trace batches (and of few rows in columns): fir / spectral; unset or "auto": the size rules
+// below.  Parsed ONCE per process, here, for every site that asks; any other value is refused by tspws_hip_plan_create (TSPWS_E_ARG) --
+// two ranks that spell it differently must not end up with different kernels or collective sequences.
+int tspws_engine_pin()
+{
+	static int eng = -2; // 0 auto, 1 fir, 2 spectral, -1 not a value
+	if (eng == -2) {
+		const char *e = getenv("TSPWS_ENGINE");
+		eng = (!e || !*e || !strcmp(e, "auto")) ? 0 : !strcmp(e, "fir") ? 1 : !strcmp(e, "spectral") ? 2 : -1;
+	}
+	return eng;
+}
 
 // TSPWS_TL_MIN=n forces the many-trace path for batches of >= n traces (tests; read at every call), unset: the rule below
 static long tl_min_env()
@@ -116,7 +130,8 @@ static long tl_min_env()
 #ifndef FWD_STEPS_TL
 #define FWD_STEPS_TL 96  /* ... beside k_fwd_tl on many traces: there are thousands of waves, longer ones amortise their set-up (cfg2 3.08 vs 3.14 ms at 32) */
 #endif
-static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, unsigned TLSTEPS, TlTable &T, unsigned spec_first = ~0u);
+static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, unsigned TLSTEPS, TlTable &T, unsigned spec_first = ~0u, unsigned spec_end = ~0u,
+                            unsigned nblk_hint = 0);
 
 // Work decomposition of the forward kernels.  Scales with >= 8 output groups and (D >= 64 or D a power of two) run on the
 // LDS-staged kernel; the rest (very coarse scales, odd small decimations) on the direct kernel, which aims at ~FWD_STEPS
@@ -181,9 +196,12 @@ int tspws_build_forward(tspws_hip_plan *p)
 // Decomposition for many-trace batches (fwd_tl.h): octaves (runs of scales with the same D and Ns) with at least MINNS
 // outputs become trace-lane work items (voice subsets of <= TL_VMAX voices), the rest stays on the direct kernel; T.sc is
 // the scale table of that decomposition (partial layout, fused flags, accumulate geometry).
-// spec_first: the scales [spec_first, S) are left to the spectral engine (spectral.hip) -- no work items here, and the scale table
-// marks them as stacked by their producer (one plane pair per 64-trace block, like the trace-lane kernel's fused scales).
-static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, unsigned TLSTEPS, TlTable &T, unsigned spec_first)
+// spec_first, spec_end: the scales [spec_first, spec_end) are left to the spectral engine (spectral.hip) -- no work items here, and the scale
+// table marks them as stacked by their producer (one plane pair per 64-trace block, like the trace-lane kernel's fused scales); scales from
+// spec_end on (filters too long for the transform window of a frame whose N is not a power of two) are the columns of the matrix-pipe
+// kernel (fwd_gemm.h): runs of samples per wave sized for ~2048 waves with nblk_hint trace blocks.
+static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINNS, unsigned TLSTEPS, TlTable &T, unsigned spec_first, unsigned spec_end,
+                            unsigned nblk_hint)
 {
 	T.minns = MINNS;
 	T.sc = p->sc;
@@ -242,11 +260,24 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINN
 	// scale table of the decomposition: partial layout, direct-kernel waves, accumulate geometry
 	unsigned woff = 0, ablk = 0;
 	unsigned long long poff = 0;
+	const bool has_gemm = spec_first < p->S && spec_end < p->S;
+	static const bool gemm_off = sweep_env("TSPWS_GEMM") && !strcmp(sweep_env("TSPWS_GEMM"), "0"); // sweeps: those scales on the direct kernel
+	if (has_gemm && !gemm_off) {
+		unsigned ncol = 0;
+		for (unsigned s = spec_end; s < p->S; s++) ncol += p->sc[s].Ns;
+		T.gcoltiles = (ncol + 15) / 16;
+		const unsigned want = (2048 + T.gcoltiles * std::max(1u, nblk_hint) - 1) / (T.gcoltiles * std::max(1u, nblk_hint));
+		T.gKS = std::max(1u, std::min(want, std::max(1u, p->N / 128u)));
+		if (const char *e = sweep_env("TSPWS_GEMM_KS")) T.gKS = (unsigned)std::max(1, atoi(e)); // sweeps
+		T.gKC = (((p->N + T.gKS - 1) / T.gKS) + 3) & ~3u;
+		T.gKS = (p->N + T.gKC - 1) / T.gKC; // (no empty runs)
+	}
 	for (unsigned s = 0; s < p->S; s++) {
 		ScaleDesc &d = T.sc[s];
 		d.use_lds = 0; d.lds_off = 0;
-		const bool is_spec = s >= spec_first;
+		const bool is_spec = s >= spec_first && s < spec_end, is_gemm = T.gcoltiles && s >= spec_end;
 		if (is_spec) { d.nsplit = 1; d.cps = 1; d.fuse_ok = 1; }
+		else if (is_gemm) { d.nsplit = 1; d.cps = 1; d.fuse_ok = 0; } // (k_gemm_reduce leaves one partial per trace and coefficient)
 		else if (is_tl[s]) {
 			d.nsplit = (d.D + TL_PMAX - 1) / TL_PMAX; d.cps = 1;
 			d.fuse_ok = d.nsplit == 1 ? 1u : 0u;
@@ -257,7 +288,7 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINN
 			d.fuse_ok = 0;
 		}
 		d.wave_off = woff;
-		if (!is_tl[s] && !is_spec) woff += d.ngw * d.nsplit;
+		if (!is_tl[s] && !is_spec && !is_gemm) woff += d.ngw * d.nsplit;
 		d.part_off = poff;
 		if (!((is_tl[s] || is_spec) && d.fuse_ok)) poff += (unsigned long long)d.nsplit * d.Ns; // fused scales never write partials
 		d.acc2_off = ablk;
@@ -270,6 +301,22 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINN
 	if (!T.n && spec_first >= p->S) return 0;
 	HIP_TRY(hipMalloc(&T.d_sc, p->S * sizeof(ScaleDesc)));
 	HIP_TRY(hipMemcpy(T.d_sc, T.sc.data(), p->S * sizeof(ScaleDesc), hipMemcpyHostToDevice));
+	if (T.gcoltiles) {
+		std::vector<GemmCol> gc((size_t)T.gcoltiles * 16);
+		memset(gc.data(), 0, gc.size() * sizeof(GemmCol));
+		size_t i = 0;
+		for (unsigned s = spec_end; s < p->S; s++) {
+			const ScaleDesc &d = T.sc[s];
+			for (unsigned k = 0; k < d.Ns; k++, i++) {
+				GemmCol &g = gc[i];
+				long long o = ((long long)d.c - (long long)k * (long long)d.D) % (long long)p->N;
+				if (o < 0) o += p->N;
+				g.L = d.L; g.o = (unsigned)o; g.Ns = d.Ns; g.tap_off = d.tap_off; g.dst = d.part_off + k;
+			}
+		}
+		HIP_TRY(hipMalloc(&T.d_gcols, gc.size() * sizeof(GemmCol)));
+		HIP_TRY(hipMemcpy(T.d_gcols, gc.data(), gc.size() * sizeof(GemmCol), hipMemcpyHostToDevice));
+	}
 	if (!T.n) return 0;
 	HIP_TRY(hipMalloc(&T.d_items, items.size() * sizeof(TLItem)));
 	HIP_TRY(hipMemcpy(T.d_items, items.data(), items.size() * sizeof(TLItem), hipMemcpyHostToDevice));
@@ -278,14 +325,14 @@ static int build_tl_forward(tspws_hip_plan *p, unsigned FWD_STEPS, unsigned MINN
 	return 0;
 }
 
-int tspws_build_tl_spectral(tspws_hip_plan *p, unsigned s_first, TlTable &T)
+int tspws_build_tl_spectral(tspws_hip_plan *p, unsigned s_first, unsigned s_end, unsigned nblk_hint, TlTable &T)
 {
 	// residue steps per workgroup of the finer octaves: SHORT workgroups (12; the FIR-only decomposition takes 96) -- the spectral chain runs
 	// beside this kernel on the side stream and gets the slots they free (cfg2 1.80 -> 1.68 ms, 1024 x 32768 default frame 1.56 -> 1.42; 8: same,
 	// 32: 1.77 / 1.48, 192: 2.11 / 1.71; outputs bit-identical)
 	unsigned steps = 12;
 	if (const char *e = sweep_env("TSPWS_SPEC_TLSTEPS")) steps = (unsigned)std::max(1, atoi(e)); // sweeps: residue steps per workgroup of the finer octaves
-	return build_tl_forward(p, FWD_STEPS_TL, TL_MINNS0, steps, T, s_first);
+	return build_tl_forward(p, FWD_STEPS_TL, TL_MINNS0, steps, T, s_first, s_end, nblk_hint);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -337,10 +384,10 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 				const char *e = sweep_env("TSPWS_FEW_SPEC_MIN"); min_rows = e ? std::max(1, atoi(e)) : 64;
 				if (const char *m = sweep_env("TSPWS_FEW_NSMAX")) nsmax_env = (unsigned)std::max(2, atoi(m));
 			}
-			const char *eng = getenv("TSPWS_ENGINE");
-			if (ntr >= (size_t)min_rows && !(eng && !strcmp(eng, "fir")) && !tspws_generic_forward()) {
+			if (ntr >= (size_t)min_rows && tspws_engine_pin() != 1 && !tspws_generic_forward()) {
 				const unsigned sf = tspws_spectral_first_scale(p, nsmax_env ? nsmax_env : std::max(512u, p->N / 8u));
-				if (sf < p->S) {
+				// (a frame whose coarsest filters do not fit the transform window keeps its rows on the FIR kernels: they take ONE run of scales)
+				if (sf < p->S && tspws_spectral_end_scale(p) == p->S) {
 					SpecDecomp *dc = nullptr;
 					int rc;
 					if ((rc = tspws_spectral_decomp(p, sf, (unsigned)((ntr + 63) / 64), &dc, true))) return rc;
@@ -531,21 +578,20 @@ static bool many_trace_size(const tspws_hip_plan *p, size_t ntr) { return ntr >=
 static bool spectral_size(const tspws_hip_plan *p, size_t ntr) { return ntr >= 64 && ((double)ntr * (double)p->N >= 1048576.0 || ntr >= 256); }
 unsigned tspws_spectral_choice(const tspws_hip_plan *p, size_t ntr)
 {
-	static int eng = -1; // 0 auto, 1 fir, 2 spectral
-	static unsigned nsmax_env = 0;
-	if (eng < 0) {
-		const char *e = getenv("TSPWS_ENGINE");
-		eng = !e ? 0 : !strcmp(e, "fir") ? 1 : !strcmp(e, "spectral") ? 2 : 0;
-		if (const char *m = sweep_env("TSPWS_SPEC_NSMAX")) nsmax_env = (unsigned)std::max(2, atoi(m));
-	}
+	const int eng = tspws_engine_pin(); // 0 auto, 1 fir, 2 spectral
+	static unsigned nsmax_env = ~0u;
+	if (nsmax_env == ~0u) { const char *m = sweep_env("TSPWS_SPEC_NSMAX"); nsmax_env = m ? (unsigned)std::max(2, atoi(m)) : 0u; }
 	if (eng == 1 || tspws_generic_forward() || !ntr) return p->S;
 	if (eng == 0 && !spectral_size(p, ntr)) return p->S;
 	// (two voices per octave -- the Mexican hat --: the trace-lane kernel is at its weakest there (it shares its staged rows among the voices of
 	// an octave), so one octave more goes through the spectrum: 1024 x 32768 Mexican hat 2.47 ms on the few-trace kernels, 1.56 / 1.52 / 1.54 ms
 	// with N_s <= 1024 / 2048 / 4096; 4096 x 8192 2.72 -> 1.51-1.54; 512 x 65536 2.52 -> 1.73 with N_s <= 4096)
-	return tspws_spectral_first_scale(p, nsmax_env ? nsmax_env : std::max(512u, p->N / (p->V > 2 ? 32u : 16u)));
+	const unsigned dmin = p->V > 2 ? 32u : 16u; // (N_s = ceil(N / D): the bound that admits D >= dmin for every N)
+	return tspws_spectral_first_scale(p, nsmax_env ? nsmax_env : std::max(512u, (p->N + dmin - 1) / dmin));
 }
 
+static int spectral_transpose_t(tspws_hip_plan *p, const float *d_x, size_t ld, unsigned ntr, float *xT, unsigned TP, hipStream_t st) { return tspws_spectral_transpose_f32(p, d_x, ld, ntr, xT, TP, st); }
+static int spectral_transpose_t(tspws_hip_plan *p, const double *d_x, size_t ld, unsigned ntr, double *xT, unsigned TP, hipStream_t st) { return tspws_spectral_transpose_f64(p, d_x, ld, ntr, xT, TP, st); }
 static int spectral_run_t(tspws_hip_plan *p, SpecDecomp *dc, const float *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st)
 { return tspws_spectral_run_f32(p, dc, xT, TP, ntr, ST, PS, stride, Y, st); }
 static int spectral_run_t(tspws_hip_plan *p, SpecDecomp *dc, const double *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st)
@@ -610,7 +656,7 @@ static int forward_spectral(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_
 	TIn *xT = (TIn *)v;
 	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
 		const unsigned nb = (unsigned)std::min(batch, ntr - t0), nblk = (nb + 63) / 64, TP = nblk * 64;
-		hipLaunchKernelGGL((k_transpose_traces<TIn>), dim3((p->N + 63) / 64, nblk), dim3(256), 0, st, d_x + t0 * ld, ld, nb, p->N, TP, xT);
+		if ((rc = spectral_transpose_t(p, d_x + t0 * ld, ld, nb, xT, TP, st))) return rc;
 		if ((rc = spectral_run_t(p, dc, (const TIn *)xT, TP, nb, nullptr, nullptr, 0, (double2 *)d_Y + t0 * p->ncoef, st))) return rc;
 	}
 	HIP_TRY(hipGetLastError());
@@ -618,6 +664,13 @@ static int forward_spectral(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_
 }
 
 extern "C" unsigned tspws_hip_spectral_first_scale(const tspws_hip_plan *p, unsigned nsmax) { return p ? tspws_spectral_first_scale(p, nsmax) : 0u; }
+extern "C" unsigned tspws_hip_spectral_end_scale(const tspws_hip_plan *p) { return p ? tspws_spectral_end_scale(p) : 0u; }
+extern "C" unsigned tspws_hip_spectral_transform_length(const tspws_hip_plan *p)
+{
+	unsigned NT = 0, e, c;
+	if (p) tspws_spectral_geometry(p, &NT, &e, &c);
+	return NT;
+}
 extern "C" unsigned tspws_hip_spectral_choice(const tspws_hip_plan *p, size_t ntr) { return p ? tspws_spectral_choice(p, ntr) : 0u; }
 extern "C" int tspws_hip_forward_spectral_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, size_t ld, double *d_Y, unsigned nsmax, void *s)
 {
@@ -729,21 +782,34 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 	TIn *xT = (TIn *)v;
 	if ((rc = scratch(p, SCR_FZ, nblk_max * 2 * p->ncoef * sizeof(double2), &v))) return rc;
 	double2 *planes = (double2 *)v;
-	double2 *part = nullptr;
+	double2 *part = nullptr, *gsum = nullptr;
 	if (T.npart) { if ((rc = scratch(p, SCR_PART, batch * T.npart * sizeof(double2), &v))) return rc; part = (double2 *)v; }
+	if (T.gcoltiles) { if ((rc = scratch(p, SCR_GEMM, (size_t)T.gKS * batch * T.gcoltiles * 16 * sizeof(double2), &v))) return rc; gsum = (double2 *)v; }
 	for (size_t t0 = 0; t0 < ntr; t0 += batch) {
 		const unsigned nb = (unsigned)std::min(batch, ntr - t0), nblk = (nb + 63) / 64, TP = nblk * 64;
 		const TIn *xb = d_x + t0 * ld;
 		// the direct kernel (scales with too few outputs for the trace-lane kernel: latency-bound, tl partial layout) on the side
 		// stream: it reads the traces themselves, so it starts with the transposition and runs beside the trace-lane kernel
 		hipStream_t sp = st;
-		if (T.waves && dc) { // (a frame whose middle octaves fit neither the trace-lane kernel nor the spectral set: the direct kernel in line)
+		bool poly_join = false;
+		if ((T.waves || T.gcoltiles) && dc) {
+			// the direct kernel of a spectral decomposition: the scales whose filters are too long for the transform window (N not a power of two:
+			// the clipped scales of the shipped example's frame, ~9 % of its FIR work) or middle octaves that fit neither the trace-lane kernel nor
+			// the set.  It reads the traces themselves: a third stream, forked here, joined before the accumulation -- beside the chain and
+			// the trace-lane kernel
+			const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+			if (!p->xs) HIP_TRY(hipStreamCreateWithFlags(&p->xs, hipStreamNonBlocking));
+			if (!p->ev_xs0) HIP_TRY(hipEventCreateWithFlags(&p->ev_xs0, evf));
+			if (!p->ev_xs1) HIP_TRY(hipEventCreateWithFlags(&p->ev_xs1, evf));
+			HIP_TRY(hipEventRecord(p->ev_xs0, st)); // (after the previous batch's accumulation: `part` is free again)
+			HIP_TRY(hipStreamWaitEvent(p->xs, p->ev_xs0, 0));
 			const unsigned nbw = (T.waves + 3) / 4;
-			for (size_t u0 = 0; u0 < nb; u0 += 2 * 32768) {
+			for (size_t u0 = 0; T.waves && u0 < nb; u0 += 2 * 32768) {
 				const unsigned nt = (unsigned)std::min<size_t>(nb - u0, 2 * 32768);
-				hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nbw, (nt + 1) / 2), dim3(256), 0, st, xb + u0 * ld, ld, nt, p->N, T.d_sc, p->S, p->d_w,
+				hipLaunchKernelGGL((k_fwd_poly<TIn, 2>), dim3(nbw, (nt + 1) / 2), dim3(256), 0, p->xs, xb + u0 * ld, ld, nt, p->N, T.d_sc, p->S, p->d_w,
 				                   part + u0 * T.npart, T.npart, T.waves);
 			}
+			poly_join = true;
 		} else if (T.waves) {
 			const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
 			if (!p->side) HIP_TRY(tspws_side_stream(p));
@@ -759,17 +825,26 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 				                   part + u0 * T.npart, T.npart, T.waves);
 			}
 		}
-		hipLaunchKernelGGL((k_transpose_traces<TIn>), dim3((p->N + 63) / 64, nblk), dim3(256), 0, st, xb, ld, nb, p->N, TP, xT);
+		// (a batch with a spectral set: the transposition also leaves the traces' maxima for the chain)
+		if (dc) { if ((rc = spectral_transpose_t(p, xb, ld, nb, xT, TP, st))) return rc; }
+		else hipLaunchKernelGGL((k_transpose_traces<TIn>), dim3((p->N + 63) / 64, nblk), dim3(256), 0, st, xb, ld, nb, p->N, TP, xT);
 		// the spectral chain (transforms through HBM / MALL: bandwidth-bound) beside the trace-lane kernel (FP64-bound) on the side stream
 		static const bool spec_serial = sweep_env("TSPWS_SPEC_SERIAL") != nullptr; // sweeps: one after the other
-		if (dc && T.n && !spec_serial) {
+		if (dc && ((T.n && !spec_serial) || T.gcoltiles)) {
 			const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
 			if (!p->side) HIP_TRY(tspws_side_stream(p));
 			if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, evf));
 			if (!p->ev_join) HIP_TRY(hipEventCreateWithFlags(&p->ev_join, evf));
 			HIP_TRY(hipEventRecord(p->ev_fork, st)); // (after the transposition)
-			HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
-			sp = p->side;
+			if (T.n && !spec_serial) { HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0)); sp = p->side; }
+			if (T.gcoltiles) { // the coarsest scales on the matrix pipe (fwd_gemm.h): the third stream, behind the transposition
+				HIP_TRY(hipStreamWaitEvent(p->xs, p->ev_fork, 0));
+				hipLaunchKernelGGL((k_fwd_gemm<TIn>), dim3((T.gcoltiles + 3) / 4, T.gKS, nblk), dim3(256), 0, p->xs, (const TIn *)xT, TP, nb, p->N,
+				                   (const GemmCol *)T.d_gcols, T.gcoltiles, T.gKC, (const double2 *)p->d_w, gsum);
+				const size_t nred = (size_t)nb * T.gcoltiles * 16;
+				hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, p->xs, (const double2 *)gsum, TP, nb, T.gcoltiles * 16, T.gKS,
+				                   (const GemmCol *)T.d_gcols, part, T.npart);
+			}
 		}
 		if (dc && (rc = spectral_run_t(p, dc, (const TIn *)xT, TP, nb, planes, planes + p->ncoef, 2 * p->ncoef, nullptr, dc && T.n && !spec_serial ? sp : st))) return rc;
 		if (T.n)
@@ -778,6 +853,10 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 		if (sp != st) {
 			HIP_TRY(hipEventRecord(p->ev_join, sp));
 			HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
+		}
+		if (poly_join) {
+			HIP_TRY(hipEventRecord(p->ev_xs1, p->xs));
+			HIP_TRY(hipStreamWaitEvent(st, p->ev_xs1, 0));
 		}
 		FuseOut fz;
 		fz.accST = planes; fz.accPS = planes + p->ncoef; fz.stride = 2 * p->ncoef; fz.tps = 64; fz.applied = true;

@@ -153,6 +153,7 @@ extern "C" int tspws_hip_plan_create(tspws_hip_plan **out, int type, unsigned J,
 	*out = nullptr;
 	if (type > -1 || type < -3) return fail(TSPWS_E_FRAME, "plan_create: only complex families -1/-2/-3");
 	if (V == 0 || J == 0 || N == 0) return fail(TSPWS_E_FRAME, "plan_create: empty frame (J, V and N must be > 0)");
+	if (tspws_engine_pin() < 0) return fail(TSPWS_E_ARG, "plan_create: TSPWS_ENGINE must be fir, spectral or auto");
 	if (tspws_hip_device_count() <= device) return fail(TSPWS_E_NODEV, "plan_create: no such HIP device");
 	HIP_TRY(hipSetDevice(device));
 

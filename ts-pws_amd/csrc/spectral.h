@@ -12,7 +12,7 @@ struct SpecSeg {
 	unsigned nfold;           // first inverse pass of a scale with fewer outputs than classes: entry q = sum of nfold rows q + p len
 	unsigned tw_mul;          // twiddle e^{2 pi i n k / (L radix)} = table entry n k tw_mul
 	unsigned last;            // 1: last pass of an inverse transform (stacks / coefficients)
-	unsigned pad;
+	unsigned nvalid;          // last pass: outputs k < nvalid are coefficients (N_s = ceil(N / D) of the len points when the transform is longer than the trace)
 	unsigned long long src, dst; // first row inside a trace block's region of the source / destination buffer
 	unsigned long long coff;     // last pass: first coefficient of the scale
 	double tau;                  // last pass: noise floor of the scale per unit of max |x|
@@ -27,7 +27,7 @@ struct SpecSlot {
 
 // The decomposition of a many-trace batch that goes with a spectral set: trace-lane items for the finer octaves + scale table.
 struct SpecDecomp {
-	unsigned s_first = 0;
+	unsigned s_first = 0, s_end = 0; // the spectral set [s_first, s_end); scales from s_end on (filters too long for the transform window) stay on the direct kernel
 	bool few = false, small = false; // few: no trace-lane table (rows in columns: spectral.hip's tspws_spectral_rows_*); small: built for < 8 trace blocks
 	TlTable T;
 	SpecPlan *sp = nullptr;

@@ -157,40 +157,28 @@ __global__ void __launch_bounds__(256) k_spec_permute(const double2 *__restrict_
 // ------------------------------------------------------------------------------------------
 // per-call kernels
 // ------------------------------------------------------------------------------------------
-// largest |sample| of every trace of the transposed batch (the noise floor of the transforms scales with it): amax[t] as float bits
-template <typename TIn>
-__global__ void __launch_bounds__(256) k_spec_colmax(const TIn *__restrict__ xT, unsigned TP, unsigned N, unsigned rows_per_wave, unsigned *__restrict__ amax)
+// ---- first pass of the trace transform: z[m] = y[2m] + i y[2m+1] from the transposed batch, L = 1 (no twiddles) -------------------
+// y = the trace itself when its length Nx is the transform length NT (the circular correlation of cdotx.c:44-70 IS the transform's), else its
+// PERIODIC EXTENSION over a window of NT >= Nx + L - 1 samples: y[n] = x[n mod Nx] for n < split = NT - cneg, y[n] = x[(n - NT) mod Nx] above
+// (the cneg samples in front of the trace, where the filters' left halves reach at the first outputs).  A circular correlation of length Nx
+// with L taps is a LINEAR correlation of the periodic signal; over that window the NT-circular one reproduces it at every lag m < Nx.
+__device__ __forceinline__ unsigned spec_ext_row(unsigned n, const unsigned Nx, const unsigned split, const unsigned NT)
 {
-	const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const unsigned w = blockIdx.x * 4 + wv, tb = blockIdx.y;
-	const unsigned n0 = w * rows_per_wave;
-	if (n0 >= N) return;
-	const unsigned n1 = min(N, n0 + rows_per_wave);
-	const TIn *col = xT + (size_t)tb * 64 + lane;
-	float m = 0.f;
-	bool bad = false;
-	unsigned n = n0;
-	for (; n + 8 <= n1; n += 8) { // eight rows in flight
-		TIn v[8];
-#pragma unroll
-		for (int i = 0; i < 8; i++) v[i] = col[(size_t)(n + i) * TP];
-#pragma unroll
-		for (int i = 0; i < 8; i++) { const float a = fabsf((float)v[i]); bad |= !(a == a); m = fmaxf(m, a); }
-	}
-	for (; n < n1; n++) { const float a = fabsf((float)col[(size_t)n * TP]); bad |= !(a == a); m = fmaxf(m, a); }
-	if (bad) m = __int_as_float(0x7f800000); // NaN in the trace: everything is above the floor
-	atomicMax(amax + (size_t)tb * 64 + lane, __float_as_uint(m * 1.0000002f));
+	if (n >= split) return n - NT + Nx; // (cneg <= Nx)
+	while (n >= Nx) n -= Nx;             // (wave-uniform; NT < 4 Nx: at most three rounds)
+	return n;
 }
 
-// ---- first pass of the trace transform: z[m] = x[2m] + i x[2m+1] from the transposed batch, L = 1 (no twiddles) -------------------
 template <typename TIn, int R>
-__device__ __forceinline__ void spec_fwd_first_body(const TIn *__restrict__ col, unsigned TP, double2 *__restrict__ dst, unsigned j, unsigned m)
+__device__ __forceinline__ void spec_fwd_first_body(const TIn *__restrict__ col, unsigned TP, double2 *__restrict__ dst, unsigned j, unsigned m, unsigned Nx,
+                                                    unsigned split)
 {
 	double2 v[R];
+	const unsigned NT = 2u * m * R;
 #pragma unroll
 	for (int n = 0; n < R; n++) {
-		const size_t idx = (size_t)j + (size_t)n * m;
-		v[n] = make_double2((double)col[(2 * idx) * TP], (double)col[(2 * idx + 1) * TP]);
+		const unsigned idx = j + (unsigned)n * m;
+		v[n] = make_double2((double)col[(size_t)spec_ext_row(2 * idx, Nx, split, NT) * TP], (double)col[(size_t)spec_ext_row(2 * idx + 1, Nx, split, NT) * TP]);
 	}
 	SpecDFT<R, false>::run(v);
 #pragma unroll
@@ -198,7 +186,8 @@ __device__ __forceinline__ void spec_fwd_first_body(const TIn *__restrict__ col,
 }
 
 template <typename TIn>
-__global__ void __launch_bounds__(256) k_spec_fwd_first(const TIn *__restrict__ xT, unsigned TP, double2 *__restrict__ dst, size_t dst_rows, unsigned M, unsigned radix)
+__global__ void __launch_bounds__(256) k_spec_fwd_first(const TIn *__restrict__ xT, unsigned TP, double2 *__restrict__ dst, size_t dst_rows, unsigned M, unsigned radix,
+                                                        unsigned Nx, unsigned split)
 {
 	const unsigned lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const unsigned m = M / radix;
@@ -207,9 +196,9 @@ __global__ void __launch_bounds__(256) k_spec_fwd_first(const TIn *__restrict__ 
 	const TIn *col = xT + (size_t)tb * 64 + lane;
 	double2 *d = dst + (size_t)tb * dst_rows * 64 + lane;
 	switch (radix) {
-	case 32: spec_fwd_first_body<TIn, 32>(col, TP, d, j, m); break;
-	case 16: spec_fwd_first_body<TIn, 16>(col, TP, d, j, m); break;
-	default: spec_fwd_first_body<TIn, 8>(col, TP, d, j, m); break;
+	case 32: spec_fwd_first_body<TIn, 32>(col, TP, d, j, m, Nx, split); break;
+	case 16: spec_fwd_first_body<TIn, 16>(col, TP, d, j, m, Nx, split); break;
+	default: spec_fwd_first_body<TIn, 8>(col, TP, d, j, m, Nx, split); break;
 	}
 }
 
@@ -624,7 +613,7 @@ __device__ __forceinline__ void spec_inv_last_body(const double2 *__restrict__ s
 		if (t < ep.ntr) {
 			double2 *y = ep.Y + (size_t)t * ep.ncoef + sg->coff;
 #pragma unroll
-			for (int n = 0; n < R; n++) y[j0 + (size_t)n * L] = make_double2(v[n].x, -v[n].y);
+			for (int n = 0; n < R; n++) if (j0 + (size_t)n * L < sg->nvalid) y[j0 + (size_t)n * L] = make_double2(v[n].x, -v[n].y);
 		}
 		return;
 	}
@@ -637,6 +626,7 @@ __device__ __forceinline__ void spec_inv_last_body(const double2 *__restrict__ s
 	constexpr int NCH = (R + 7) / 8;
 #pragma unroll
 	for (int ch = 0; ch < NCH; ch++) {
+		if (j0 + (size_t)(ch * 8) * L >= sg->nvalid) break; // (wave-uniform) a transform longer than the trace: the outputs from N_s on are not coefficients
 		double st16[16], ps16[16];
 #pragma unroll
 		for (int i = 0; i < 8; i++) {
@@ -654,8 +644,10 @@ __device__ __forceinline__ void spec_inv_last_body(const double2 *__restrict__ s
 		const int n = ch * 8 + (int)(o16 >> 1);
 		if ((lane & 3) == 0 && n < R) {
 			const size_t kk = j0 + (size_t)n * L;
-			((double *)(pS + kk))[o16 & 1] = sm;
-			((double *)(pP + kk))[o16 & 1] = q;
+			if (kk < sg->nvalid) {
+				((double *)(pS + kk))[o16 & 1] = sm;
+				((double *)(pP + kk))[o16 & 1] = q;
+			}
 		}
 	}
 }
@@ -771,8 +763,10 @@ static std::vector<unsigned> radix_bits(unsigned m, unsigned last_max)
 }
 
 struct SpecPlan {
-	unsigned s_first = 0;                 // scales [s_first, S) are spectral
-	unsigned N = 0, M = 0, R = 0, logsteps = 0, NS = 0, ngroups = 0;
+	unsigned s_first = 0, s_end = 0;      // scales [s_first, s_end) are spectral
+	unsigned N = 0;                       // transform length NT (a power of two; the trace length itself when that is one)
+	unsigned Nx = 0, split = 0;           // trace length; samples [split, NT) of the transform window hold the samples in FRONT of the trace (spec_ext_row)
+	unsigned M = 0, R = 0, logsteps = 0, NS = 0, ngroups = 0;
 	size_t grows = 0;                     // rows of a trace block's folded spectra (all slots)
 	std::vector<unsigned> fwd_bits;       // passes of the trace transform
 	double2 *d_tw = nullptr, *d_tab = nullptr;
@@ -784,57 +778,113 @@ struct SpecPlan {
 	unsigned long long nrowcoef = 0;      // ... and their coefficients altogether
 };
 
+static void spec_plan_free(SpecPlan *sp)
+{
+	if (!sp) return;
+	if (sp->d_tw) (void)hipFree(sp->d_tw);
+	if (sp->d_tab) (void)hipFree(sp->d_tab);
+	if (sp->d_slots) (void)hipFree(sp->d_slots);
+	if (sp->d_fseg) (void)hipFree(sp->d_fseg);
+	for (SpecSeg *s : sp->d_iseg) if (s) (void)hipFree(s);
+	if (sp->d_rows) (void)hipFree(sp->d_rows);
+	delete sp;
+}
+
+static void spec_decomp_free(SpecDecomp *d)
+{
+	if (!d) return;
+	spec_plan_free(d->sp);
+	if (d->T.d_sc) (void)hipFree(d->T.d_sc);
+	if (d->T.d_items) (void)hipFree(d->T.d_items);
+	if (d->T.d_gcols) (void)hipFree(d->T.d_gcols);
+	delete d;
+}
+
 void tspws_spectral_destroy(tspws_hip_plan *p)
 {
-	for (SpecDecomp *d : p->spec) {
-		if (!d) continue;
-		if (SpecPlan *sp = d->sp) {
-			if (sp->d_tw) (void)hipFree(sp->d_tw);
-			if (sp->d_tab) (void)hipFree(sp->d_tab);
-			if (sp->d_slots) (void)hipFree(sp->d_slots);
-			if (sp->d_fseg) (void)hipFree(sp->d_fseg);
-			for (SpecSeg *s : sp->d_iseg) if (s) (void)hipFree(s);
-			if (sp->d_rows) (void)hipFree(sp->d_rows);
-			delete sp;
-		}
-		if (d->T.d_sc) (void)hipFree(d->T.d_sc);
-		if (d->T.d_items) (void)hipFree(d->T.d_items);
-		delete d;
-	}
+	for (SpecDecomp *d : p->spec) spec_decomp_free(d);
 	p->spec.clear();
 }
 
-// Can scale s go through the spectrum?  N a power of two >= 1024, D a power of two >= 8 that divides N, at least two outputs.
-static bool spec_scale_ok(const tspws_hip_plan *p, unsigned s)
+// Transform geometry of this frame: the transform length NT, the end of the scales whose filters fit its window, the samples kept in front
+// of the trace.  N a power of two: NT = N, the reference's circular correlation (cdotx.c:44-70) IS the transform's, every scale fits.  Any
+// other N: the correlation is evaluated as a linear one over a window of the trace's periodic extension (k_spec_fwd_first), which takes
+// NT >= N + L - 1 for a filter of L taps.  NT0 = the next power of two above N serves the scales with L <= NT0 - N + 1; the longer ones (the
+// coarsest scales, few outputs each) stay on the direct FIR kernel -- unless they are more than a quarter of the far-decimated work, then the
+// window is 2 NT0 >= 2 N and holds every filter (L <= N).  TSPWS_SPEC_NT = min / double (sweeps) pins the choice.
+void tspws_spectral_geometry(const tspws_hip_plan *p, unsigned *NT, unsigned *s_end, unsigned *cneg)
 {
-	const unsigned N = p->N, D = p->sc[s].D;
-	return N >= 1024 && (N & (N - 1)) == 0 && D >= 8 && (D & (D - 1)) == 0 && N % D == 0 && p->sc[s].Ns == N / D && p->sc[s].Ns >= 2 && p->sc[s].L <= N;
+	const unsigned N = p->N, S = p->S;
+	*NT = N; *s_end = S; *cneg = 0;
+	if ((N & (N - 1)) == 0) return;
+	unsigned nt = 1;
+	while (nt < N) nt <<= 1;
+	unsigned e = 0;
+	while (e < S && (unsigned long long)N + p->sc[e].L - 1 <= nt) e++; // (L grows with the scale)
+	double in = 0, out = 0;
+	for (unsigned s = 0; s < S; s++) {
+		const unsigned D = p->sc[s].D;
+		if (D < 8 || (D & (D - 1))) continue;
+		(s < e ? in : out) += (double)p->sc[s].L * (double)p->sc[s].Ns;
+	}
+	bool dbl = e < S && out > 0.25 * (in + out);
+	if (const char *v = sweep_env("TSPWS_SPEC_NT")) { if (!strcmp(v, "min")) dbl = false; else if (!strcmp(v, "double")) dbl = true; }
+	if (dbl && nt <= (1u << 30)) { nt <<= 1; e = S; }
+	int cm = 0;
+	for (unsigned s = 0; s < e; s++) cm = std::max(cm, p->sc[s].c);
+	*NT = nt; *s_end = e; *cneg = (unsigned)cm;
 }
 
-// first scale of the spectral set when every octave with at most nsmax outputs is to go through the spectrum (S: none).
-// The set is a run at the coarse end of the frame: whole octaves, D strictly growing from octave to octave.
+unsigned tspws_spectral_end_scale(const tspws_hip_plan *p)
+{
+	unsigned NT, e, c;
+	tspws_spectral_geometry(p, &NT, &e, &c);
+	return e;
+}
+
+// Can scale s go through the spectrum?  N >= 1024, D a power of two >= 8 with at least two folded bins, the filter inside the transform window
+// (N a power of two: D | N and the window is the trace).
+static bool spec_scale_ok(const tspws_hip_plan *p, unsigned s, unsigned NT, unsigned s_end)
+{
+	const unsigned N = p->N, D = p->sc[s].D;
+	if (N < 1024 || s >= s_end || D < 8 || (D & (D - 1)) || NT / D < 2 || p->sc[s].L > N) return false;
+	if (NT == N) return N % D == 0 && p->sc[s].Ns == N / D && p->sc[s].Ns >= 2;
+	return (unsigned long long)N + p->sc[s].L - 1 <= NT && p->sc[s].Ns == (N + D - 1) / D;
+}
+
+// first scale of the spectral set when every octave with at most nsmax outputs is to go through the spectrum (none: the set's end).
+// The set is a run of scales that ends at tspws_spectral_end_scale (S for most frames): whole octaves at its fine end, D doubling from octave to octave.
 unsigned tspws_spectral_first_scale(const tspws_hip_plan *p, unsigned nsmax)
 {
-	unsigned first = p->S;
-	for (unsigned e = p->S; e > 0;) {
+	unsigned NT, s_end, cneg;
+	tspws_spectral_geometry(p, &NT, &s_end, &cneg);
+	unsigned first = s_end;
+	for (unsigned e = s_end; e > 0;) {
 		unsigned s = e - 1;
 		while (s > 0 && p->sc[s - 1].D == p->sc[e - 1].D && p->sc[s - 1].Ns == p->sc[e - 1].Ns) s--;
-		bool ok = p->sc[s].Ns <= nsmax && p->S - s <= 128; // (at most 8 groups of 16 accumulators)
-		for (unsigned v = s; v < e && ok; v++) ok = spec_scale_ok(p, v);
-		if (ok && e < p->S && p->sc[e].D != 2 * p->sc[s].D) ok = false; // consecutive octaves double the decimation
+		bool ok = p->sc[s].Ns <= nsmax && s_end - s <= 128; // (at most 8 groups of 16 accumulators)
+		for (unsigned v = s; v < e && ok; v++) ok = spec_scale_ok(p, v, NT, s_end);
+		if (ok && e < s_end && p->sc[e].D != 2 * p->sc[s].D) ok = false; // consecutive octaves double the decimation
 		if (!ok) break;
 		first = s;
 		e = s;
 	}
-	return first;
+	return first < s_end ? first : p->S; // (S: no set)
 }
 
-static int spec_build(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, SpecPlan **out)
+static int spec_build(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, SpecPlan *sp)
 {
-	SpecPlan *sp = new SpecPlan;
-	*out = sp;
-	const unsigned N = p->N, M = N / 2, S = p->S, nsc = S - s_first;
-	sp->s_first = s_first; sp->N = N; sp->M = M;
+	// (device temporaries of the plan-time transforms: freed on every exit)
+	struct Tmp {
+		void *v[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+		~Tmp() { for (void *q : v) if (q) (void)hipFree(q); }
+	} tmp;
+	unsigned NT, s_end, cneg;
+	tspws_spectral_geometry(p, &NT, &s_end, &cneg);
+	const unsigned N = NT, M = N / 2, S = p->S;
+	if (s_first >= s_end) return fail(TSPWS_E_ARG, "spectral: empty set");
+	const unsigned nsc = s_end - s_first;
+	sp->s_first = s_first; sp->s_end = s_end; sp->N = N; sp->M = M; sp->Nx = p->N; sp->split = N - cneg;
 	// scale groups: groups of at most 16 scales (a wave's accumulators for two trace blocks: 128 VGPRs), padded to 8 or 16 slots (a 1-KB
 	// block of a group's table stream holds 8 or 4 steps); the groups of a class share a workgroup (k_spec_fold)
 	if (nsc > 128) return fail(TSPWS_E_ARG, "spectral: more than 128 scales in the spectral set");
@@ -851,7 +901,8 @@ static int spec_build(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, S
 	unsigned R = 64;
 	while ((size_t)R * ngroups * std::max(1u, nblk_hint) < 4096 && N / (2 * R) >= 32) R *= 2;
 	sp->R = R; sp->logsteps = ilog2u(N / R);
-	// slots of a group in the order of the scales (D grows), partial ones (N_s < R) last by construction; pads are idle
+	// slots of a group in the order of the scales (D grows), partial ones (fewer folded bins than classes) last by construction; pads are idle.
+	// A scale's folded spectrum has N / D bins (= its N_s outputs when the transform is the trace's length)
 	std::vector<SpecSlot> slots((size_t)ngroups * NS);
 	std::vector<unsigned> slot_scale((size_t)ngroups * NS, ~0u);
 	std::vector<size_t> goff(S, 0);
@@ -860,12 +911,12 @@ static int spec_build(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, S
 		for (unsigned i = 0; i < NS; i++) {
 			SpecSlot &sl = slots[(size_t)g * NS + i];
 			const unsigned s = s_first + g * per + i;
-			if (i < per && s < S) {
-				const unsigned D = p->sc[s].D, Ns = p->sc[s].Ns;
+			if (i < per && s < s_end) {
+				const unsigned D = p->sc[s].D, Nb = N / D;
 				slot_scale[(size_t)g * NS + i] = s;
 				goff[s] = rows;
 				sl.goff = rows;
-				if (Ns >= R) { sl.ld = ilog2u(D); sl.lb = ilog2u(Ns / R); rows += Ns; }
+				if (Nb >= R) { sl.ld = ilog2u(D); sl.lb = ilog2u(Nb / R); rows += Nb; }
 				else { sl.ld = 31; sl.lb = 0; rows += R; }
 			} else { sl.ld = 31; sl.lb = 31; sl.goff = 0; }
 		}
@@ -896,31 +947,31 @@ static int spec_build(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, S
 	// ---- tap norms (noise floor of a scale) ----
 	std::vector<double> wn(S, 0.0);
 	{
-		double *d_wn = nullptr;
-		HIP_TRY(hipMalloc(&d_wn, S * sizeof(double)));
-		hipLaunchKernelGGL(k_spec_wnorm, dim3(S), dim3(256), 0, 0, (const ScaleDesc *)p->d_sc, (const double2 *)p->d_w, d_wn);
-		HIP_TRY(hipMemcpy(wn.data(), d_wn, S * sizeof(double), hipMemcpyDeviceToHost));
-		(void)hipFree(d_wn);
+		HIP_TRY(hipMalloc(&tmp.v[0], S * sizeof(double)));
+		hipLaunchKernelGGL(k_spec_wnorm, dim3(S), dim3(256), 0, 0, (const ScaleDesc *)p->d_sc, (const double2 *)p->d_w, (double *)tmp.v[0]);
+		HIP_TRY(hipMemcpy(wn.data(), tmp.v[0], S * sizeof(double), hipMemcpyDeviceToHost));
 	}
+	// |error| of an output of the transform-based correlation <~ eps log2(N) ||y||_2 ||w||_2 <= eps log2(N) sqrt(N) max|x| ||w||_2; x 8
+	auto tau_of = [&](unsigned s) { return 8.0 * 1.1102230246251565e-16 * (double)ilog2u(N) * sqrt((double)N) * wn[s]; };
 	// ---- inverse transforms: level l = pass l of every scale with more than l passes ----
 	{
 		std::vector<std::vector<SpecSeg>> lev;
-		for (unsigned s = s_first; s < S; s++) {
-			const unsigned Ns = p->sc[s].Ns;
-			const std::vector<unsigned> bits = radix_bits(ilog2u(Ns), 4); // (last pass <= 16 points: its epilogue holds the normalised copies too)
+		for (unsigned s = s_first; s < s_end; s++) {
+			const unsigned Nb = N / p->sc[s].D;
+			const std::vector<unsigned> bits = radix_bits(ilog2u(Nb), 4); // (last pass <= 16 points: its epilogue holds the normalised copies too)
 			unsigned L = 1;
 			for (size_t i = 0; i < bits.size(); i++) {
 				if (lev.size() <= i) lev.emplace_back();
 				const unsigned Rr = 1u << bits[i];
 				SpecSeg g;
 				memset(&g, 0, sizeof g);
-				g.len = Ns; g.L = L; g.radix = Rr; g.tw_mul = N / (L * Rr);
-				g.nfold = (i == 0 && Ns < R) ? R / Ns : 1u;
+				g.len = Nb; g.L = L; g.radix = Rr; g.tw_mul = N / (L * Rr);
+				g.nfold = (i == 0 && Nb < R) ? R / Nb : 1u;
 				g.src = g.dst = goff[s];
 				g.last = (i + 1 == bits.size()) ? 1u : 0u;
+				g.nvalid = p->sc[s].Ns;
 				g.coff = p->sc[s].coef_off;
-				// |error| of an output of the FFT-based correlation <~ eps log2(N) ||x||_2 ||w||_2 <= eps log2(N) sqrt(N) max|x| ||w||_2; x 8
-				g.tau = 8.0 * 1.1102230246251565e-16 * (double)ilog2u(N) * sqrt((double)N) * wn[s];
+				g.tau = tau_of(s);
 				lev[i].push_back(g);
 				L *= Rr;
 			}
@@ -928,13 +979,13 @@ static int spec_build(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, S
 		{ // the scales' final rows for k_spec_stack_rows: the last of a scale's npass passes wrote buffer (npass & 1) (pass 0 reads buffer 0)
 			std::vector<SpecRowScale> rv;
 			unsigned long long ro = 0;
-			for (unsigned s = s_first; s < S; s++) {
+			for (unsigned s = s_first; s < s_end; s++) {
 				const unsigned Ns = p->sc[s].Ns;
 				SpecRowScale q;
 				memset(&q, 0, sizeof q);
 				q.roff = ro; q.goff = goff[s]; q.coff = p->sc[s].coef_off; q.Ns = Ns;
-				q.buf = (unsigned)(radix_bits(ilog2u(Ns), 4).size() & 1u);
-				q.tau = 8.0 * 1.1102230246251565e-16 * (double)ilog2u(N) * sqrt((double)N) * wn[s];
+				q.buf = (unsigned)(radix_bits(ilog2u(N / p->sc[s].D), 4).size() & 1u);
+				q.tau = tau_of(s);
 				rv.push_back(q);
 				ro += Ns;
 			}
@@ -947,22 +998,22 @@ static int spec_build(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, S
 			for (SpecSeg &g : v) { g.item0 = items; items += g.len / g.radix; }
 			SpecSeg *d = nullptr;
 			HIP_TRY(hipMalloc(&d, v.size() * sizeof(SpecSeg)));
-			HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(SpecSeg), hipMemcpyHostToDevice));
 			sp->d_iseg.push_back(d); sp->iseg_n.push_back((unsigned)v.size()); sp->iseg_items.push_back(items);
+			HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(SpecSeg), hipMemcpyHostToDevice));
 		}
 	}
-	// ---- tables H_s: taps placed circularly -> N-point transform with lane = slot -> class / step order, 1 / N ----
+	// ---- tables H_s: taps placed circularly in the transform window -> N-point transform with lane = slot -> class / step order, 1 / N ----
 	{
 		const unsigned nslots = ngroups * NS, nsb = (nslots + 63) / 64;
-		unsigned *d_ss = nullptr;
-		double2 *a = nullptr, *b = nullptr;
 		const size_t bytes = (size_t)nsb * N * 64 * sizeof(double2);
-		HIP_TRY(hipMalloc(&d_ss, slot_scale.size() * sizeof(unsigned)));
+		HIP_TRY(hipMalloc(&tmp.v[1], slot_scale.size() * sizeof(unsigned)));
+		unsigned *d_ss = (unsigned *)tmp.v[1];
 		HIP_TRY(hipMemcpy(d_ss, slot_scale.data(), slot_scale.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-		HIP_TRY(hipMalloc(&a, bytes));
-		HIP_TRY(hipMalloc(&b, bytes));
+		HIP_TRY(hipMalloc(&tmp.v[2], bytes));
+		HIP_TRY(hipMalloc(&tmp.v[3], bytes));
+		double2 *a = (double2 *)tmp.v[2], *b = (double2 *)tmp.v[3];
 		HIP_TRY(hipMemset(a, 0, bytes));
-		hipLaunchKernelGGL(k_spec_place, dim3((N + 255) / 256, nslots), dim3(256), 0, 0, (const ScaleDesc *)p->d_sc, (const double2 *)p->d_w, (const unsigned *)d_ss, N, a);
+		hipLaunchKernelGGL(k_spec_place, dim3((p->N + 255) / 256, nslots), dim3(256), 0, 0, (const ScaleDesc *)p->d_sc, (const double2 *)p->d_w, (const unsigned *)d_ss, N, a);
 		const std::vector<unsigned> bits = radix_bits(ilog2u(N), 5);
 		std::vector<SpecSeg> ts;
 		unsigned L = 1;
@@ -973,8 +1024,8 @@ static int spec_build(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, S
 			ts.push_back(g);
 			L *= g.radix;
 		}
-		SpecSeg *d_ts = nullptr;
-		HIP_TRY(hipMalloc(&d_ts, ts.size() * sizeof(SpecSeg)));
+		HIP_TRY(hipMalloc(&tmp.v[4], ts.size() * sizeof(SpecSeg)));
+		SpecSeg *d_ts = (SpecSeg *)tmp.v[4];
 		HIP_TRY(hipMemcpy(d_ts, ts.data(), ts.size() * sizeof(SpecSeg), hipMemcpyHostToDevice));
 		for (size_t i = 0; i < ts.size(); i++) {
 			const unsigned items = N / ts[i].radix;
@@ -987,13 +1038,14 @@ static int spec_build(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, S
 		HIP_TRY(hipMemset(sp->d_tab + total, 0, 8 * sizeof(double2)));
 		hipLaunchKernelGGL(k_spec_permute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, (const double2 *)a, N, R, sp->logsteps, NS, ngroups, sp->d_tab);
 		HIP_TRY(hipDeviceSynchronize());
-		(void)hipFree(a); (void)hipFree(b); (void)hipFree(d_ts); (void)hipFree(d_ss);
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
 
-// The decomposition of a many-trace batch with the scales [s_first, S) on the spectral engine (built on first use, kept by the plan).
+// The decomposition of a many-trace batch with the scales [s_first, end of the frame's spectral scales) on the spectral engine (built on
+// first use, kept by the plan).  Built into a local object: a failed build (an allocation of the plan-time tables) leaves nothing behind
+// that a later call could find under its key.
 int tspws_spectral_decomp(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, SpecDecomp **out, bool few)
 {
 	// (the class count of the fold is sized for the batch: a decomposition built for a few trace blocks is not the one for many)
@@ -1001,9 +1053,12 @@ int tspws_spectral_decomp(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hin
 	for (SpecDecomp *d : p->spec) if (d->s_first == s_first && d->few == few && d->small == small) { *out = d; return 0; }
 	SpecDecomp *d = new SpecDecomp;
 	d->s_first = s_first; d->few = few; d->small = small;
+	d->sp = new SpecPlan;
+	int rc = spec_build(p, s_first, nblk_hint, d->sp);
+	d->s_end = d->sp->s_end;
+	if (!rc && !few) rc = tspws_build_tl_spectral(p, s_first, d->s_end, nblk_hint, d->T); // (few rows in columns: the FIR kernels of the few-trace path do the rest)
+	if (rc) { spec_decomp_free(d); return rc; }
 	p->spec.push_back(d);
-	if (int rc = spec_build(p, s_first, nblk_hint, &d->sp)) return rc;
-	if (!few) if (int rc = tspws_build_tl_spectral(p, s_first, d->T)) return rc; // (few rows in columns: the FIR kernels of the few-trace path do the rest)
 	*out = d;
 	return 0;
 }
@@ -1015,7 +1070,7 @@ static int spectral_run(tspws_hip_plan *p, SpecDecomp *dc, const TIn *xT, unsign
                         const SpecRowsOut *ro = nullptr, unsigned tps = 0, unsigned ncol = 0)
 {
 	SpecPlan *sp = dc->sp;
-	const unsigned N = sp->N, M = sp->M, nblk = TP / 64;
+	const unsigned N = sp->N, M = sp->M, nblk = TP / 64; // (N: the transform length; the traces have sp->Nx samples)
 	const size_t xrows = (size_t)M + 1;
 	void *v;
 	int rc;
@@ -1027,16 +1082,12 @@ static int spectral_run(tspws_hip_plan *p, SpecDecomp *dc, const TIn *xT, unsign
 	double2 *G = (double2 *)v;
 	if ((rc = scratch(p, SCR_SPM, (size_t)TP * sizeof(unsigned), &v))) return rc;
 	unsigned *amax = (unsigned *)v;
-	if (!ro) { // (rows in columns: the transposition left the rows' maxima there already)
-		HIP_TRY(hipMemsetAsync(amax, 0, (size_t)TP * sizeof(unsigned), st));
-		const unsigned rpw = 64, waves = (N + rpw - 1) / rpw;
-		hipLaunchKernelGGL((k_spec_colmax<TIn>), dim3((waves + 3) / 4, nblk), dim3(256), 0, st, xT, TP, N, rpw, amax);
-	}
+	// (amax: the largest |sample| of every trace / row, left there by the transposition -- tspws_spectral_transpose_*, spectral_rows)
 	// trace transform
 	const size_t np = sp->fwd_bits.size();
 	{
 		const unsigned R0 = 1u << sp->fwd_bits[0];
-		hipLaunchKernelGGL((k_spec_fwd_first<TIn>), dim3((M / R0 + 3) / 4, nblk), dim3(256), 0, st, xT, TP, A, xrows, M, R0);
+		hipLaunchKernelGGL((k_spec_fwd_first<TIn>), dim3((M / R0 + 3) / 4, nblk), dim3(256), 0, st, xT, TP, A, xrows, M, R0, sp->Nx, sp->split);
 	}
 	double2 *cur = A, *oth = B;
 	for (size_t i = 1; i + 1 < np; i++) {
@@ -1099,7 +1150,7 @@ static int spectral_run(tspws_hip_plan *p, SpecDecomp *dc, const TIn *xT, unsign
 	if (ro) {
 		if (nblk > 8) return fail(TSPWS_E_ARG, "spectral: at most 512 rows in columns");
 		const size_t lds = (size_t)4 * nblk * 64 * 4 * sizeof(double);
-		hipLaunchKernelGGL(k_spec_stack_rows, dim3((unsigned)((sp->nrowcoef + 3) / 4)), dim3(256), lds, st, (const SpecRowScale *)sp->d_rows, p->S - sp->s_first, sp->nrowcoef,
+		hipLaunchKernelGGL(k_spec_stack_rows, dim3((unsigned)((sp->nrowcoef + 3) / 4)), dim3(256), lds, st, (const SpecRowScale *)sp->d_rows, sp->s_end - sp->s_first, sp->nrowcoef,
 		                   (const double2 *)G, sp->grows, (const double2 *)g2, g2rows, nblk, ntr, tps, ncol, (const unsigned *)amax, *ro);
 	}
 	HIP_TRY(hipGetLastError());
@@ -1167,6 +1218,27 @@ __global__ void __launch_bounds__(1024) k_spec_rowmax(const unsigned *__restrict
 	}
 }
 
+// xT[n][t] = x[t][n] for a batch of ntr traces / rows (TP = padded count, pad lanes zero) + the largest |sample| of each into the plan's
+// SCR_SPM block, where spectral_run looks for them (the noise floor of the transforms scales with it).  One pass over the batch: a pass of its
+// own over the transposed copy for the maxima was 26 us at the head of the chain of a 499 x 16501 call.
+template <typename TIn>
+static int spectral_transpose(tspws_hip_plan *p, const TIn *d_x, size_t ld, unsigned ntr, TIn *xT, unsigned TP, hipStream_t st)
+{
+	const unsigned nblk = TP / 64;
+	void *v;
+	const unsigned np = (p->N + 64 * SPEC_TR_TILES - 1) / (64 * SPEC_TR_TILES);
+	if (int rc = scratch(p, SCR_SPM, (size_t)TP * (np + 1) * sizeof(unsigned), &v)) return rc;
+	unsigned *amax = (unsigned *)v, *pmax = amax + TP;
+	hipLaunchKernelGGL((k_spec_transpose_rows<TIn>), dim3(np, nblk), dim3(256), 0, st, d_x, ld, ntr, p->N, TP, xT, pmax);
+	hipLaunchKernelGGL(k_spec_rowmax, dim3(nblk), dim3(1024), 0, st, (const unsigned *)pmax, np, TP, amax);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+int tspws_spectral_transpose_f32(tspws_hip_plan *p, const float *d_x, size_t ld, unsigned ntr, float *xT, unsigned TP, hipStream_t st)
+{ return spectral_transpose<float>(p, d_x, ld, ntr, xT, TP, st); }
+int tspws_spectral_transpose_f64(tspws_hip_plan *p, const double *d_x, size_t ld, unsigned ntr, double *xT, unsigned TP, hipStream_t st)
+{ return spectral_transpose<double>(p, d_x, ld, ntr, xT, TP, st); }
+
 template <typename TIn>
 static int spectral_rows(tspws_hip_plan *p, SpecDecomp *dc, const TIn *d_x, size_t ld, unsigned ntr, unsigned tps, const SpecRowsOut &ro, hipStream_t st,
                          hipEvent_t after_transposition)
@@ -1176,11 +1248,7 @@ static int spectral_rows(tspws_hip_plan *p, SpecDecomp *dc, const TIn *d_x, size
 	int rc;
 	if ((rc = scratch(p, SCR_XT, (size_t)p->N * TP * sizeof(TIn), &v))) return rc;
 	TIn *xT = (TIn *)v;
-	const unsigned np = (p->N + 64 * SPEC_TR_TILES - 1) / (64 * SPEC_TR_TILES);
-	if ((rc = scratch(p, SCR_SPM, (size_t)TP * (np + 1) * sizeof(unsigned), &v))) return rc;
-	unsigned *amax = (unsigned *)v, *pmax = amax + TP;
-	hipLaunchKernelGGL((k_spec_transpose_rows<TIn>), dim3(np, nblk), dim3(256), 0, st, d_x, ld, ntr, p->N, TP, xT, pmax);
-	hipLaunchKernelGGL(k_spec_rowmax, dim3(nblk), dim3(1024), 0, st, (const unsigned *)pmax, np, TP, amax);
+	if ((rc = spectral_transpose<TIn>(p, d_x, ld, ntr, xT, TP, st))) return rc;
 	if (after_transposition) HIP_TRY(hipEventRecord(after_transposition, st)); // (the rows themselves are not read again by this chain)
 	return spectral_run<TIn>(p, dc, (const TIn *)xT, TP, ntr, nullptr, nullptr, 0, nullptr, st, &ro, tps, ncol);
 }

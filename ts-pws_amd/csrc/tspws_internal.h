@@ -53,7 +53,7 @@ static inline hipStream_t S_(void *s) { return (hipStream_t)s; }
 // lib/libtspws_hip_sweeps.so, what tools/build_variant.sh and the engine-agreement tests load through TSPWS_LIB_PATH).  The shipped
 // library's environment is TSPWS_DEVICE / TSPWS_DEVICES / TSPWS_PLAN_CACHE (tspws_main.c), TSPWS_COMM (comm.hip), TSPWS_PART_MB,
 // TSPWS_ENGINE (forward.hip) and, in the Python binding, TSPWS_SCHEDULE / TSPWS_SHARD_FINISH -- nothing else a caller's
-// environment could reach.
+// environment could reach.  (TSPWS_SCHEDULE is also read by comm.hip's device-list call.)
 #ifdef TSPWS_SWEEPS
 static inline const char *sweep_env(const char *name) { return getenv(name); }
 #else
@@ -166,13 +166,14 @@ struct AccExtra {
 	bool fused_done = false;          // the fused forward kernel completed (and weighted) the stacks of its scales itself: only the others are left
 };
 
-enum { SCR_Y = 0, SCR_PART, SCR_XT, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_JKTAB, SCR_SPA, SCR_SPB, SCR_SPG, SCR_SPH, SCR_SPM, SCR_N };
+enum { SCR_Y = 0, SCR_PART, SCR_XT, SCR_OBUF, SCR_SEL, SCR_SUBST, SCR_CONV, SCR_CHUNK, SCR_P, SCR_STPS, SCR_OUT, SCR_X2, SCR_CLS, SCR_JKP, SCR_JKOUT, SCR_TAB, SCR_FZ, SCR_JKTAB, SCR_SPA, SCR_SPB, SCR_SPG, SCR_SPH, SCR_SPM, SCR_GEMM, SCR_N };
 
 struct OctDesc; // inverse work items (inv_poly.h)
 struct TLItem;  // many-trace forward work items (fwd_tl.h)
 
 // One work decomposition of the many-trace forward path: its own scale table (partial layout, fused flags, accumulate
 // geometry), the trace-lane work items of k_fwd_tl and the waves of the direct kernel for the scales it leaves out.
+struct GemmCol; // columns of the matrix-pipe kernel for the coarsest scales (fwd_gemm.h)
 struct TlTable {
 	unsigned minns = 0;              // octaves with fewer outputs than this stay on the direct kernel
 	std::vector<ScaleDesc> sc;
@@ -180,6 +181,9 @@ struct TlTable {
 	TLItem *d_items = nullptr;
 	unsigned n = 0, wgs = 0, waves = 0, acc2_blocks = 0; // items, workgroups per trace block, direct-kernel waves, accumulate blocks
 	size_t npart = 0, lds = 0;
+	// spectral decompositions of frames whose coarsest filters do not fit the transform window: those scales as one dense contraction (k_fwd_gemm)
+	GemmCol *d_gcols = nullptr;
+	unsigned gcoltiles = 0, gKS = 0, gKC = 0; // tiles of 16 columns, runs of samples per (trace block, tile), samples per run
 };
 
 struct SpecDecomp; // spectral engine (spectral.h)
@@ -346,15 +350,21 @@ bool tspws_fused_forward(const tspws_hip_plan *p);        // the few-trace forwa
 bool tspws_many_trace_path(const tspws_hip_plan *p, size_t ntr); // a batch this size goes to the trace-lane kernel
 unsigned tspws_spectral_choice(const tspws_hip_plan *p, size_t ntr); // first scale of the batch's spectral set (S: none)
 size_t tspws_part_budget_bytes();
+int  tspws_engine_pin();   // TSPWS_ENGINE: 0 auto, 1 fir, 2 spectral, -1 not a value (refused by plan_create)
 bool tspws_generic_forward();
 // spectral.hip: the far-decimated octaves of a many-trace batch through the traces' spectra
-unsigned tspws_spectral_first_scale(const tspws_hip_plan *p, unsigned nsmax); // first scale of the spectral set for octaves of <= nsmax outputs (S: none)
+unsigned tspws_spectral_first_scale(const tspws_hip_plan *p, unsigned nsmax); // first scale of the spectral set [first, tspws_spectral_end_scale) for octaves of <= nsmax outputs (S: none)
 int  tspws_spectral_decomp(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, SpecDecomp **out, bool few = false);
 int  tspws_spectral_rows_f64(tspws_hip_plan *p, SpecDecomp *dc, const double *d_x, size_t ld, unsigned ntr, unsigned tps, const FuseOut &fz, hipStream_t st,
                              hipEvent_t after_transposition = nullptr); // few rows in columns
-int  tspws_build_tl_spectral(tspws_hip_plan *p, unsigned s_first, TlTable &T); // (forward.hip) scale table + trace-lane items of that decomposition
+int  tspws_build_tl_spectral(tspws_hip_plan *p, unsigned s_first, unsigned s_end, unsigned nblk_hint, TlTable &T); // (forward.hip) scale table + trace-lane items of that decomposition
+void tspws_spectral_geometry(const tspws_hip_plan *p, unsigned *NT, unsigned *s_end, unsigned *cneg); // transform length, end of the scales that fit its window, samples in front of the trace
+unsigned tspws_spectral_end_scale(const tspws_hip_plan *p); // end of the spectral set (S unless the coarsest filters do not fit the transform window)
 int  tspws_spectral_run_f32(tspws_hip_plan *p, SpecDecomp *dc, const float *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st);
 int  tspws_spectral_run_f64(tspws_hip_plan *p, SpecDecomp *dc, const double *xT, unsigned TP, unsigned ntr, double2 *ST, double2 *PS, size_t stride, double2 *Y, hipStream_t st);
+// the batch transposed (xT[n][t], TP = padded trace count) + the traces' largest |sample| where the spectral chain looks for them
+int  tspws_spectral_transpose_f32(tspws_hip_plan *p, const float *d_x, size_t ld, unsigned ntr, float *xT, unsigned TP, hipStream_t st);
+int  tspws_spectral_transpose_f64(tspws_hip_plan *p, const double *d_x, size_t ld, unsigned ntr, double *xT, unsigned TP, hipStream_t st);
 void tspws_spectral_destroy(tspws_hip_plan *p);
 // inverse.hip
 int  tspws_build_inverse(tspws_hip_plan *p);
