@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--shard-of", type=int, default=None,
                     help="one GPU only: treat the traces as rank 0's shard of an ensemble this many times larger (cfg5 on one GPU: 12 500 of 100 000; "
                          "default 8 for --config cfg5 --gpus 1, else 1)")
+    ap.add_argument("--strong-total", type=int, default=None,
+                    help="N > 1: after the weak-scaling legs, one more leg with this many traces IN ALL, sharded over the ranks (strong scaling; default "
+                         "100 000 = BASELINE configs[4] when the per-GPU size is the default one, else off; 0: off)")
+    ap.add_argument("--collective-timeout", type=int, default=180, help="N > 1: seconds after which a hung collective fails the run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline, host-path and other-config legs")
     ap.add_argument("--no-extra", action="store_true", help="skip the host-path and other-config legs only")
     return ap.parse_args()
@@ -116,10 +120,13 @@ def run(args):
         local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
+        import datetime
+        # (a schedule that hangs -- ranks issuing different collective sequences -- must fail the run, not eat the caller's lease)
+        tmo = datetime.timedelta(seconds=max(30, args.collective_timeout))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
     mtr_local = args.traces if args.traces is not None else (12500 if args.config == "cfg5" else 10000)
     N, K = args.samples, args.kmax
@@ -142,99 +149,128 @@ def run(args):
     red = plan.reduce_buffer(mtr_global)
 
     single = world == 1 and shard_of == 1
-    # N > 1: share of the scales this rank finishes (None: no sharded finish -- agreed across the ranks)
-    shard = tspws._finish_shard(plan, mtr_global) if (world > 1 and schedule == "sharded-finish") else None
-    if world > 1 and schedule == "sharded-finish" and shard is None:
-        schedule = "split"   # this frame / these parameters have no sharded finish
     x2 = torch.empty(2 * N, dtype=torch.float64, device=X.device)
-    # events on the launch stream of every timed step: start, end of streaming, reductions done (finish may start), end
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    launches = [0]
 
-    def piece(g0, g1, count):
-        plan.partial_stacks_range(X, first, mtr_global, g0, g1)
-        if count:
-            launches[0] += lib.tspws_hip_stream_launches(plan.h)
+    def make_leg(sched, Xl, first_l, glob_l):
+        """One timed configuration: a schedule on a shard.  Returns (step, events, launch counter, the schedule that actually runs)."""
+        # N > 1: share of the scales this rank finishes (None: no sharded finish -- agreed across the ranks)
+        shard = tspws._finish_shard(plan, glob_l) if (world > 1 and sched == "sharded-finish") else None
+        if world > 1 and sched == "sharded-finish" and shard is None:
+            sched = "split"   # this frame / these parameters have no sharded finish
+        # events on the launch stream of every timed step: start, end of streaming, reductions done (finish may start), end
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+        launches = [0]
+        buf = plan.reduce_buffer(glob_l).view(K, N)
 
-    def step(i=None, count=False):
-        if single:
-            # one GPU: tspws_hip_stack = stack_local + stack_finish in one C call; HIP events inside the library bracket the
-            # call and its streaming stage on the launch stream
-            plan.stack_single(X, ls, ts)
-            return
-        buf = red.view(K, N)
-        if i is not None:
-            ev[i][0].record()
-        if world == 1:
-            # one GPU standing in for one rank of a larger job: the shard-local half with the global group index, no collective
-            # (there is no peer), then the finish stage on the shard's own buffer
-            plan.stack_local(X, first, mtr_global)
+        def piece(g0, g1, count):
+            plan.partial_stacks_range(Xl, first_l, glob_l, g0, g1)
             if count:
                 launches[0] += lib.tspws_hip_stream_launches(plan.h)
-            if i is not None:
-                ev[i][1].record()
-                ev[i][2].record()
-            plan.stack_finish(mtr_global, ls, ts)
-        elif schedule == "single" or K < 2:
-            # north_star's wording: ONE all-reduce of the whole buffer between the halves, every rank finishes redundantly
-            piece(0, K, count)
-            if i is not None:
-                ev[i][1].record()
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-            if i is not None:
-                ev[i][2].record()
-            plan.stack_finish(mtr_global, ls, ts)
-        else:
-            # the streaming stage in two pieces of the groups; the all-reduce of the first piece (RCCL, its own stream) overlaps the
-            # streaming of the second -- still one logical fp64 reduction of P[Kmax][N] (ts-pws_amd.stack_sharded)
-            half = max(1, tspws.split_groups(K, shard is not None))
-            piece(0, half, count)
-            w1 = dist.all_reduce(buf[:half], op=dist.ReduceOp.SUM, async_op=True)
-            piece(half, K, count)
-            if i is not None:
-                ev[i][1].record()
-            w2 = dist.all_reduce(buf[half:], op=dist.ReduceOp.SUM, async_op=True)
-            if shard is not None:
-                # scale-sharded finish: this rank transforms / weights / reconstructs its share of the scales only; the ranks
-                # add their partial reconstructions (2 N doubles) and every rank ends with the outputs
-                w1.wait()
-                w2.wait()
-                if i is not None:
-                    ev[i][2].record()
-                plan.stack_finish_scales(mtr_global, shard[0], shard[1], x2)
-                dist.all_reduce(x2, op=dist.ReduceOp.SUM)
-                plan.epilogue(x2, mtr_global, ls, ts)
-            else:
-                w1.wait()
-                plan.stack_finish_range(mtr_global, 0, half)   # transforms of the reduced half run beside the second reduction
-                w2.wait()
-                if i is not None:
-                    ev[i][2].record()
-                plan.stack_finish_range(mtr_global, half, K)
-                plan.stack_finish_tail(mtr_global, ls, ts)
-        if i is not None:
-            ev[i][3].record()
 
-    for w in range(max(1, args.warmup)):
-        step(count=(w == 0))
-    torch.cuda.synchronize()
-    if single:
-        plan.profile_begin(args.steps)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=X.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        def step(i=None, count=False):
+            if single:
+                # one GPU: tspws_hip_stack = stack_local + stack_finish in one C call; HIP events inside the library bracket the
+                # call and its streaming stage on the launch stream
+                plan.stack_single(Xl, ls, ts)
+                return
+            if i is not None:
+                ev[i][0].record()
+            if world == 1:
+                # one GPU standing in for one rank of a larger job: the shard-local half with the global group index, no collective
+                # (there is no peer), then the finish stage on the shard's own buffer
+                plan.stack_local(Xl, first_l, glob_l)
+                if count:
+                    launches[0] += lib.tspws_hip_stream_launches(plan.h)
+                if i is not None:
+                    ev[i][1].record()
+                    ev[i][2].record()
+                plan.stack_finish(glob_l, ls, ts)
+            elif sched == "single" or K < 2:
+                # north_star's wording: ONE all-reduce of the whole buffer between the halves, every rank finishes redundantly
+                piece(0, K, count)
+                if i is not None:
+                    ev[i][1].record()
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                if i is not None:
+                    ev[i][2].record()
+                plan.stack_finish(glob_l, ls, ts)
+            else:
+                # the streaming stage in two pieces of the groups; the all-reduce of the first piece (RCCL, its own stream) overlaps the
+                # streaming of the second -- still one logical fp64 reduction of P[Kmax][N] (ts-pws_amd.stack_sharded)
+                half = max(1, tspws.split_groups(K, shard is not None))
+                piece(0, half, count)
+                w1 = dist.all_reduce(buf[:half], op=dist.ReduceOp.SUM, async_op=True)
+                piece(half, K, count)
+                if i is not None:
+                    ev[i][1].record()
+                w2 = dist.all_reduce(buf[half:], op=dist.ReduceOp.SUM, async_op=True)
+                if shard is not None:
+                    # scale-sharded finish: this rank transforms / weights / reconstructs its share of the scales only; the ranks
+                    # add their partial reconstructions (2 N doubles) and every rank ends with the outputs
+                    w1.wait()
+                    w2.wait()
+                    if i is not None:
+                        ev[i][2].record()
+                    plan.stack_finish_scales(glob_l, shard[0], shard[1], x2)
+                    dist.all_reduce(x2, op=dist.ReduceOp.SUM)
+                    plan.epilogue(x2, glob_l, ls, ts)
+                else:
+                    w1.wait()
+                    plan.stack_finish_range(glob_l, 0, half)   # transforms of the reduced half run beside the second reduction
+                    w2.wait()
+                    if i is not None:
+                        ev[i][2].record()
+                    plan.stack_finish_range(glob_l, half, K)
+                    plan.stack_finish_tail(glob_l, ls, ts)
+            if i is not None:
+                ev[i][3].record()
+        return step, ev, launches, sched
+
+    def time_leg(step, warm):
+        """warm untimed steps, then EXACTLY args.steps timed ones between barrier + synchronize on both sides; MAX over the ranks"""
+        for w in range(max(1, warm)):
+            step(count=(w == 0))
+        torch.cuda.synchronize()
+        if single:
+            plan.profile_begin(args.steps)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=X.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def rank_columns(ev):
+        """where a step's time goes on every rank (HIP events on the launch stream): streaming, the part of the reduction(s) that is NOT
+        hidden behind streaming or transforms (end of streaming -> all partial stacks reduced), the rest (finish stage incl. its own small
+        all-reduce under sharded-finish)"""
+        mine = [float(np.mean([e[0].elapsed_time(e[1]) for e in ev])), float(np.mean([e[1].elapsed_time(e[2]) for e in ev])),
+                float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))]
+        if world > 1:
+            t3 = torch.tensor(mine, dtype=torch.float64, device=X.device)
+            allr = [torch.zeros_like(t3) for _ in range(world)]
+            dist.all_gather(allr, t3)
+            return [[round(float(v), 4) for v in t.tolist()] for t in allr]
+        return [[round(v, 4) for v in mine]]
+
+    def digest():
+        import hashlib
+        torch.cuda.synchronize()
+        return hashlib.sha1(ls.cpu().numpy().tobytes() + ts.cpu().numpy().tobytes()).hexdigest()[:16]
+
+    step, ev, launches, schedule = make_leg(schedule, X, first, mtr_global)
+    dt = time_leg(step, args.warmup)
+    out_sha = digest() if world > 1 else None
 
     if single:
         stage_ms, call_ms = plan.profile_read()
@@ -298,19 +334,34 @@ def run(args):
     }
 
     if not single:
-        # where a step's time goes on every rank (HIP events on the launch stream): streaming, the part of the reduction(s) that is
-        # NOT hidden behind streaming or transforms (end of streaming -> all partial stacks reduced), the rest (finish stage incl. its
-        # own small all-reduce under sharded-finish)
-        mine = [float(np.mean([e[0].elapsed_time(e[1]) for e in ev])), float(np.mean([e[1].elapsed_time(e[2]) for e in ev])),
-                float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))]
-        if world > 1:
-            t3 = torch.tensor(mine, dtype=torch.float64, device=X.device)
-            allr = [torch.zeros_like(t3) for _ in range(world)]
-            dist.all_gather(allr, t3)
-            per_rank = [[round(float(v), 4) for v in t.tolist()] for t in allr]
-        else:
-            per_rank = [[round(v, 4) for v in mine]]
-        res["per_rank_ms"] = {"columns": ["stream", "exposed_collective", "finish"], "ranks": per_rank, "schedule": schedule if world > 1 else None}
+        res["per_rank_ms"] = {"columns": ["stream", "exposed_collective", "finish"], "ranks": rank_columns(ev), "schedule": schedule if world > 1 else None}
+    if world > 1:
+        # The driver's ONE multi-GPU run as an A/B: every schedule in the same invocation -- same plan, same traces, args.steps timed
+        # steps each between barriers.  `value` / `ms_per_step` above stay the default schedule's; `single` (north_star's wording) and
+        # `split` end in the one-GPU call's accumulation order, so their outputs are bit-identical to it (output_sha1: ls || tsPWS on rank 0).
+        legs = {}
+        for sc in ("single", "split", "sharded-finish"):
+            if sc == schedule:
+                legs[sc] = {"ms_per_step": dt / args.steps * 1e3, "value": mtr_local * world * N * args.steps / dt, "per_rank_ms": res["per_rank_ms"]["ranks"],
+                            "runs_as": schedule, "output_sha1": out_sha, "is_default": True}
+                continue
+            st2, ev2, _, eff = make_leg(sc, X, first, mtr_global)
+            d2 = time_leg(st2, min(2, max(1, args.warmup)))
+            legs[sc] = {"ms_per_step": d2 / args.steps * 1e3, "value": mtr_local * world * N * args.steps / d2, "per_rank_ms": rank_columns(ev2),
+                        "runs_as": eff, "output_sha1": digest(), "is_default": False}
+        res["schedules"] = legs
+        # Strong scaling beside the weak figures: a FIXED ensemble (BASELINE configs[4]: 100 000 traces in all) sharded over the ranks
+        total = args.strong_total if args.strong_total is not None else (100000 if (args.traces is None and args.config == "cfg3") else 0)
+        if total and total >= world:
+            lo, cnt = tspws.shard_range(total, rank, world)
+            X5 = tspws.synth(cnt, N, seed=1, first=lo, device=local)
+            st5, ev5, _, eff5 = make_leg(schedule, X5, lo, total)
+            d5 = time_leg(st5, min(2, max(1, args.warmup)))
+            res["strong_scaling"] = {"workload": f"{total} traces IN ALL x {N} samples over {world} GPUs (BASELINE configs[4] when 100 000 x 131 072), same frame and "
+                                                 f"parameters; rank r holds the contiguous shard tspws_shard_range(total, r, world)",
+                                     "traces_total": total, "traces_on_rank0": cnt if rank == 0 else None, "schedule": eff5, "ms_per_step": d5 / args.steps * 1e3,
+                                     "value": total * N * args.steps / d5, "unit": "samples/s", "scaling": "strong", "per_rank_ms": rank_columns(ev5)}
+            del X5
     if world == 1 and shard_of == 1 and rank == 0:
         res["with_output_d2h"] = with_d2h(torch, plan, X, ls, ts, N, mtr_local, args.steps)
         if not args.no_cpu:

@@ -153,8 +153,24 @@ def _bench(args, env_extra=None, timeout=600):
 def test_bench_starts_its_own_ranks():
     """`bench.py --gpus 2` without a launcher around it: the parent starts two ranks before touching the GPU (here both on the
     one GPU of the box, collectives over gloo), rank 0's JSON line comes back through the parent."""
-    r = _bench(["--gpus", "2", "--traces", "64", "--samples", "4096", "--steps", "3", "--warmup", "1"], {"BENCH_BACKEND": "gloo"})
+    r = _bench(["--gpus", "2", "--traces", "64", "--samples", "4096", "--steps", "3", "--warmup", "1", "--strong-total", "300"], {"BENCH_BACKEND": "gloo"})
     assert r["n_gpus"] == 2 and r["config"]["world_size"] == 2 and r["config"]["backend"] == "gloo"
+    # the one multi-GPU run is an A/B of the three placements of the reduction (same plan, same traces, `steps` timed steps each); the
+    # headline fields are the default schedule's; `single` -- north_star's ONE all-reduce -- ends bit-identical to the one-GPU call
+    sch = r["schedules"]
+    assert set(sch) == {"single", "split", "sharded-finish"} and sum(1 for v in sch.values() if v["is_default"]) == 1
+    for name, v in sch.items():
+        assert v["ms_per_step"] > 0 and v["value"] > 0 and len(v["per_rank_ms"]) == 2 and v["runs_as"] in ("single", "split", "sharded-finish"), name
+    assert sch["sharded-finish"]["is_default"] and abs(sch["sharded-finish"]["ms_per_step"] - r["ms_per_step"]) < 1e-9
+    import hashlib
+    import torch
+    pl = tspws.Plan(tspws.resolve(abi.default_params(Kmax=10, unbiased=1), 4096), 4096)
+    ls, ts = pl.stack(tspws.synth(128, 4096, seed=1))
+    torch.cuda.synchronize()
+    one = hashlib.sha1(ls.cpu().numpy().tobytes() + ts.cpu().numpy().tobytes()).hexdigest()[:16]
+    assert sch["single"]["output_sha1"] == one and sch["split"]["output_sha1"] == one
+    st = r["strong_scaling"]
+    assert st["traces_total"] == 300 and st["traces_on_rank0"] == 150 and st["scaling"] == "strong" and st["value"] > 0 and len(st["per_rank_ms"]) == 2
     # the N > 1 line is complete: the CPU path on rank 0's shard beside the GPU number (cores stated), the shard's partial stacks
     # checked against it, the roofline object (counter traffic null: collected on one GPU only), where every rank's step went
     for k in ("cpu_baseline", "roofline", "per_rank_ms"):
@@ -212,3 +228,28 @@ def test_mismatching_sac_file_is_skipped_like_the_reference(tmp_path, bad, field
     ts, ls = abi.read_sac(tmp_path / "ts_pws_skip.sac"), abi.read_sac(tmp_path / "tl_skip.sac")
     assert abi.relerr(ts["data"], want["tsPWS"]) < 2e-6 and abi.relerr(ls["data"], want["ls"]) < 2e-6
     assert ts["f"][40] == float(mtr)                # user0 = the trace count the reference passes on: the file count
+
+
+def test_batch_of_three_lists_equals_three_single_runs(sac_list, tmp_path):
+    """`ts_pws @batch.txt [options]` (several ensembles in one process: one HIP start-up, the frame kept per (N, options), the files of
+    ensemble i + 1 read while ensemble i is stacked): the outputs of every ensemble are BYTE for byte those of a single run with
+    osac=<tag> (the reference's naming, ts_pws1f.c:335-349) -- also for the jackknife replicas of a two-stage run."""
+    names = (sac_list / "list.txt").read_text().split()
+    lists = {"pair_a": names, "pair_b": names[:20], "pair_c": names[7:]}
+    for k, v in lists.items():
+        (tmp_path / f"{k}.txt").write_text("\n".join(v) + "\n")
+    (tmp_path / "batch.txt").write_text("pair_a.txt\npair_b.txt tagged_b\n# comment\npair_c.txt\n")
+    tags = {"pair_a": "pair_a", "pair_b": "tagged_b", "pair_c": "pair_c"}
+    for opts in (["rm"], ["TwoStage=4", "unbiased", "jackknife_n=4", "jackknife_d=1"]):
+        single, batch = tmp_path / ("single" + str(len(opts))), tmp_path / ("batch" + str(len(opts)))
+        single.mkdir(); batch.mkdir()
+        for k in lists:
+            run_cli(single, str(tmp_path / f"{k}.txt"), f"osac={tags[k]}", *opts)
+        for k in lists:   # (the batch's lists are given relative to the working directory)
+            (batch / f"{k}.txt").write_text((tmp_path / f"{k}.txt").read_text())
+        (batch / "batch.txt").write_text((tmp_path / "batch.txt").read_text())
+        run_cli(batch, "@batch.txt", *opts)
+        made = sorted(f for f in os.listdir(single) if f.endswith(".sac"))
+        assert len(made) == (2 + (8 if len(opts) > 1 else 0)) * 3, made
+        for f in made:
+            assert (single / f).read_bytes() == (batch / f).read_bytes(), f

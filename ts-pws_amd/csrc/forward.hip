@@ -792,7 +792,19 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 		// stream: it reads the traces themselves, so it starts with the transposition and runs beside the trace-lane kernel
 		hipStream_t sp = st;
 		bool poly_join = false;
-		if ((T.waves || T.gcoltiles) && dc) {
+		// order of the matrix-pipe kernel for the coarsest scales (fwd_gemm.h): 1 = on the caller's stream BEHIND the trace-lane kernel (default: the
+		// chain is the longer branch, and its transform passes are at their slowest with a second kernel beside them at the start -- 499 x 16501:
+		// 0.631 ms; 500 x 20000: 0.731), 0 = in front of the trace-lane kernel (0.662 / 0.769), 2 = on a third stream beside both (0.644 / 0.777);
+		// TSPWS_GEMM_ORDER, sweeps (tools/experiments/r6_gemm_order.sh)
+		static const int gemm_order = sweep_env("TSPWS_GEMM_ORDER") ? atoi(sweep_env("TSPWS_GEMM_ORDER")) : 1;
+		auto launch_gemm = [&](hipStream_t gs) {
+			hipLaunchKernelGGL((k_fwd_gemm<TIn>), dim3((T.gcoltiles + 3) / 4, T.gKS, nblk), dim3(256), 0, gs, (const TIn *)xT, TP, nb, p->N,
+			                   (const GemmCol *)T.d_gcols, T.gcoltiles, T.gKC, (const double2 *)p->d_w, gsum);
+			const size_t nred = (size_t)nb * T.gcoltiles * 16;
+			hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, gs, (const double2 *)gsum, TP, nb, T.gcoltiles * 16, T.gKS,
+			                   (const GemmCol *)T.d_gcols, part, T.npart);
+		};
+		if ((T.waves || (T.gcoltiles && gemm_order == 2)) && dc) {
 			// the direct kernel of a spectral decomposition: the scales whose filters are too long for the transform window (N not a power of two:
 			// the clipped scales of the shipped example's frame, ~9 % of its FIR work) or middle octaves that fit neither the trace-lane kernel nor
 			// the set.  It reads the traces themselves: a third stream, forked here, joined before the accumulation -- beside the chain and
@@ -830,26 +842,21 @@ static int stacks_tl(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t ld, d
 		else hipLaunchKernelGGL((k_transpose_traces<TIn>), dim3((p->N + 63) / 64, nblk), dim3(256), 0, st, xb, ld, nb, p->N, TP, xT);
 		// the spectral chain (transforms through HBM / MALL: bandwidth-bound) beside the trace-lane kernel (FP64-bound) on the side stream
 		static const bool spec_serial = sweep_env("TSPWS_SPEC_SERIAL") != nullptr; // sweeps: one after the other
-		if (dc && ((T.n && !spec_serial) || T.gcoltiles)) {
+		if (dc && ((T.n && !spec_serial) || (T.gcoltiles && gemm_order == 2))) {
 			const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
 			if (!p->side) HIP_TRY(tspws_side_stream(p));
 			if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, evf));
 			if (!p->ev_join) HIP_TRY(hipEventCreateWithFlags(&p->ev_join, evf));
 			HIP_TRY(hipEventRecord(p->ev_fork, st)); // (after the transposition)
 			if (T.n && !spec_serial) { HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0)); sp = p->side; }
-			if (T.gcoltiles) { // the coarsest scales on the matrix pipe (fwd_gemm.h): the third stream, behind the transposition
-				HIP_TRY(hipStreamWaitEvent(p->xs, p->ev_fork, 0));
-				hipLaunchKernelGGL((k_fwd_gemm<TIn>), dim3((T.gcoltiles + 3) / 4, T.gKS, nblk), dim3(256), 0, p->xs, (const TIn *)xT, TP, nb, p->N,
-				                   (const GemmCol *)T.d_gcols, T.gcoltiles, T.gKC, (const double2 *)p->d_w, gsum);
-				const size_t nred = (size_t)nb * T.gcoltiles * 16;
-				hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, p->xs, (const double2 *)gsum, TP, nb, T.gcoltiles * 16, T.gKS,
-				                   (const GemmCol *)T.d_gcols, part, T.npart);
-			}
+			if (T.gcoltiles && gemm_order == 2) { HIP_TRY(hipStreamWaitEvent(p->xs, p->ev_fork, 0)); launch_gemm(p->xs); }
 		}
+		if (T.gcoltiles && gemm_order == 0) launch_gemm(st);
 		if (dc && (rc = spectral_run_t(p, dc, (const TIn *)xT, TP, nb, planes, planes + p->ncoef, 2 * p->ncoef, nullptr, dc && T.n && !spec_serial ? sp : st))) return rc;
 		if (T.n)
 			hipLaunchKernelGGL((k_fwd_tl<TIn>), dim3(T.wgs, nblk), dim3(TL_NT), T.lds, st, (const TIn *)xT, TP, nb, p->N, T.d_items, T.n, p->d_w,
 			                   planes, planes + p->ncoef, 2 * p->ncoef, part, T.npart);
+		if (T.gcoltiles && gemm_order == 1) launch_gemm(st);
 		if (sp != st) {
 			HIP_TRY(hipEventRecord(p->ev_join, sp));
 			HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));

@@ -8,12 +8,21 @@
  * The stacking itself is tspws_main() from libtspws_hip.so.  SAC I/O is this repo's own minimal
  * implementation (sacio_min.c) because SAC's sacio.a is not available.
  *
- * Extension over the reference: when reading a SAC list, each trace's start time is taken from the SAC
- * reference time (nzyear/nzjday/...), so the jackknife also works without an msacs file (the reference
- * leaves `time` zero there and runs on uninitialised masks).
+ * Extensions over the reference:
+ *  - when reading a SAC list, each trace's start time is taken from the SAC reference time (nzyear/nzjday/...), so the
+ *    jackknife also works without an msacs file (the reference leaves `time` zero there and runs on uninitialised masks);
+ *  - `ts_pws @batch.txt [options]`: SEVERAL ensembles in one process.  Every line of batch.txt is `<filelist> [tag]`; ensemble
+ *    i is stacked with the same options and its outputs are named as a single run with `osac=<tag>` names them (:335-349;
+ *    tag defaults to the list's base name without extension).  One HIP start-up (~0.25 s, most of a one-call process), one
+ *    frame per (N, options) kept by tspws_main, and the files of ensemble i + 1 are read by a second thread while ensemble i
+ *    is stacked -- the paper's workload is tens of station pairs per run.
+ * A malformed input (missing / truncated SAC file, npts <= 0, a `bin` file whose header is short or promises more traces
+ * than the file could hold) ends the ensemble with the reference's message and a non-zero status, every buffer freed.
  */
 #include <ctype.h>
+#include <limits.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -56,8 +65,9 @@ static unsigned binomial(unsigned n, unsigned d)
 static void usage(void)
 {
 	puts("\nTime-scale phase-weighted stack (ts-PWS) on AMD MI355X -- drop-in for ts_pws (Ventosa et al., GJI 2017).\n"
-	     "USAGE: ts_pws filelist [options]\n"
+	     "USAGE: ts_pws filelist [options]      |      ts_pws @batch [options]\n"
 	     "  filelist           text file with one SAC file per line (or an msacs binary with `bin`)\n"
+	     "  @batch             text file with one `filelist [tag]` per line: every ensemble with the same options, outputs as osac=tag\n"
 	     "  wu=2               phase-weight power            J= V= s0= b0= fmin=   frame sampling\n"
 	     "  Q= | cycles= | cyc= | w0=   Morlet shape         MexHat   complex Mexican-hat frame\n"
 	     "  rm  fold  uni  verbose  unbiased                 TwoStage[=10]   two-stage stack\n"
@@ -88,13 +98,26 @@ static char **read_list(const char *path, unsigned *n_out)
 	return v;
 }
 
+static void free_list(char **v, unsigned n)
+{
+	if (!v) return;
+	for (unsigned i = 0; i < n; i++) free(v[i]);
+	free(v);
+}
+
+static void free_data(t_data *in)
+{
+	free(in->sigall); free(in->time); free(in->lag0); free(in->reference);
+	in->sigall = NULL; in->time = NULL; in->lag0 = NULL; in->reference = NULL;
+}
+
 static void trim_copy(char dst[9], const char *src8)
 {
 	memcpy(dst, src8, 8);
 	dst[8] = '\0';
 }
 
-/* reference: ReadData, ts_pws1f.c:570-723 */
+/* reference: ReadData, ts_pws1f.c:570-723.  On a non-zero return nothing is left allocated in *in. */
 static int read_data(t_data *in, const char *filein, int bin, int verbose)
 {
 	t_hdr *hdr = &in->hdr;
@@ -102,7 +125,21 @@ static int read_data(t_data *in, const char *filein, int bin, int verbose)
 		FILE *f = fopen(filein, "rb");
 		if (!f) { printf("tspws_main: cannot open the %s file\n", filein); return -2; }
 		msacs_header b;
-		if (fread(&b, sizeof b, 1, f) != 1) printf("tspws_main: %s is shorter than predicted (header).\n", filein);
+		/* (the reference prints this and carries on with an uninitialised header, ts_pws1f.c:587-589: nothing useful can follow) */
+		if (fread(&b, sizeof b, 1, f) != 1) { printf("tspws_main: %s is shorter than predicted (header).\n", filein); fclose(f); return -2; }
+		long fsize = -1;
+		if (!fseek(f, 0, SEEK_END)) fsize = ftell(f);
+		if (fsize < 0 || fseek(f, (long)sizeof b, SEEK_SET)) { printf("tspws_main: cannot size the %s file\n", filein); fclose(f); return -2; }
+		/* header sanity before anything is sized from it (the reference's check_header only looks at the text fields, :606): at least two
+		 * lags (dt divides by nlags - 1, :597), sample count within int (hdr->max is one), and the file must at least hold the time and
+		 * lag0 tables and ONE whole trace -- a file cut inside the data block still reads like the reference's (warning, zeros behind) */
+		const unsigned long long nl = b.nlags, ns = b.nseq;
+		const unsigned long long tables = ns * (unsigned long long)(sizeof(time_t) + sizeof(float));
+		if (nl < 2 || nl > (unsigned long long)INT_MAX || (ns && (ns > (1ull << 31) || (unsigned long long)fsize < sizeof b + tables + nl * sizeof(float)))) {
+			printf("\a ReadData: Found the header corrupted when reading the %s file (nlags = %u, nseq = %u, %ld bytes)\n", filein, b.nlags, b.nseq, fsize);
+			fclose(f);
+			return 2;
+		}
 		hdr->max = (int)b.nlags; hdr->mtr = b.nseq;
 		hdr->evla = b.stlat1; hdr->evlo = b.stlon1; hdr->stla = b.stlat2; hdr->stlo = b.stlon2; hdr->stel = b.stel2;
 		hdr->dt = (b.lag2 - b.lag1) / (float)(b.nlags - 1);
@@ -113,7 +150,7 @@ static int read_data(t_data *in, const char *filein, int bin, int verbose)
 		in->sigall = (float *)calloc((mtr * max) > 0 ? mtr * max : 1, sizeof(float));
 		in->time = (time_t *)calloc(mtr ? mtr : 1, sizeof(time_t));
 		in->lag0 = (float *)calloc(mtr ? mtr : 1, sizeof(float));
-		if (!in->sigall || !in->time || !in->lag0) { fclose(f); return 4; }
+		if (!in->sigall || !in->time || !in->lag0) { fclose(f); free_data(in); return 4; }
 		if (fread(in->time, sizeof(time_t), mtr, f) != mtr) printf("tspws_main: %s is shorter than predicted (time).\n", filein);
 		if (fread(in->lag0, sizeof(float), mtr, f) != mtr) printf("tspws_main: %s is shorter than predicted (lag0).\n", filein);
 		if (fread(in->sigall, sizeof(float), mtr * max, f) != mtr * max) printf("tspws_main: %s is shorter than predicted (data).\n", filein);
@@ -126,9 +163,10 @@ static int read_data(t_data *in, const char *filein, int bin, int verbose)
 	if (!nfiles) { printf("tspws_main: nothing to do, %s is empty!\n", filein); free(files); hdr->mtr = 0; return 0; }
 	sac_header h;
 	int npts = 0, rc = sac_read(files[0], &h, NULL, 0, &npts);
-	if (rc) { printf("\a tspws_main: Error reading %s header (nerr=%d).\n", files[0], rc); return 2; }
+	if (rc) { printf("\a tspws_main: Error reading %s header (nerr=%d).\n", files[0], rc); free_list(files, nfiles); return 2; }
 	if (h.f[SAC_F_DELTA] == SAC_UNDEF_F || h.f[SAC_F_B] == SAC_UNDEF_F || npts <= 0) {
 		printf("\a tspws_main: Error reading %s header, npts/delta/b is not defined!\n", files[0]);
+		free_list(files, nfiles);
 		return 2;
 	}
 	hdr->max = npts; hdr->mtr = nfiles;
@@ -147,6 +185,7 @@ static int read_data(t_data *in, const char *filein, int bin, int verbose)
 	in->lag0 = (float *)calloc(nfiles, sizeof(float));
 	if (!in->sigall || !in->time || !in->lag0) {
 		printf("tspws_main: Out of memory when reading %s (mtr = %u, npts = %d)\n", filein, nfiles, npts);
+		free_list(files, nfiles); free_data(in);
 		return 4;
 	}
 	/* The reference's reader, literally (ts_pws1f.c:680-708): trace i is read into slot i - nskip; a trace whose dt differs by more
@@ -160,7 +199,7 @@ static int read_data(t_data *in, const char *filein, int bin, int verbose)
 		float *dst = in->sigall + (size_t)(i - nskip) * max;
 		int n = 0;
 		rc = sac_read(files[i], &h, dst, npts, &n);
-		if (rc) { printf("tspws_main: Error reading %s file (nerr=%d)\n", files[i], rc); return -2; }
+		if (rc) { printf("tspws_main: Error reading %s file (nerr=%d)\n", files[i], rc); free_list(files, nfiles); free_data(in); return -2; }
 		if (n > npts) printf("tspws_main: WARNING: using only %d samples on %u trace\n", npts, i);
 		else if (n < npts) printf("tspws_main: WARNING: trace %u has only %d samples\n", i, n);
 		if (fabs(h.f[SAC_F_DELTA] - dt1) > dt1 * 0.01) { /* :695-700 */
@@ -181,8 +220,7 @@ static int read_data(t_data *in, const char *filein, int bin, int verbose)
 		printf("ts_pws: %u of %u traces skipped (dt / b mismatch): the stack keeps %u rows like the reference's reader (ts_pws1f.c:680-708) -- %u accepted "
 		       "traces in front, the rest as the skipping left them (zero rows, or a mismatched LAST trace still in its slot); ls is divided by %u\n",
 		       nskip, nfiles, nfiles, kept, nfiles);
-	for (unsigned i = 0; i < nfiles; i++) free(files[i]);
-	free(files);
+	free_list(files, nfiles);
 	for (unsigned i = 0; i < kept; i++) {
 		const float *x = in->sigall + (size_t)i * max;
 		size_t n = 0;
@@ -249,84 +287,48 @@ static double now_s(void)
 	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-int main(int argc, char *argv[])
+static void free_out(t_tsPWS_out *out)
 {
-	const double t_start = now_s();
-	/* defaults of the reference, ts_pws1f.c:140-142 */
-	t_tsPWS p;
-	memset(&p, 0, sizeof p);
-	p.type = -1; p.V = 4; p.s0 = 2.; p.b0 = 1.0; p.w0 = PI * sqrt(2 / log(2)); p.wu = 2.; p.cycle = 2.;
-	if (argc == 1) { usage(); return 0; }
-	p.filein = argv[1];
-	if (starts(p.filein, "info")) { usage(); return 0; }
+	if (out->ls_subsmpl) free(out->ls_subsmpl[0]);
+	if (out->tsPWS_subsmpl) free(out->tsPWS_subsmpl[0]);
+	free(out->ls_subsmpl); free(out->tsPWS_subsmpl); free(out->mtr_subsmpl);
+	free(out->ls); free(out->tsPWS);
+	free(out->ls_sim); free(out->tsPWS_sim); free(out->ls_misfit); free(out->tsPWS_misfit); free(out->ls_steps); free(out->tsPWS_steps);
+	memset(out, 0, sizeof *out);
+}
 
-	for (int i = 2; i < argc; i++) {
-		const char *a = argv[i];
-		if (starts(a, "wu=")) rd_double(&p.wu, a + 3);
-		else if (starts(a, "J=")) rd_uint(&p.J, a + 2);
-		else if (starts(a, "Nmax=")) rd_uint(&p.Nmax, a + 5);
-		else if (starts(a, "fmin=")) rd_double(&p.fmin, a + 5);
-		else if (starts(a, "V=")) { rd_uint(&p.V, a + 2); p.lVfix = 1; }
-		else if (starts(a, "s0=")) { rd_double(&p.s0, a + 3); p.ls0fix = 1; }
-		else if (starts(a, "b0=")) { rd_double(&p.b0, a + 3); p.lb0fix = 1; }
-		else if (starts(a, "uni")) p.uni = 1;
-		else if (starts(a, "rm")) p.lrm = 1;
-		else if (starts(a, "bin")) p.bin = 1;
-		else if (starts(a, "verbose")) p.verbose = 1;
-		else if (starts(a, "fold")) p.fold = 1;
-		else if (starts(a, "unbiased")) p.unbiased = 1;
-		else if (starts(a, "MexHat")) p.type = -3;
-		else if (starts(a, "AllSteps")) p.AllSteps = 1;
-		else if (starts(a, "subsmpl_N=")) rd_uint(&p.subsmpl_N, a + 10);
-		else if (starts(a, "subsmpl_prob=")) rd_double(&p.subsmpl_p, a + 13);
-		else if (starts(a, "jackknife_n=")) rd_uint(&p.jackknife_n, a + 12);
-		else if (starts(a, "jackknife_d=")) rd_uint(&p.jackknife_d, a + 12);
-		else if (starts(a, "obin")) p.obin = 1;
-		else if (starts(a, "TwoStage")) { p.Kmax = 10; if (starts(a, "TwoStage=")) rd_uint(&p.Kmax, a + 9); }
-		else if (starts(a, "convergence")) { p.convergence = 1; if (starts(a, "convergence=")) p.fileconv = argv[i] + 12; }
-		else if (starts(a, "Q=")) { rd_double(&p.Q, a + 2); if (p.w0set < 1) p.w0set = 1; }
-		else if (starts(a, "cycles=")) { rd_double(&p.cycle, a + 7); if (p.w0set < 2) p.w0set = 2; }
-		else if (starts(a, "cyc=")) { if (p.w0set < 3) { p.w0set = 3; rd_double(&p.w0, a + 4); p.w0 *= PI; } }
-		else if (starts(a, "w0=")) { rd_double(&p.w0, a + 3); if (p.w0set < 4) p.w0set = 4; }
-		else if (starts(a, "osac=")) { p.fileout = argv[i] + 5; if (!strlen(p.fileout)) p.fileout = NULL; }
-		else if (starts(a, "kinst=")) { p.kinst = argv[i] + 6; p.lkinst = 1; }
-		else if (starts(a, "info")) { usage(); return 0; }
-	}
-
-	t_data in;
-	memset(&in, 0, sizeof in);
-	int er = read_data(&in, p.filein, p.bin, p.verbose);
-	if (er) return er;
-	const double t_read = now_s();
-	if (!in.hdr.mtr) return 0;
-
+/* One ensemble, already read: set-up of the outputs (ts_pws1f.c:229-280), tspws_main, output files (:313-428).  p is this ensemble's own
+ * copy of the parsed options (tspws_main rewrites fold / fmin / w0 / V / b0 / s0 / J); frees *in. */
+static int run_ensemble(t_tsPWS p, t_data *in, double t_start, double t_read)
+{
 	t_tsPWS_out out;
 	memset(&out, 0, sizeof out);
-	const size_t max = (size_t)in.hdr.max;
+	int er = 0;
+	const size_t max = (size_t)in->hdr.max;
 	out.N = (unsigned)max;
 	/* the reference takes Nmax unchecked (:65); tspws_main clamps it to the traces read, so every size derived from it
 	   (convergence dumps, the user0 header field) uses the clamped count too */
-	out.mtr = (p.Nmax && p.Nmax < in.hdr.mtr) ? p.Nmax : in.hdr.mtr;
+	out.mtr = (p.Nmax && p.Nmax < in->hdr.mtr) ? p.Nmax : in->hdr.mtr;
 	out.ls = (float *)calloc(max, sizeof(float));
 	out.tsPWS = (float *)calloc(max, sizeof(float));
-	if (!out.ls || !out.tsPWS) { printf("main: Out of memory\n"); return 4; }
+	if (!out.ls || !out.tsPWS) { printf("main: Out of memory\n"); er = 4; goto done; }
 	if (p.convergence && p.fileconv) { /* alternative reference trace, :287-305 */
 		sac_header rh;
 		int rn = 0;
-		in.reference = (float *)calloc(max, sizeof(float));
-		if (!in.reference || sac_read(p.fileconv, &rh, in.reference, (int)max, &rn) || rn != (int)max) {
-			if (in.reference && rn != (int)max) printf("The reference for convergence has a different length (%d:%d)\n", (int)max, rn);
-			free(in.reference); in.reference = NULL; p.fileconv = NULL;
+		in->reference = (float *)calloc(max, sizeof(float));
+		if (!in->reference || sac_read(p.fileconv, &rh, in->reference, (int)max, &rn) || rn != (int)max) {
+			if (in->reference && rn != (int)max) printf("The reference for convergence has a different length (%d:%d)\n", (int)max, rn);
+			free(in->reference); in->reference = NULL; p.fileconv = NULL;
 		}
 	}
 	if (p.convergence) { /* :233-243 */
 		out.ls_sim = (double *)calloc(out.mtr, sizeof(double)); out.tsPWS_sim = (double *)calloc(out.mtr, sizeof(double));
 		out.ls_misfit = (double *)calloc(out.mtr, sizeof(double)); out.tsPWS_misfit = (double *)calloc(out.mtr, sizeof(double));
-		if (!out.ls_sim || !out.tsPWS_sim || !out.ls_misfit || !out.tsPWS_misfit) { printf("main: Out of memory\n"); return 4; }
+		if (!out.ls_sim || !out.tsPWS_sim || !out.ls_misfit || !out.tsPWS_misfit) { printf("main: Out of memory\n"); er = 4; goto done; }
 		if (p.AllSteps) {
 			out.ls_steps = (float *)calloc((size_t)out.mtr * max, sizeof(float));
 			out.tsPWS_steps = (float *)calloc((size_t)out.mtr * max, sizeof(float));
-			if (!out.ls_steps || !out.tsPWS_steps) { printf("main: Out of memory\n"); return 4; }
+			if (!out.ls_steps || !out.tsPWS_steps) { printf("main: Out of memory\n"); er = 4; goto done; }
 		}
 	}
 	if (p.jackknife_n) { /* :247-252 */
@@ -343,14 +345,14 @@ int main(int argc, char *argv[])
 		out.ls_subsmpl = (float **)calloc(out.M, sizeof(float *));
 		out.tsPWS_subsmpl = (float **)calloc(out.M, sizeof(float *));
 		float *a = (float *)calloc((size_t)out.M * max, sizeof(float)), *b = (float *)calloc((size_t)out.M * max, sizeof(float));
-		if (!out.mtr_subsmpl || !out.ls_subsmpl || !out.tsPWS_subsmpl || !a || !b) { printf("main: Out of memory\n"); return 4; }
+		if (!out.mtr_subsmpl || !out.ls_subsmpl || !out.tsPWS_subsmpl || !a || !b) { printf("main: Out of memory\n"); free(a); free(b); er = 4; goto done; }
 		for (unsigned m = 0; m < out.M; m++) { out.ls_subsmpl[m] = a + (size_t)m * max; out.tsPWS_subsmpl[m] = b + (size_t)m * max; }
 	}
 
 	if (p.subsmpl_N) for (unsigned i = 1; i < out.M; i++) out.mtr_subsmpl[i] = (unsigned)(out.mtr * p.subsmpl_p); /* :277 (entry 0 stays 0) */
 
 	const double t_call0 = now_s();
-	er = tspws_main(&p, &out, &in);
+	er = tspws_main(&p, &out, in);
 	const double t_call1 = now_s();
 	(void)t_start; (void)t_read; (void)t_call0; (void)t_call1;
 #ifdef TSPWS_SWEEPS
@@ -358,7 +360,7 @@ int main(int argc, char *argv[])
 #endif
 
 	if (!er) {
-		t_hdr hdr = in.hdr;
+		t_hdr hdr = in->hdr;
 		unsigned first = 0;
 		if (p.fold) { /* :322-328 */
 			if (2 * hdr.beg + (hdr.max - 1) * hdr.dt < 0.5 * hdr.dt) {
@@ -406,10 +408,147 @@ int main(int argc, char *argv[])
 				}
 		}
 	}
-	if (out.ls_subsmpl) { free(out.ls_subsmpl[0]); free(out.tsPWS_subsmpl[0]); }
-	free(out.ls_subsmpl); free(out.tsPWS_subsmpl); free(out.mtr_subsmpl);
-	free(out.ls); free(out.tsPWS);
-	free(out.ls_sim); free(out.tsPWS_sim); free(out.ls_misfit); free(out.tsPWS_misfit); free(out.ls_steps); free(out.tsPWS_steps);
-	free(in.sigall); free(in.time); free(in.lag0); free(in.reference);
+done:
+	free_out(&out);
+	free_data(in);
 	return er; /* the reference returns 0 even when tspws_main failed (:430); a non-zero status is more useful */
+}
+
+/* ---- several ensembles in one process: `ts_pws @batch.txt [options]` ----------------------------------------------- */
+typedef struct { char *list, *tag; } batch_job;
+
+/* lines `<filelist> [tag]`; tag defaults to the list's base name without its extension */
+static batch_job *read_batch(const char *path, unsigned *n_out)
+{
+	unsigned nl = 0;
+	char **lines = read_list(path, &nl);
+	if (!lines) return NULL;
+	batch_job *jobs = (batch_job *)calloc(nl ? nl : 1, sizeof *jobs);
+	unsigned n = 0;
+	for (unsigned i = 0; jobs && i < nl; i++) {
+		char *l = lines[i];
+		while (*l == ' ' || *l == '\t') l++;
+		if (!*l || *l == '#') continue;
+		char *e = l;
+		while (*e && *e != ' ' && *e != '\t') e++;
+		char *t = e;
+		while (*t == ' ' || *t == '\t') t++;
+		if (*e) *e = '\0';
+		char *te = t;
+		while (*te && *te != ' ' && *te != '\t') te++;
+		*te = '\0';
+		jobs[n].list = strdup(l);
+		if (*t) jobs[n].tag = strdup(t);
+		else {
+			const char *b = strrchr(l, '/');
+			b = b ? b + 1 : l;
+			jobs[n].tag = strdup(b);
+			char *dot = jobs[n].tag ? strrchr(jobs[n].tag, '.') : NULL;
+			if (dot && dot != jobs[n].tag) *dot = '\0';
+		}
+		if (!jobs[n].list || !jobs[n].tag) { free(jobs[n].list); free(jobs[n].tag); break; }
+		n++;
+	}
+	free_list(lines, nl);
+	*n_out = n;
+	return jobs;
+}
+
+typedef struct { t_data in; const char *list; int bin, verbose, rc; double t0, t1; } read_task;
+static void *read_thread(void *arg)
+{
+	read_task *t = (read_task *)arg;
+	t->t0 = now_s();
+	t->rc = read_data(&t->in, t->list, t->bin, t->verbose);
+	t->t1 = now_s();
+	return NULL;
+}
+
+int main(int argc, char *argv[])
+{
+	const double t_start = now_s();
+	/* defaults of the reference, ts_pws1f.c:140-142 */
+	t_tsPWS p;
+	memset(&p, 0, sizeof p);
+	p.type = -1; p.V = 4; p.s0 = 2.; p.b0 = 1.0; p.w0 = PI * sqrt(2 / log(2)); p.wu = 2.; p.cycle = 2.;
+	if (argc == 1) { usage(); return 0; }
+	p.filein = argv[1];
+	if (starts(p.filein, "info")) { usage(); return 0; }
+
+	for (int i = 2; i < argc; i++) {
+		const char *a = argv[i];
+		if (starts(a, "wu=")) rd_double(&p.wu, a + 3);
+		else if (starts(a, "J=")) rd_uint(&p.J, a + 2);
+		else if (starts(a, "Nmax=")) rd_uint(&p.Nmax, a + 5);
+		else if (starts(a, "fmin=")) rd_double(&p.fmin, a + 5);
+		else if (starts(a, "V=")) { rd_uint(&p.V, a + 2); p.lVfix = 1; }
+		else if (starts(a, "s0=")) { rd_double(&p.s0, a + 3); p.ls0fix = 1; }
+		else if (starts(a, "b0=")) { rd_double(&p.b0, a + 3); p.lb0fix = 1; }
+		else if (starts(a, "uni")) p.uni = 1;
+		else if (starts(a, "rm")) p.lrm = 1;
+		else if (starts(a, "bin")) p.bin = 1;
+		else if (starts(a, "verbose")) p.verbose = 1;
+		else if (starts(a, "fold")) p.fold = 1;
+		else if (starts(a, "unbiased")) p.unbiased = 1;
+		else if (starts(a, "MexHat")) p.type = -3;
+		else if (starts(a, "AllSteps")) p.AllSteps = 1;
+		else if (starts(a, "subsmpl_N=")) rd_uint(&p.subsmpl_N, a + 10);
+		else if (starts(a, "subsmpl_prob=")) rd_double(&p.subsmpl_p, a + 13);
+		else if (starts(a, "jackknife_n=")) rd_uint(&p.jackknife_n, a + 12);
+		else if (starts(a, "jackknife_d=")) rd_uint(&p.jackknife_d, a + 12);
+		else if (starts(a, "obin")) p.obin = 1;
+		else if (starts(a, "TwoStage")) { p.Kmax = 10; if (starts(a, "TwoStage=")) rd_uint(&p.Kmax, a + 9); }
+		else if (starts(a, "convergence")) { p.convergence = 1; if (starts(a, "convergence=")) p.fileconv = argv[i] + 12; }
+		else if (starts(a, "Q=")) { rd_double(&p.Q, a + 2); if (p.w0set < 1) p.w0set = 1; }
+		else if (starts(a, "cycles=")) { rd_double(&p.cycle, a + 7); if (p.w0set < 2) p.w0set = 2; }
+		else if (starts(a, "cyc=")) { if (p.w0set < 3) { p.w0set = 3; rd_double(&p.w0, a + 4); p.w0 *= PI; } }
+		else if (starts(a, "w0=")) { rd_double(&p.w0, a + 3); if (p.w0set < 4) p.w0set = 4; }
+		else if (starts(a, "osac=")) { p.fileout = argv[i] + 5; if (!strlen(p.fileout)) p.fileout = NULL; }
+		else if (starts(a, "kinst=")) { p.kinst = argv[i] + 6; p.lkinst = 1; }
+		else if (starts(a, "info")) { usage(); return 0; }
+	}
+
+	if (p.filein[0] != '@') { /* the reference's command line: one ensemble */
+		t_data in;
+		memset(&in, 0, sizeof in);
+		int er = read_data(&in, p.filein, p.bin, p.verbose);
+		if (er) return er;
+		const double t_read = now_s();
+		if (!in.hdr.mtr) { free_data(&in); return 0; }
+		return run_ensemble(p, &in, t_start, t_read);
+	}
+
+	/* several ensembles: the files of ensemble i + 1 are read while ensemble i is stacked */
+	unsigned njobs = 0;
+	batch_job *jobs = read_batch(p.filein + 1, &njobs);
+	if (!jobs) { printf("tspws_main: cannot read the %s file\n", p.filein + 1); return -2; }
+	int worst = 0;
+	read_task cur, nxt;
+	memset(&cur, 0, sizeof cur);
+	if (njobs) { cur.list = jobs[0].list; cur.bin = p.bin; cur.verbose = p.verbose; read_thread(&cur); }
+	for (unsigned j = 0; j < njobs; j++) {
+		pthread_t th;
+		int have_next = 0;
+		if (j + 1 < njobs) {
+			memset(&nxt, 0, sizeof nxt);
+			nxt.list = jobs[j + 1].list; nxt.bin = p.bin; nxt.verbose = p.verbose;
+			have_next = !pthread_create(&th, NULL, read_thread, &nxt);
+			if (!have_next) read_thread(&nxt); /* (no thread: read it here) */
+		}
+		int er = cur.rc;
+		if (!er && cur.in.hdr.mtr) {
+			t_tsPWS q = p;
+			q.filein = jobs[j].list;
+			q.fileout = jobs[j].tag;
+			er = run_ensemble(q, &cur.in, cur.t0, cur.t1);
+		} else free_data(&cur.in);
+		if (er) { printf("ts_pws: ensemble %u (%s) ended with status %d\n", j, jobs[j].list, er); if (!worst) worst = er; }
+		if (j + 1 < njobs) {
+			if (have_next) pthread_join(th, NULL);
+			cur = nxt;
+		}
+	}
+	for (unsigned j = 0; j < njobs; j++) { free(jobs[j].list); free(jobs[j].tag); }
+	free(jobs);
+	return worst;
 }
