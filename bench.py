@@ -46,8 +46,8 @@ def parse():
     ap.add_argument("--kmax", type=int, default=10)
     ap.add_argument("--schedule", choices=["single", "split", "sharded-finish"], default=None,
                     help="N > 1: placement of the one logical reduction of P[K][N] (ts-pws_amd.stack_sharded): single = ONE all-reduce + redundant "
-                         "finish (north_star's wording), split = two halves overlapped with streaming / transforms, sharded-finish (default) = "
-                         "pieces K-2 | 2 + scale-sharded finish")
+                         "finish (north_star's wording; default), split = two halves overlapped with streaming / transforms, sharded-finish = "
+                         "pieces K-2 | 2 + scale-sharded finish; the other two are timed in the same run as well (`schedules`)")
     ap.add_argument("--shard-of", type=int, default=None,
                     help="one GPU only: treat the traces as rank 0's shard of an ensemble this many times larger (cfg5 on one GPU: 12 500 of 100 000; "
                          "default 8 for --config cfg5 --gpus 1, else 1)")
@@ -55,6 +55,8 @@ def parse():
                     help="N > 1: after the weak-scaling legs, one more leg with this many traces IN ALL, sharded over the ranks (strong scaling; default "
                          "100 000 = BASELINE configs[4] when the per-GPU size is the default one, else off; 0: off)")
     ap.add_argument("--collective-timeout", type=int, default=180, help="N > 1: seconds after which a hung collective fails the run")
+    ap.add_argument("--leg-deadline", type=int, default=60,
+                    help="N > 1: seconds an A/B leg (another schedule, the strong-scaling leg) may take before rank 0 prints the line it has and every rank exits")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline, host-path and other-config legs")
     ap.add_argument("--no-extra", action="store_true", help="skip the host-path and other-config legs only")
     return ap.parse_args()
@@ -136,7 +138,10 @@ def run(args):
     assert shard_of == 1 or world == 1, "--shard-of is the one-GPU stand-in for a shard of a larger ensemble"
     mtr_global = mtr_local * world * shard_of
     first = rank * mtr_local
-    schedule = args.schedule or os.environ.get("TSPWS_SCHEDULE") or "sharded-finish"
+    # default placement of the reduction: north_star's wording -- ONE all-reduce between the halves.  The other two placements are timed in
+    # the same run (`schedules`), each under a deadline, so that the first run on real xGMI links A/Bs them without betting the headline
+    # on a collective sequence that has only ever run over gloo / with one RCCL rank
+    schedule = args.schedule or os.environ.get("TSPWS_SCHEDULE") or "single"
     params = tspws.resolve(abi.default_params(Kmax=K, unbiased=1), N)
     t_plan = time.perf_counter()
     plan = tspws.Plan(params, N, device=local)  # frame geometry + tap generation on the device (outside the timed region)
@@ -335,32 +340,63 @@ def run(args):
 
     if not single:
         res["per_rank_ms"] = {"columns": ["stream", "exposed_collective", "finish"], "ranks": rank_columns(ev), "schedule": schedule if world > 1 else None}
+    if world > 1 and rank == 0 and not args.no_cpu:
+        # N > 1: the reference OpenMP path on THIS node's host cores beside the N-GPU number, in the same run (north_star): rank 0
+        # runs it on its own shard after the timed loop (the other ranks wait in the barrier below), and checks its shard-local
+        # partial stacks -- global group index, before any reduction -- against direct FP64 sums of the same traces
+        res["cpu_baseline"] = cpu_baseline_shard(abi, plan, X, abi.default_params(Kmax=K, unbiased=1), N, K, mtr_local, first, mtr_global, red)
     if world > 1:
         # The driver's ONE multi-GPU run as an A/B: every schedule in the same invocation -- same plan, same traces, args.steps timed
         # steps each between barriers.  `value` / `ms_per_step` above stay the default schedule's; `single` (north_star's wording) and
         # `split` end in the one-GPU call's accumulation order, so their outputs are bit-identical to it (output_sha1: ls || tsPWS on rank 0).
         legs = {}
+        res["schedules"] = legs
+
+        class Deadline:
+            """An optional leg must not cost the run its headline: when it overruns (a hung collective blocks in synchronize, which releases
+            the GIL), rank 0 prints the line measured so far with the leg named, and every rank leaves with status 0."""
+            def __init__(self, label):
+                import threading
+                self.label = label
+                self.t = threading.Timer(max(5, args.leg_deadline), self.bail)
+                self.t.daemon = True
+            def bail(self):
+                if rank == 0:
+                    res["aborted_leg"] = {"leg": self.label, "deadline_s": args.leg_deadline}
+                    sys.stdout.write(json.dumps(res) + "\n")
+                    sys.stdout.flush()
+                os._exit(0)
+            def __enter__(self):
+                self.t.start()
+                return self
+            def __exit__(self, *a):
+                self.t.cancel()
+                return False
+
         for sc in ("single", "split", "sharded-finish"):
             if sc == schedule:
                 legs[sc] = {"ms_per_step": dt / args.steps * 1e3, "value": mtr_local * world * N * args.steps / dt, "per_rank_ms": res["per_rank_ms"]["ranks"],
                             "runs_as": schedule, "output_sha1": out_sha, "is_default": True}
                 continue
-            st2, ev2, _, eff = make_leg(sc, X, first, mtr_global)
-            d2 = time_leg(st2, min(2, max(1, args.warmup)))
-            legs[sc] = {"ms_per_step": d2 / args.steps * 1e3, "value": mtr_local * world * N * args.steps / d2, "per_rank_ms": rank_columns(ev2),
-                        "runs_as": eff, "output_sha1": digest(), "is_default": False}
-        res["schedules"] = legs
+            with Deadline(f"schedule {sc}"):
+                st2, ev2, _, eff = make_leg(sc, X, first, mtr_global)
+                d2 = time_leg(st2, min(2, max(1, args.warmup)))
+                cols2, sha2 = rank_columns(ev2), digest()
+            legs[sc] = {"ms_per_step": d2 / args.steps * 1e3, "value": mtr_local * world * N * args.steps / d2, "per_rank_ms": cols2,
+                        "runs_as": eff, "output_sha1": sha2, "is_default": False}
         # Strong scaling beside the weak figures: a FIXED ensemble (BASELINE configs[4]: 100 000 traces in all) sharded over the ranks
         total = args.strong_total if args.strong_total is not None else (100000 if (args.traces is None and args.config == "cfg3") else 0)
         if total and total >= world:
             lo, cnt = tspws.shard_range(total, rank, world)
-            X5 = tspws.synth(cnt, N, seed=1, first=lo, device=local)
-            st5, ev5, _, eff5 = make_leg(schedule, X5, lo, total)
-            d5 = time_leg(st5, min(2, max(1, args.warmup)))
+            with Deadline("strong scaling"):
+                X5 = tspws.synth(cnt, N, seed=1, first=lo, device=local)
+                st5, ev5, _, eff5 = make_leg(schedule, X5, lo, total)
+                d5 = time_leg(st5, min(2, max(1, args.warmup)))
+                cols5 = rank_columns(ev5)
             res["strong_scaling"] = {"workload": f"{total} traces IN ALL x {N} samples over {world} GPUs (BASELINE configs[4] when 100 000 x 131 072), same frame and "
                                                  f"parameters; rank r holds the contiguous shard tspws_shard_range(total, r, world)",
                                      "traces_total": total, "traces_on_rank0": cnt if rank == 0 else None, "schedule": eff5, "ms_per_step": d5 / args.steps * 1e3,
-                                     "value": total * N * args.steps / d5, "unit": "samples/s", "scaling": "strong", "per_rank_ms": rank_columns(ev5)}
+                                     "value": total * N * args.steps / d5, "unit": "samples/s", "scaling": "strong", "per_rank_ms": cols5}
             del X5
     if world == 1 and shard_of == 1 and rank == 0:
         res["with_output_d2h"] = with_d2h(torch, plan, X, ls, ts, N, mtr_local, args.steps)
@@ -372,11 +408,6 @@ def run(args):
                                                         res["cpu_baseline"].get("seconds"))
                 del Xh
                 res["other_configs"] = other_configs(abi, tspws, lib, torch, X, N)
-    if world > 1 and rank == 0 and not args.no_cpu:
-        # N > 1: the reference OpenMP path on THIS node's host cores beside the N-GPU number, in the same run (north_star): rank 0
-        # runs it on its own shard after the timed loop (the other ranks wait in the barrier below), and checks its shard-local
-        # partial stacks -- global group index, before any reduction -- against direct FP64 sums of the same traces
-        res["cpu_baseline"] = cpu_baseline_shard(abi, plan, X, abi.default_params(Kmax=K, unbiased=1), N, K, mtr_local, first, mtr_global, red)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

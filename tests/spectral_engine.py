@@ -68,4 +68,36 @@ for name in ("ex1", "ex2", "ex3", "ex_mexhat"):
     worst = max(worst, e)
     h.update(r["ls"].tobytes()); h.update(r["tsPWS"].tobytes())
 check(dict(Kmax=200, unbiased=1), 600, 2048, 10)         # two-stage with 200 groups: the partial stacks are a many-trace batch (double input)
+
+
+# Ensembles that live AT the engine's noise floor (a coefficient at or below the transforms' rounding noise is skipped by the
+# phase stack like the reference's exact zero, ts_pws1f_lib.c:489-492): constant traces, band-limited traces (part of the frame sees rounding
+# noise only), a spike over a 1e-13 background -- tools/noise_floor_probe.py measured 0.0 on the float outputs with either engine
+def check_traces(kw, X, what):
+    global worst
+    X = np.ascontiguousarray(X.astype(np.float32))
+    p = abi.default_params(**kw)
+    a = abi.run_main(lib.tspws_main, p, X)
+    b = abi.run_main(abi.oracle().orc_tspws_main, p, X)
+    e = max(abi.relerr(a["ls"], b["ls"]), abi.relerr(a["tsPWS"], b["tsPWS"]))
+    assert a["rc"] == 0 and b["rc"] == 0 and e < 2e-6, (what, kw, e)
+    worst = max(worst, e)
+    h.update(a["ls"].tobytes()); h.update(a["tsPWS"].tobytes())
+
+
+rng = np.random.default_rng(7)
+mtr, N = 96, 4096
+noise = rng.uniform(-0.5, 0.5, (mtr, N))
+F = np.fft.rfft(noise, axis=1)
+lo, hi = F.copy(), F.copy()
+lo[:, N // 16:] = 0                                      # low-pass: the fine scales see rounding noise only
+hi[:, :N // 8] = 0                                       # high-pass: the far-decimated (spectral) scales see rounding noise only
+spike = 1e-13 * noise
+spike[:, N // 2] += 1.0
+for kw in (dict(), dict(type=-2), dict(Kmax=70, unbiased=1)):
+    check_traces(kw, np.repeat(rng.uniform(0.5, 2.0, (mtr, 1)), N, axis=1), "DC only")
+    check_traces(kw, 50.0 + noise, "DC + noise")
+    check_traces(kw, np.fft.irfft(lo, N, axis=1), "low-pass")
+    check_traces(kw, np.fft.irfft(hi, N, axis=1), "high-pass")
+    check_traces(kw, spike, "spike over a 1e-13 background")
 print("SPECTRAL_ENGINE", worst, h.hexdigest()[:16])

@@ -309,3 +309,43 @@ def test_device_list_request_runs_on_the_first_listed_device(lib, monkeypatch):
     if lib.tspws_hip_device_count() <= 7:
         monkeypatch.setenv("TSPWS_DEVICES", "7,7")
         assert abi.run_main(lib.tspws_main, abi.default_params(**kw), X)["rc"] == 5
+
+
+@pytest.mark.parametrize("ndev", [2, 4, 8])
+def test_physical_devices_all_schedules_and_the_jackknife(lib, monkeypatch, ndev):
+    """The first run with SEVERAL physical GPUs (skipped on a one-GPU box -- every test above stands in with virtual shards or one RCCL
+    rank): the drop-in tspws_main under TSPWS_DEVICES over real RCCL ranks with each TSPWS_SCHEDULE -- `split` / `sharded-finish` issue
+    reductions on the communicator from two streams per device and ncclReduce to owners --, then the sharded jackknife (replica rows reduced
+    to their owners), each against the one-device call on the same host traces."""
+    if lib.tspws_hip_device_count() < ndev:
+        pytest.skip(f"needs {ndev} GPUs")
+    mtr, N = 240, 8192
+    X = np.round(abi.synth_traces(mtr, N, seed=91) * 64.0).astype(np.float32)   # integers / 64: shard sums are exact in any order
+    devs = ",".join(str(i) for i in range(ndev))
+    try:
+        for kw in (dict(Kmax=10, unbiased=1), dict()):
+            monkeypatch.delenv("TSPWS_DEVICES", raising=False)
+            monkeypatch.delenv("TSPWS_SCHEDULE", raising=False)
+            want = abi.run_main(lib.tspws_main, abi.default_params(**kw), X)
+            assert want["rc"] == 0
+            monkeypatch.setenv("TSPWS_DEVICES", devs)
+            for sch in ("single", "split", "sharded-finish"):
+                monkeypatch.setenv("TSPWS_SCHEDULE", sch)
+                got = abi.run_main(lib.tspws_main, abi.default_params(**kw), X)
+                assert got["rc"] == 0, (kw, sch)
+                if sch != "sharded-finish" and kw:
+                    np.testing.assert_array_equal(got["ls"], want["ls"]); np.testing.assert_array_equal(got["tsPWS"], want["tsPWS"])
+                else:
+                    assert abi.relerr(got["ls"], want["ls"]) < 1e-6 and abi.relerr(got["tsPWS"], want["tsPWS"]) < 1e-6, (kw, sch)
+        monkeypatch.delenv("TSPWS_SCHEDULE", raising=False)
+        times = (1262304000 + 86400 * np.arange(mtr)).astype(np.int64)
+        pj = dict(Kmax=6, unbiased=1, jackknife_n=5, jackknife_d=1)
+        monkeypatch.delenv("TSPWS_DEVICES", raising=False)
+        want = abi.run_main(lib.tspws_main, abi.default_params(**pj), X, times=times)
+        monkeypatch.setenv("TSPWS_DEVICES", devs)
+        got = abi.run_main(lib.tspws_main, abi.default_params(**pj), X, times=times)
+        assert got["rc"] == 0 and want["rc"] == 0
+        np.testing.assert_array_equal(got["jk_mtr"], want["jk_mtr"])
+        assert abi.relerr(got["tsPWS"], want["tsPWS"]) < 1e-6 and abi.relerr(got["jk_ts"], want["jk_ts"]) < 1e-6 and abi.relerr(got["jk_ls"], want["jk_ls"]) < 1e-6
+    finally:
+        lib.tspws_main_release()

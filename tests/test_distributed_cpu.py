@@ -212,7 +212,7 @@ def _worker(rank, world, port, kw, mtr, N, out_dir):
         X = abi.synth_traces(mtr, N, seed=17)
         first, count = tspws.shard_range(mtr, rank, world)
         plan = OraclePlan(abi.default_params(**kw), N)
-        ls, ts = tspws.stack_sharded(plan, torch.from_numpy(X[first:first + count]), first, mtr)
+        ls, ts = tspws.stack_sharded(plan, torch.from_numpy(X[first:first + count]), first, mtr, schedule=os.environ.get("TEST_SCHEDULE") or None)
         np.save(os.path.join(out_dir, f"ls{rank}.npy"), ls.numpy())
         np.save(os.path.join(out_dir, f"ts{rank}.npy"), ts.numpy())
     finally:
@@ -237,11 +237,12 @@ def test_two_rank_shards_match_unsharded(tmp_path, kw):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_scale_sharded_finish_over_gloo(tmp_path, world, monkeypatch):
-    """stack_sharded with the scale-sharded finish stage (default for world > 1 when the plan offers one): the ranks finish
+    """stack_sharded(schedule="sharded-finish"), the scale-sharded finish stage: the ranks finish
     disjoint runs of octaves and add their partial reconstructions; with TSPWS_SHARD_FINISH=0 every rank finishes
     redundantly.  Both schedules against the unsharded oracle call."""
     kw, mtr, N = dict(Kmax=5, unbiased=1), 23, 1024
     want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(**kw), abi.synth_traces(mtr, N, seed=17))
+    monkeypatch.setenv("TEST_SCHEDULE", "sharded-finish")
     for mode in ("1", "0"):
         monkeypatch.setenv("TSPWS_SHARD_FINISH", mode)
         out = tmp_path / mode

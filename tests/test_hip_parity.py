@@ -1144,7 +1144,7 @@ def _gpu_shard_worker(rank, world, port, kw, mtr, N, out_dir):
         pl = tspws.Plan(tspws.resolve(abi.default_params(**kw), N), N)
         first, count = tspws.shard_range(mtr, rank, world)
         X = tspws.synth(count, N, seed=31, first=first)
-        ls, ts = tspws.stack_sharded(pl, X, first, mtr)
+        ls, ts = tspws.stack_sharded(pl, X, first, mtr, schedule="sharded-finish")   # (TSPWS_SHARD_FINISH=0: falls back to "split")
         th.cuda.synchronize()
         np.save(os.path.join(out_dir, f"ls{rank}.npy"), ls.cpu().numpy())
         np.save(os.path.join(out_dir, f"ts{rank}.npy"), ts.cpu().numpy())

@@ -420,7 +420,7 @@ def stack_sharded(plan, traces, first=0, mtr_global=None, group=None, schedule=N
     group) there is no collective at all.  `plan` only needs stack_local / reduce_buffer /
     stack_finish / N, so the CPU tests drive the same orchestration with an oracle-backed plan.
 
-    `schedule` (N > 1, two-stage; default: $TSPWS_SCHEDULE or "sharded-finish") -- three ways to place the one logical
+    `schedule` (N > 1, two-stage; default: $TSPWS_SCHEDULE or "single") -- three ways to place the one logical
     reduction of P[Kmax][N], selectable so that a multi-GPU node can A/B them (bench.py --schedule):
       "single"          north_star's wording: local half, ONE all-reduce of the whole buffer, redundant finish on every rank
                         (bit-identical to the one-GPU result when the shards add exactly);
@@ -433,7 +433,7 @@ def stack_sharded(plan, traces, first=0, mtr_global=None, group=None, schedule=N
     mtr_global = traces.shape[0] if mtr_global is None else mtr_global
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     K = getattr(getattr(plan, "params", None), "Kmax", 0)
-    schedule = schedule or os.environ.get("TSPWS_SCHEDULE") or "sharded-finish"
+    schedule = schedule or os.environ.get("TSPWS_SCHEDULE") or "single"
     if schedule not in SCHEDULES:
         raise TspwsError(f"schedule must be one of {SCHEDULES}, got {schedule!r}")
     if distributed and schedule != "single" and callable(getattr(plan, "partial_stacks_range", None)) and K >= 2 and K <= mtr_global:

@@ -421,7 +421,10 @@ static unsigned multi_split_groups(unsigned K, bool sharded_finish)
 // The ONE logical fp64 reduction of the stage-1 buffer is placed by TSPWS_SCHEDULE exactly as in ts-pws_amd.stack_sharded (one process
 // per GPU): "single" = local halves, one all-reduce of the whole buffer, finish on the first device; "split" = the groups in two pieces,
 // the first reduction (on the communicator's second streams) beside the streaming of the second piece, the second beside the
-// transforms of the first piece; "sharded-finish" (default) = pieces K - 2 | 2 + the finish stage split by scales over the devices.
+// transforms of the first piece; "sharded-finish" = pieces K - 2 | 2 + the finish stage split by scales over the devices.  Default: "single"
+// (north_star's wording, and the one collective sequence that needs nothing but an all-reduce) -- the overlapped schedules issue reductions
+// on the communicator from two streams per device and ncclReduce to owners, which have run over the local backend / one RCCL rank only;
+// they are opt-in until a node with several GPUs has measured them (bench.py --gpus N times all three in one run).
 extern "C" int tspws_hip_multi_stack(tspws_hip_multi *m, const t_tsPWS *p, const float *const *d_shards, size_t ld, size_t mtr, float *d_ls,
                                      float *d_ts)
 {
@@ -432,7 +435,7 @@ extern "C" int tspws_hip_multi_stack(tspws_hip_multi *m, const t_tsPWS *p, const
 	const unsigned K = p->Kmax;
 	int rc;
 	const char *se = getenv("TSPWS_SCHEDULE");
-	int schedule = 2; // 0 single, 1 split, 2 sharded-finish
+	int schedule = 0; // 0 single (default), 1 split, 2 sharded-finish
 	if (se && *se) {
 		if (!strcmp(se, "single")) schedule = 0; else if (!strcmp(se, "split")) schedule = 1; else if (!strcmp(se, "sharded-finish")) schedule = 2;
 		else return fail(TSPWS_E_ARG, "multi_stack: TSPWS_SCHEDULE must be single, split or sharded-finish");

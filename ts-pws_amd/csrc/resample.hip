@@ -551,6 +551,14 @@ static int masked_stream_stage(tspws_hip_plan *pl, const MaskedPlan &mp, MaskedD
 		if (sg == 0 && mp.unwritten) HIP_TRY(hipMemsetAsync(d_rows, 0, (size_t)nrow * N * sizeof(double), st));
 		const unsigned q0 = mp.stage_run0[sg], q1 = mp.stage_run0[sg + 1];
 		if (q1 > q0) {
+			// what the VEC4 walk takes for granted (stream.hip: ONE load stream per segment from the first run's t0 over the runs' total, the loaders'
+			// and the writer wave's barrier counts from the same descriptors): inside a segment the runs tile consecutive traces, none is empty
+			const unsigned qm_ = (mp.stage_mid[sg] > q0 && mp.stage_mid[sg] < q1) ? mp.stage_mid[sg] : q1;
+			for (unsigned q = q0; q < q1; q++) {
+				const RunDesc &d = mp.rdesc[q];
+				if (!d.count || (q + 1 < q1 && q + 1 != qm_ && mp.rdesc[q + 1].t0 != d.t0 + d.count))
+					return fail(TSPWS_E_ARG, "masked stack: the runs of a walk segment do not tile consecutive traces");
+			}
 			if ((rc = tspws_rows_walk_launch(d_x, ld, N, (const RunDesc *)(dv.tb + mp.o_rd), q0, mp.stage_mid[sg], q1, W, (const unsigned *)(dv.tb + mp.o_fr),
 			                                 (const unsigned *)(dv.tb + mp.o_fx) + (size_t)sg * W, d_rows, dv.carryblk, dv.have_carry ? 1 : 0, sg + 1 < mp.nstage ? 1 : 0, st)))
 				return rc;
