@@ -628,6 +628,34 @@ def other_configs(abi, tspws, lib, torch, X, N):
         r = call_main(abi, cpu_fn, pin, X1h, N1, m1)   # the WHOLE ensemble on the CPU: this is the reference's own runnable size
         c1[name] = {"ms_per_call": sec * 1e3, "value": m1 * N1 / sec, "unit": "samples/s", "cpu_seconds": r["seconds"], "speedup_hbm_resident": r["seconds"] / sec,
                     "relerr": {"ls": abi.relerr(l1.cpu().numpy(), r["ls"]), "tsPWS": abi.relerr(t1.cpu().numpy(), r["tsPWS"])}}
+        if name == "single_stage":
+            # FP64 roofline of the single-stage call (the reference's default mode on its only data set): EXECUTED forward flops by engine --
+            # FIR sums of the fine octaves (trace-lane kernel), the spectral chain of the far-decimated ones over a window of NT >= N + L - 1
+            # samples of the periodic extension (N is odd: no decimation divides it), the clipped scales as a dense contraction (4 N N_s flop per
+            # scale and trace on the matrix pipe) -- and what the FIR form of the whole frame costs, as for cfg2
+            tab1 = pl1.tables()
+            L1, Ns1 = tab1["L"].astype(np.float64), tab1["Ns"].astype(np.float64)
+            sf1, se1 = int(lib.tspws_hip_spectral_choice(pl1.h, m1)), int(lib.tspws_hip_spectral_end_scale(pl1.h))
+            NT1 = int(lib.tspws_hip_spectral_transform_length(pl1.h))
+            fir_all = 4.0 * float(np.sum(L1 * Ns1))
+            if sf1 < pl1.S:
+                Mh = NT1 // 2
+                Nb = NT1 / tab1["D"][sf1:se1].astype(np.float64)
+                parts = {"fir_scales": 4.0 * float(np.sum(L1[:sf1] * Ns1[:sf1])),
+                         "spectral_scales": 5.0 * Mh * np.log2(Mh) + 10.0 * Mh + 8.0 * NT1 * (se1 - sf1) + float(np.sum(5.0 * Nb * np.log2(np.maximum(Nb, 2.0)))),
+                         "contraction_scales": 4.0 * N1 * float(np.sum(Ns1[se1:]))}
+                eng = (f"fir (scales 0..{sf1 - 1}: D <= {int(tab1['D'][sf1 - 1])}) + spectral (scales {sf1}..{se1 - 1}: D >= {int(tab1['D'][sf1])}, transform window {NT1})"
+                       + (f" + matrix-pipe contraction (scales {se1}..{pl1.S - 1}: filters longer than the window)" if se1 < pl1.S else ""))
+            else:
+                parts, eng = {"fir_scales": fir_all}, "fir"
+            ex1 = sum(parts.values()) * m1
+            c1[name]["engine"] = eng
+            c1[name]["roofline"] = {"bound": "fp64 vector", "flops_per_call": ex1, "achieved": ex1 / sec / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": ex1 / sec / 1e12 / FP64_PEAK_TFLOPS, "hbm_frac": 4.0 * m1 * N1 / sec / 1e9 / HBM_PEAK_GBS,
+                                    "flops_executed": {k: v * m1 for k, v in parts.items()},
+                                    "fir_equivalent_flops_per_call": fir_all * m1, "fir_equivalent_tflops": fir_all * m1 / sec / 1e12,
+                                    "note": "EXECUTED forward flops by engine (the spectral chain counts its padded transforms); `fir_equivalent_*` = the FIR form of "
+                                            "the whole frame over the same time: a speed figure comparable with earlier rounds (round 5: 23.0 TFLOP/s), not a fraction"}
         del pl1
     out["cfg1_example_shape_499x16501"] = {"timed_calls": 40, "warmup_calls": 10, "check_kind": kind, "note": "BASELINE configs[0]: synthetic traces of the shipped "
                                            "example's shape; whole ensemble checked against the CPU path", **c1}
@@ -664,12 +692,24 @@ def other_configs(abi, tspws, lib, torch, X, N):
     g = pl4.stack_jackknife(X[:nsub], sel_s)
     torch.cuda.synchronize()
     r = call_main(abi, cpu_fn, pin, X[:nsub].cpu().numpy(), N, nsub, times=times[:nsub].copy(), C_rep=Cn)
+    traffic4 = None   # whole-call counter traffic (profiles/pmc_record_call.py), quoted only for this size and the sources it was measured on
+    tf4 = os.path.join(ROOT, "profiles", "pmc_cfg4_call.json")
+    if os.path.exists(tf4) and (mtr, N) == (10000, 131072):
+        try:
+            import hashlib
+            rec = json.load(open(tf4))
+            hh = hashlib.sha256()
+            for sname in rec.get("sources", []):
+                hh.update(open(os.path.join(ROOT, "ts-pws_amd", "csrc", sname), "rb").read())
+            traffic4 = rec.get("hbm_bytes_per_call") if hh.hexdigest() == rec.get("sources_sha256") else None
+        except Exception:
+            traffic4 = None
     out["cfg4_mexhat_twostage_jackknife_n10_d1"] = {
         "ms_per_call": sec * 1e3, "ms_per_call_changed_selection": sec_changed * 1e3,
         "selection": "ms_per_call: the same selection every call (class structure found in the per-thread memo); ms_per_call_changed_selection: a different selection every call",
         "timed_calls": 10, "warmup_calls": 3, "value": mtr * N / sec, "unit": "samples/s", "replicas": Cn, "traces": mtr, "V": p4.V, "J": p4.J, "scales": pl4.S,
         "roofline": {"bound": "hbm", "algorithmic_bytes": alg, "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg / sec / 1e9 / HBM_PEAK_GBS,
+                     "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": traffic4,
                      "note": "every sample read once (the stack and all replicas share ONE pass) + K partials + outputs; the 110 transforms "
                              "(3.6e10 flop) are as long as the stream"},
         "roofline_fp64": {"bound": "fp64 vector", "flops_per_call": flops4, "achieved": flops4 / sec / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -13,6 +13,7 @@ run() { # name, counters...
 want() { [ -z "$PMC_SETS" ] || [[ " $PMC_SETS " == *" $1 "* ]]; }
 want sq && run sq   SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
 want sq2 && run sq2  SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM
+want mfma && run mfma SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU
 want tcc && run tcc  TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 want fetch && run fetch FETCH_SIZE
 want write && run write WRITE_SIZE

@@ -70,7 +70,7 @@ for name in ("ex1", "ex2", "ex3", "ex_mexhat"):
 check(dict(Kmax=200, unbiased=1), 600, 2048, 10)         # two-stage with 200 groups: the partial stacks are a many-trace batch (double input)
 
 
-# Ensembles that live AT the engine's noise floor (DESIGN section 7: a coefficient at or below the transforms' rounding noise is skipped by the
+# Ensembles that live AT the engine's noise floor (DESIGN section 10: a coefficient at or below the transforms' rounding noise is skipped by the
 # phase stack like the reference's exact zero, ts_pws1f_lib.c:489-492): constant traces, band-limited traces (part of the frame sees rounding
 # noise only), a spike over a 1e-13 background -- tools/noise_floor_probe.py measured 0.0 on the float outputs with either engine
 def check_traces(kw, X, what):

@@ -201,7 +201,7 @@ def test_large_batch_default_rule_matches_fir(lib, torch):
 
 @pytest.mark.parametrize("kw,mtr,N,n,d", [(dict(type=-3, Kmax=10), 400, 4096, 10, 1), (dict(Kmax=8, unbiased=1), 300, 8192, 9, 1), (dict(Kmax=12, wu=1.0), 500, 2048, 6, 2)])
 def test_jackknife_rows_through_the_spectral_engine(lib, kw, mtr, N, n, d):
-    """The one-pass stack + jackknife call transforms (replicas + 1) x Kmax partial stacks: from 64 rows on, the octaves with D >= 8 of
+    """The one-pass stack + jackknife call transforms (replicas + 1) x Kmax partial stacks: from 64 rows on, the octaves with D >= 16 of
     those rows go through the spectral engine (lanes = rows, per-column stacks by k_spec_stack_rows) -- 110 rows (n = 10, d = 1),
     80 rows, 192 rows -- against the oracle's tspws_main, replicas included; one bin of traces is all zero."""
     Cn = abi.binomial(n, d)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What the spectral engine's noise floor (DESIGN section 7: a coefficient at or below the transforms' rounding noise is skipped by the phase stack like
+"""What the spectral engine's noise floor (DESIGN section 10: a coefficient at or below the transforms' rounding noise is skipped by the phase stack like
 the reference's exact zero) does to ensembles that LIVE at that floor: DC-only traces, band-limited traces (no energy in part of the frame), a spike
 over a 1e-13 background.  Whole tspws_main calls, engine pinned by TSPWS_ENGINE (run once with fir, once with spectral), against the oracle."""
 import importlib, os, sys

@@ -373,9 +373,9 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 	bool spec_join = false;
 	hipStream_t fir = st; // stream of the FIR kernels (the caller's, unless a spectral chain of few rows keeps that one: below)
 	// Few rows in columns (the K partial stacks of every jackknife replica, resample.hip) whose weighted sets the forward launch completes
-	// itself: from FEW_SPEC_MIN rows on, the octaves with D >= 8 go through the spectral engine (lanes = rows; per-column stacks by
+	// itself: from FEW_SPEC_MIN rows on, the octaves with D >= 16 go through the spectral engine (lanes = rows; per-column stacks by
 	// k_spec_stack_rows) and the FIR kernels below keep the finer ones.  cfg4 (110 rows of 131072 samples, Mexican hat): forward stage
-	// 1.22 -> see DESIGN.md section 4.  TSPWS_ENGINE=fir switches it off.
+	// 1.22 -> 0.87 ms (docs/history/round-5.md).  TSPWS_ENGINE=fir switches it off.
 	if constexpr (std::is_same<TIn, double>::value) {
 		if (fz && fz->allow_spec && !rg.on() && fz->fin.OUT && fz->fin.nprev == 0 && ntr <= 512 && fz->tps) {
 			static int min_rows = -1;
@@ -385,7 +385,9 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 				if (const char *m = sweep_env("TSPWS_FEW_NSMAX")) nsmax_env = (unsigned)std::max(2, atoi(m));
 			}
 			if (ntr >= (size_t)min_rows && tspws_engine_pin() != 1 && !tspws_generic_forward()) {
-				const unsigned sf = tspws_spectral_first_scale(p, nsmax_env ? nsmax_env : std::max(512u, p->N / 8u));
+				// (octaves with at most N / 16 outputs, D >= 16: with D = 8 in the set as well the chain -- two trace blocks, latency-bound -- ends 0.35 ms
+				// after the FIR kernels; cfg4 2.025 -> 1.979 ms, N / 32: 2.014, N / 64: 2.069; tools/experiments/r6_cfg4_split.sh)
+				const unsigned sf = tspws_spectral_first_scale(p, nsmax_env ? nsmax_env : std::max(512u, (p->N + 15u) / 16u));
 				// (a frame whose coarsest filters do not fit the transform window keeps its rows on the FIR kernels: they take ONE run of scales)
 				if (sf < p->S && tspws_spectral_end_scale(p) == p->S) {
 					SpecDecomp *dc = nullptr;
@@ -397,7 +399,7 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 					// 0.16-ms transposition and the FIR kernels launched first, the pair took 1.70 ms side by side against 1.05 one after the
 					// other); the chain's other kernels need no LDS to speak of and fill the register space the FIR kernels leave.  cfg4 with
 					// the end-of-round kernels on one box: 2.08-2.11 ms one after the other, 2.05 side by side with the FIR kernels first,
-					// 2.03-2.04 in this order (tools/experiments/r5_rows_parallel.sh; TSPWS_SPEC_PARALLEL=0, sweeps build: one after the other).
+					// 2.03-2.04 in this order (docs/history/experiments/r5_rows_parallel.sh; TSPWS_SPEC_PARALLEL=0, sweeps build: one after the other).
 					static const bool serial = sweep_env("TSPWS_SPEC_PARALLEL") && !strcmp(sweep_env("TSPWS_SPEC_PARALLEL"), "0");
 					hipEvent_t behind_tr = nullptr;
 					if (!serial && sf > 0) {
@@ -406,7 +408,7 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 						// another 0.03 ms at cfg4 when the plan is alone in the process -- the chain's short workgroups take the slots the long FIR
 						// workgroups free -- but with the streams of a SECOND plan alive in the process any non-default priority costs 0.4-0.5 ms:
 						// 2.00 / 2.46 ms least urgent, 2.10 / 2.56 most urgent, 2.03 / 2.03 plain, 2.10 / 2.10 one after the other;
-						// tools/experiments/r5_cfg4_robust.sh, 150 calls each.)  TSPWS_XS_PRIO (sweeps): -1 least, 1 most urgent
+						// docs/history/experiments/r5_cfg4_robust.sh, 150 calls each.)  TSPWS_XS_PRIO (sweeps): -1 least, 1 most urgent
 						const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
 						if (!p->xs) {
 							int plo = 0, phi = 0;
@@ -571,7 +573,7 @@ bool tspws_fused_forward(const tspws_hip_plan *p) { return p->n_fusable != 0; }
 // bit-identical at every size.  TSPWS_SPEC_NSMAX overrides the octave bound.
 static bool many_trace_size(const tspws_hip_plan *p, size_t ntr) { return ntr >= 128 && (double)ntr * (double)p->N >= 7.0 * 1048576.0; }
 // ... and the size from which the spectral engine (with the trace-lane kernel for the finer octaves) beats the few-trace kernels: a full
-// block of 64 traces and >= 1 M samples, or >= 256 traces of any frame that has a spectral set (tools/experiments/r5_thresh.sh, default
+// block of 64 traces and >= 1 M samples, or >= 256 traces of any frame that has a spectral set (docs/history/experiments/r5_thresh.sh, default
 // Morlet, FIR / spectral in ms: 64 x 32768 0.284 / 0.233, 64 x 16384 0.170 / 0.154, 256 x 2048 0.153 / 0.115, 512 x 1024 0.212 / 0.112,
 // 256 x 8192 0.293 / 0.170, 1024 x 4096 0.565 / 0.246; below: 48 x 32768 0.226 / 0.244, 64 x 8192 0.106 / 0.128, 128 x 4096 0.113 / 0.119,
 // 32 x 131072 0.562 / 0.693 -- fewer than 64 traces leave lanes of the trace blocks idle)

@@ -157,7 +157,7 @@ static int finish_replicas(tspws_hip_plan *pl, const t_tsPWS *p, double *d_P, co
 // register-only FP64 stream keeps its rate beside a streaming kernel (which drops to 70 %), but k_fwd_lds beside the streaming
 // side loses as much as the overlap gains: ten stages of one group each 2.82 ms (and 4.0 ms with fused slices of one trace),
 // three stages 2.82, two 2.68-2.74, one (no overlap at all) 2.73-2.77; the round-3 call was 3.13 ms.  Stream / wave priorities,
-// the cache policy of the streaming loads and the number of streaming workgroups change nothing.
+// the cache policy of the streaming loads and the number of streaming workgroups change nothing (docs/history/round-4.md).
 // Everything that depends on the selection only (runs, segments, term lists, row map, trace counts) is built once per
 // selection (per host thread, keyed by content) AND stays on the device while the plan's table block is not reused
 // (plan->jk_gen): a repeated selection issues no host-to-device copy at all.

@@ -186,7 +186,7 @@ extern "C" int tspws_hip_stack_finish_scales(tspws_hip_plan *pl, const t_tsPWS *
 // Whole call on one GPU = stack_local + stack_finish, with optional HIP events on the caller's stream around the call and
 // around its streaming stage (bench.py: roofline of the streaming kernel, per-call durations).
 //
-// Measured and not kept (profiles/r03_overlap_experiments.txt): transforming finished groups on a
+// Measured and not kept (docs/history/round-2-3.md, profiles/r03_overlap_experiments.txt): transforming finished groups on a
 // second stream while the next ones are streamed -- with one launch per hand-over or with ONE persistent streaming kernel
 // that releases the groups through hipStreamWaitValue32 -- shortens the tail by 0.1 ms and slows the streaming pass by as much.
 // ------------------------------------------------------------------------------------------
