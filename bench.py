@@ -369,8 +369,16 @@ def run(args):
             def __enter__(self):
                 self.t.start()
                 return self
-            def __exit__(self, *a):
+            def __exit__(self, et, ev_, tb):
                 self.t.cancel()
+                if et is not None and issubclass(et, Exception):
+                    # a leg that FAILS (not hangs) on this rank: the peers sit in its next collective until their own deadline; this rank
+                    # leaves the same way -- rank 0 with the line it has
+                    if rank == 0:
+                        res["aborted_leg"] = {"leg": self.label, "error": repr(ev_)[:500]}
+                        sys.stdout.write(json.dumps(res) + "\n")
+                        sys.stdout.flush()
+                    os._exit(0)
                 return False
 
         for sc in ("single", "split", "sharded-finish"):

@@ -688,6 +688,36 @@ def test_padded_rows_and_many_traces(sweeps, torch, pad, monkeypatch):
     assert abi.relerr(ts1.cpu().numpy(), want1["tsPWS"]) < TOL32 and abi.relerr(ls1.cpu().numpy(), want1["ls"]) < TOL32
 
 
+@pytest.mark.parametrize("pad", [4, 3])
+def test_shipped_library_batches_and_padded_rows(lib, torch, pad):
+    """The SHIPPED library's own thresholds (the path-forcing tests above run on the -DTSPWS_SWEEPS build): a single-stage ensemble of 5000
+    traces x 1024 samples is walked in two batches of the many-trace path (4096 + 904 traces, the second batch partially filled) with the
+    default engine rule (>= 256 traces: spectral chain beside the trace-lane kernel); the same through rows that are ld = N + pad samples apart,
+    and a 300 x 3000 call (N not a power of two: window of the periodic extension) through padded rows."""
+    mtr, N = 5000, 1024
+    X = abi.synth_traces(mtr, N, seed=52)
+    X[4500] = 0
+    p = abi.default_params(wu=1.0)
+    want = abi.run_main(abi.oracle().orc_tspws_main, p, X)
+    pl = tspws.Plan(tspws.resolve(p, N), N)
+    assert lib.tspws_hip_spectral_choice(pl.h, mtr) < pl.S
+    buf = torch.zeros((mtr, N + pad), dtype=torch.float32, device="cuda")
+    buf[:, :N] = torch.as_tensor(X, device="cuda")
+    for view in (torch.as_tensor(X, device="cuda"), buf[:, :N]):
+        ls, ts = pl.stack(view)
+        torch.cuda.synchronize()
+        assert abi.relerr(ls.cpu().numpy(), want["ls"]) < TOL32 and abi.relerr(ts.cpu().numpy(), want["tsPWS"]) < TOL32, view.stride(0)
+    mtr, N = 300, 3000
+    X = abi.synth_traces(mtr, N, seed=53)
+    want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(), X)
+    pl = tspws.Plan(tspws.resolve(abi.default_params(), N), N)
+    buf = torch.zeros((mtr, N + pad), dtype=torch.float32, device="cuda")
+    buf[:, :N] = torch.as_tensor(X, device="cuda")
+    ls, ts = pl.stack(buf[:, :N])
+    torch.cuda.synchronize()
+    assert abi.relerr(ls.cpu().numpy(), want["ls"]) < TOL32 and abi.relerr(ts.cpu().numpy(), want["tsPWS"]) < TOL32
+
+
 def test_plan_reuse_and_argument_errors(lib, torch):
     N = 2048
     p = tspws.resolve(abi.default_params(Kmax=4), N)

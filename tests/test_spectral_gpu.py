@@ -221,12 +221,14 @@ def test_jackknife_rows_through_the_spectral_engine(lib, kw, mtr, N, n, d):
         assert abi.relerr(a["jk_ts"][c], b["jk_ts"][c]) < TOL32 and abi.relerr(a["jk_ls"][c], b["jk_ls"][c]) < TOL32, c
 
 
-def test_spectral_engine_over_several_batches(sweeps, torch, monkeypatch):
+@pytest.mark.parametrize("N", [4096, 4097])
+def test_spectral_engine_over_several_batches(sweeps, torch, monkeypatch, N):
     """Large ensembles are walked in batches (transposed copy <= 1 GiB, at most 4096 traces): forced here to 64 / 128 traces per batch
     (TSPWS_TL_BATCH, sweeps build) on 300 traces -- the later batches add their blocks' planes to the stacks of the first, the last batch is
-    partial; the engine is the default rule's (300 traces: spectral) and the pinned one."""
+    partial; the engine is the default rule's (300 traces: spectral) and the pinned one.  N = 4097: the window of the periodic extension and
+    the dense contraction of the clipped scales (fwd_gemm.h), whose run buffer is reused batch after batch."""
     sw, swlib = sweeps
-    mtr, N = 300, 4096
+    mtr = 300
     X = abi.synth_traces(mtr, N, seed=81)
     X[17] = 0
     want = abi.run_main(abi.oracle().orc_tspws_main, abi.default_params(wu=1.5), X)

@@ -4,7 +4,9 @@ Mexican hat, V = 2 .. 8, w0, b0, s0, J), N = 1024 .. 16384 (powers of two: frame
 1 .. 300 traces with zero traces / stretches of exact zeros / a DC offset, single-stage (wu, unbiased, rm), two-stage with many groups
 (the FP64 partial stacks as a many-trace batch) and stack + jackknife calls with >= 64 rows (rows in columns).  The engine is pinned by
 the environment of the process (TSPWS_ENGINE=spectral, TSPWS_SPEC_NSMAX / TSPWS_FEW_NSMAX from the -DTSPWS_SWEEPS build):
-  usage: TSPWS_LIB_PATH=ts-pws_amd/lib/libtspws_hip_sweeps.so TSPWS_ENGINE=spectral [TSPWS_SPEC_NSMAX=n] random_sweep_spectral.py [first_seed [n_seeds]]"""
+  usage: TSPWS_LIB_PATH=ts-pws_amd/lib/libtspws_hip_sweeps.so TSPWS_ENGINE=spectral [TSPWS_SPEC_NSMAX=n] random_sweep_spectral.py [first_seed [n_seeds]]
+SWEEP_ANYN=1 (round 6): trace lengths that are not powers of two in every case (the window of the periodic extension, the dense contraction
+for the scales that do not fit it; TSPWS_SPEC_NT=min|double, TSPWS_GEMM=0, TSPWS_GEMM_KS=n, TSPWS_GEMM_ORDER=0|1|2 on the sweeps build)."""
 import importlib
 import os
 import sys
@@ -33,7 +35,11 @@ for seed in range(first, first + nseeds):
             kw["b0"] = float(rng.choice([0.5, 1.0, 2.0, 4.0]))
         if rng.random() < 0.2:
             kw["J"] = int(rng.integers(3, 9))
-        N = int(rng.choice([1024, 2048, 4096, 8192, 16384])) if (it + seed) % 8 else int(rng.choice([1500, 3000, 5000, 12288]))
+        if os.environ.get("SWEEP_ANYN"):   # round 6: ANY trace length -- odd, just above / below a power of two, 3 * 2^k, the shipped example's 16501
+            N = int(rng.choice([int(rng.integers(1024, 20000)), int(2 ** rng.integers(10, 15)) + int(rng.integers(-3, 4)), 3 * int(2 ** rng.integers(9, 13)), 16501, 4097, 8191]))
+            N = max(N, 1024)
+        else:
+            N = int(rng.choice([1024, 2048, 4096, 8192, 16384])) if (it + seed) % 8 else int(rng.choice([1500, 3000, 5000, 12288]))
         mode = int(rng.integers(0, 4))
         times = None
         if mode == 0:     # single-stage
@@ -73,4 +79,4 @@ for seed in range(first, first + nseeds):
         if not ok:
             bad += 1
             print("MISMATCH", seed, it, kw, N, mtr, a["rc"], b["rc"], flush=True)
-print("cases", n, "mismatches", bad, "engine", os.environ.get("TSPWS_ENGINE"), "nsmax", os.environ.get("TSPWS_SPEC_NSMAX"), os.environ.get("TSPWS_FEW_NSMAX"), "few min", os.environ.get("TSPWS_FEW_SPEC_MIN"))
+print("cases", n, "mismatches", bad, "anyN", os.environ.get("SWEEP_ANYN"), "NT", os.environ.get("TSPWS_SPEC_NT"), "gemm", os.environ.get("TSPWS_GEMM"), os.environ.get("TSPWS_GEMM_KS"), os.environ.get("TSPWS_GEMM_ORDER"), "engine", os.environ.get("TSPWS_ENGINE"), "nsmax", os.environ.get("TSPWS_SPEC_NSMAX"), os.environ.get("TSPWS_FEW_NSMAX"), "few min", os.environ.get("TSPWS_FEW_SPEC_MIN"))

@@ -496,10 +496,20 @@ static int forward_parts(tspws_hip_plan *p, const TIn *d_x, size_t ntr, size_t l
 		HIP_TRY(hipStreamWaitEvent(fir, p->ev_join, 0));
 	}
 	if (spec_join) {
-		HIP_TRY(hipEventRecord(p->ev_xs1, p->xs));
-		HIP_TRY(hipStreamWaitEvent(st, p->ev_xs1, 0));
+		if (fz && fz->defer_fir_join) fz->fir_stream = p->xs; // (the caller enqueues more behind the FIR kernels and joins: tspws_join_fir_stream)
+		else {
+			HIP_TRY(hipEventRecord(p->ev_xs1, p->xs));
+			HIP_TRY(hipStreamWaitEvent(st, p->ev_xs1, 0));
+		}
 	}
 	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int tspws_join_fir_stream(tspws_hip_plan *p, hipStream_t fir, hipStream_t st)
+{
+	HIP_TRY(hipEventRecord(p->ev_xs1, fir));
+	HIP_TRY(hipStreamWaitEvent(st, p->ev_xs1, 0));
 	return 0;
 }
 

@@ -296,6 +296,79 @@ extern "C" int tspws_hip_inverse(tspws_hip_plan *p, const double *d_Y, size_t nr
 	return 0;
 }
 
+// Batched pairs of reconstructions in TWO halves (the one-pass stack + jackknife call, resample.hip): the octaves of the scales [0, s_split) --
+// those the FIR forward kernels completed -- EARLY, on the stream `early` on which their weighted coefficient sets are complete, beside whatever
+// the caller's stream still runs (the spectral chain of the other scales: its tail is a run of short, latency-bound kernels); the other octaves
+// and the combining kernel LATE, on the caller's stream once it has been made to wait for `early`.  The octave items are independent (one row
+// of the octave buffer each), so the halves are two wave ranges of the same launch list.  *done = false: this plan / call has no such split
+// (generic octaves, a single reconstruction, octave items not in scale order) -- the caller takes tspws_hip_inverse.
+static bool inv_split_point(const tspws_hip_plan *p, unsigned s_split, unsigned *w_split)
+{
+	if (tspws_generic_inverse() || !p->inv_noct || p->inv_ngeneric || p->inv_waves_fast != p->inv_waves) return false;
+	unsigned w = p->inv_waves_fast;
+	for (unsigned i = 0; i < p->inv_noct; i++) {
+		if (i && p->oc_s0[i] < p->oc_s0[i - 1]) return false;
+		if (p->oc_s0[i] < s_split && p->oc_s0[i] + p->oc_nv[i] > s_split) return false; // (an octave item across the split)
+		if (p->oc_s0[i] >= s_split) { w = p->oc_wave_off[i]; break; }
+	}
+	*w_split = w;
+	return w > 0 && w < p->inv_waves_fast && p->inv_waves_lds <= w;
+}
+
+int tspws_inverse_pairs_early(tspws_hip_plan *p, const double2 *Y, unsigned nb, unsigned s_split, hipStream_t early, bool *done)
+{
+	*done = false;
+	unsigned w_split = 0;
+	if (nb < 2 || !inv_split_point(p, s_split, &w_split)) return 0;
+	const size_t slot = (size_t)2 * p->N;
+	const unsigned nslots = p->inv_noct;
+	void *v;
+	int rc = scratch(p, SCR_OBUF, (size_t)nb * nslots * slot * sizeof(double), &v);
+	if (rc) return rc;
+	double *obuf = (double *)v;
+	const unsigned lds_w = p->inv_waves_lds;
+	if (lds_w && w_split > lds_w) { // the LDS-staged octaves (D = 1) beside the per-lane ones, as in inverse_launch
+		const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+		if (!p->side) HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+		if (!p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, evf));
+		if (!p->ev_join) HIP_TRY(hipEventCreateWithFlags(&p->ev_join, evf));
+		HIP_TRY(hipEventRecord(p->ev_fork, early));
+		HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+		hipLaunchKernelGGL((k_inv_poly<2, false, true>), dim3((lds_w + 3) / 4, nb), dim3(256), 0, p->side, Y, p->ncoef, p->N, p->d_sc, p->d_oc, p->inv_noct,
+		                   p->d_wd, obuf, slot, lds_w, (size_t)2 * p->ncoef, (size_t)nslots * slot, 0u);
+		HIP_TRY(hipEventRecord(p->ev_join, p->side));
+		hipLaunchKernelGGL((k_inv_poly<2, false>), dim3((w_split - lds_w + 3) / 4, nb), dim3(256), 0, early, Y, p->ncoef, p->N, p->d_sc, p->d_oc, p->inv_noct,
+		                   p->d_wd, obuf, slot, w_split, (size_t)2 * p->ncoef, (size_t)nslots * slot, lds_w);
+		HIP_TRY(hipStreamWaitEvent(early, p->ev_join, 0));
+	} else if (lds_w) {
+		hipLaunchKernelGGL((k_inv_poly<2, false, true>), dim3((lds_w + 3) / 4, nb), dim3(256), 0, early, Y, p->ncoef, p->N, p->d_sc, p->d_oc, p->inv_noct,
+		                   p->d_wd, obuf, slot, lds_w, (size_t)2 * p->ncoef, (size_t)nslots * slot, 0u);
+	} else {
+		hipLaunchKernelGGL((k_inv_poly<2, false>), dim3((w_split + 3) / 4, nb), dim3(256), 0, early, Y, p->ncoef, p->N, p->d_sc, p->d_oc, p->inv_noct,
+		                   p->d_wd, obuf, slot, w_split, (size_t)2 * p->ncoef, (size_t)nslots * slot, 0u);
+	}
+	HIP_TRY(hipGetLastError());
+	*done = true;
+	return 0;
+}
+
+int tspws_inverse_pairs_late(tspws_hip_plan *p, const double2 *Y, double *x, unsigned nb, unsigned s_split, hipStream_t st)
+{
+	unsigned w_split = 0;
+	if (nb < 2 || !inv_split_point(p, s_split, &w_split)) return fail(TSPWS_E_ARG, "inverse_pairs_late: no early half was launched");
+	const size_t slot = (size_t)2 * p->N;
+	const unsigned nslots = p->inv_noct;
+	void *v;
+	int rc = scratch(p, SCR_OBUF, (size_t)nb * nslots * slot * sizeof(double), &v);
+	if (rc) return rc;
+	double *obuf = (double *)v;
+	hipLaunchKernelGGL((k_inv_poly<2, false>), dim3((p->inv_waves_fast - w_split + 3) / 4, nb), dim3(256), 0, st, Y, p->ncoef, p->N, p->d_sc, p->d_oc, p->inv_noct,
+	                   p->d_wd, obuf, slot, p->inv_waves_fast, (size_t)2 * p->ncoef, (size_t)nslots * slot, w_split);
+	hipLaunchKernelGGL(k_inv_combine, dim3((unsigned)((slot + 255) / 256), nb), dim3(256), 0, st, obuf, slot, nslots, slot, x, (size_t)nslots * slot, slot);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
 // Two reconstructions (sets 0 and 1 of Y) from the scales [s_lo, s_hi) ONLY -- whole decimation octaves -- as FP64 partial
 // sums x2[2][N]: the reconstruction is a sum over scales, so the shares of disjoint scale ranges add up to the whole.
 int tspws_inverse_scales(tspws_hip_plan *p, const double2 *Y, double *x2, hipStream_t st, ScaleRange rg)

@@ -645,6 +645,8 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	if (fin_env == -2) { const char *e = sweep_env("TSPWS_JK_FINAL"); fin_env = e ? atoi(e) : -1; }
 	const bool fin_in_kernel = fin_env < 0 ? mp.nstage == 1 : fin_env != 0;
 	unsigned last_spec_first = pl->S; // scales [.., S) of the last stage were completed by the spectral engine (forward.hip)
+	bool early_inv = false;           // the inverses of the FIR kernels' octaves were launched behind those kernels (tspws_inverse_pairs_early)
+	unsigned early_split = 0;
 	bool lin_mid = false;             // ... and its chain recorded ev_mid behind itself
 	// stream of the transforms: the second stream, so that a stage's transforms run beside the next stage's walk -- with ONE stage (the default) the
 	// caller's own: nothing runs beside the walk then, and every hand-over to another stream costs ~20 us before the first kernel there starts
@@ -672,10 +674,24 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 			if (!pl->ev_mid) HIP_TRY(hipEventCreateWithFlags(&pl->ev_mid, hipEventDisableTiming | hipEventDisableSystemFence));
 			fz.ev_mid = pl->ev_mid;
 		}
+		// The inverses in two halves (one stage, in-kernel completion, pairs of reconstructions): the octaves of the scales the FIR kernels complete
+		// start behind THEM on their stream, beside the tail of the spectral chain -- a run of short, latency-bound kernels that ends 0.2 ms after
+		// the FIR kernels at cfg4 -- instead of behind the chain; only the chain's own octaves and the combining kernel are left for the end.
+		// TSPWS_JK_EARLY_INV=0 (sweeps): all inverses behind the chain
+		static const bool early_off = sweep_env("TSPWS_JK_EARLY_INV") && !strcmp(sweep_env("TSPWS_JK_EARLY_INV"), "0");
+		const bool want_early = fuse && fz.fin.OUT && mp.nstage == 1 && !(nrec & 1u) && !early_off;
+		fz.defer_fir_join = want_early;
 		pl->le.ready = pl->stage_ev[sg]; // the producer's own event: the forward launch's other streams wait for it directly, not for a re-record on xf
 		rc = tspws_forward_parts_f64(pl, d_rows + (size_t)r0 * N, r1 - r0, N, part + (size_t)r0 * pl->npart, fs, fuse ? &fz : nullptr, ScaleRange());
 		pl->le.ready = nullptr;
 		if (rc) return rc;
+		if (fz.fir_stream) { // the FIR kernels are still un-joined on their stream
+			// (every scale below the chain's must be complete behind the FIR kernels: fused and completed in the kernel -- no pass of k_accumulate_parts)
+			if (fz.spec_first < pl->S && tspws_first_unfused_scale(pl) >= fz.spec_first)
+				if ((rc = tspws_inverse_pairs_early(pl, (const double2 *)OUT, nrec / 2, fz.spec_first, fz.fir_stream, &early_inv))) return rc;
+			if ((rc = tspws_join_fir_stream(pl, fz.fir_stream, fs))) return rc;
+			early_split = fz.spec_first;
+		}
 		if (fuse) stage_spec_first = fz.spec_first;
 		last_spec_first = stage_spec_first;
 		lin_mid = fuse && fz.mid_recorded;
@@ -719,7 +735,8 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 		tspws_launch_accumulate(pl, (const double2 *)part, KM, (double2 *)STr, (double2 *)STr + nc, 1, fuse ? &fa : nullptr, mp.nstage, st, W, 0, 2 * nc, nullptr, &wa, ScaleRange(), &ex);
 		if (with_stack) HIP_TRY(hipMemcpyAsync(OUT + (size_t)W * 2 * nc, STr + (size_t)C * 4 * nc, nc * sizeof(double2), hipMemcpyDeviceToDevice, st)); // ST of the plain stack: the last set
 	}
-	if ((rc = tspws_hip_inverse(pl, OUT, nrec, xr, s))) return rc;
+	if (early_inv) { if ((rc = tspws_inverse_pairs_late(pl, (const double2 *)OUT, xr, nrec / 2, early_split, st))) return rc; }
+	else if ((rc = tspws_hip_inverse(pl, OUT, nrec, xr, s))) return rc;
 	if (C) tspws_epilogue_rows(d_ts_out, xr, N, C, st);
 	if (with_stack && (rc = tspws_hip_epilogue(d_ls, d_ts, xr + (size_t)(C + 1) * N, xr + (size_t)C * N, N, (unsigned)mtr, s))) return rc;
 	for (unsigned c = 0; c < C; c++) h_mtr_out[c] = (unsigned)mp.Kc[c];

@@ -26,6 +26,7 @@
 #include "lane_reduce.h"
 #include "spectral.h"
 
+
 // ------------------------------------------------------------------------------------------
 // compile-time twiddles of the register transforms: cos / sin (2 pi k / 32)
 // ------------------------------------------------------------------------------------------

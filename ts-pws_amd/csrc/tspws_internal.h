@@ -138,6 +138,10 @@ struct FuseOut {
 	// the other): work that only must not run beside that transposition can start here (resample.hip: the replicas' linear stacks)
 	hipEvent_t ev_mid = nullptr;
 	bool mid_recorded = false;
+	// the caller joins the FIR kernels' stream itself (it has more work for that stream: the early half of the inverses, resample.hip): when the
+	// FIR kernels ran on a stream of their own beside the spectral chain, the forward launch leaves it un-joined and names it here
+	bool defer_fir_join = false;
+	hipStream_t fir_stream = nullptr;
 };
 
 // Phase weighting of one coefficient (tspws_biased :909-943, tspws_unbiased :965-984).
@@ -335,6 +339,7 @@ __device__ __forceinline__ double2 weight_value(const double2 st, const double2 
 int  tspws_build_forward(tspws_hip_plan *p);              // work decomposition of the forward kernels (few-trace and many-trace tables)
 int  tspws_forward_parts_f32(tspws_hip_plan *p, const float *d_x, size_t ntr, size_t ld, double2 *d_part, hipStream_t st, FuseOut *fz, ScaleRange rg);
 int  tspws_forward_parts_f64(tspws_hip_plan *p, const double *d_x, size_t ntr, size_t ld, double2 *d_part, hipStream_t st, FuseOut *fz, ScaleRange rg);
+int  tspws_join_fir_stream(tspws_hip_plan *p, hipStream_t fir, hipStream_t st); // FuseOut::defer_fir_join: st waits for what is enqueued on fir
 // ST / PS of ntr traces (keep: add to the stacks already there; wa: weighting applied by the launch that completes the
 // stacks, *weighted tells whether that happened; rg: only these scales)
 int  tspws_stacks_f32(tspws_hip_plan *p, const float *d_x, size_t ntr, size_t ld, double *d_ST, double *d_PS, hipStream_t st, bool keep,
@@ -375,6 +380,10 @@ void tspws_weight_batched(tspws_hip_plan *p, double2 *OUT, const double2 *ST, co
 // the stack's pair of reconstructions (set 0 = OUT, set 1 = ST of Y) straight to the float outputs
 int  tspws_inverse_pair_out(tspws_hip_plan *p, const double2 *Y, float *d_ts, float *d_ls, float mtr, hipStream_t st);
 int  tspws_inverse_scales(tspws_hip_plan *p, const double2 *Y, double *x2, hipStream_t st, ScaleRange rg);
+// nb pairs of reconstructions in two halves: the octaves of the scales [0, s_split) early on the stream where their sets are complete, the rest + the
+// combining kernel late on the caller's stream (which the caller has made wait for `early` in between); *done = false: no such split, nothing launched
+int  tspws_inverse_pairs_early(tspws_hip_plan *p, const double2 *Y, unsigned nb, unsigned s_split, hipStream_t early, bool *done);
+int  tspws_inverse_pairs_late(tspws_hip_plan *p, const double2 *Y, double *x, unsigned nb, unsigned s_split, hipStream_t st);
 bool tspws_generic_inverse();
 // ts rows: (float) x[j][n] for nb rows (replica outputs)
 void tspws_epilogue_rows(float *d_ts, const double *d_x, size_t N, unsigned nb, hipStream_t st);
