@@ -207,7 +207,8 @@ int  tspws_hip_jackknife(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_
 /* The two-stage stack AND its C jackknife replicas from ONE pass over the device-resident traces (the reference walks them
  * 1 + C times, :216 and :758-772): same outputs as tspws_hip_stack followed by tspws_hip_jackknife, except that the stack's
  * groups are summed class by class (last-bit differences in the FP64 partial stacks).  Falls back to tspws_hip_stack for
- * single-stage parameters or C == 0. */
+ * single-stage parameters or C == 0.  h_mtr_out is filled on return; the device outputs are ordered on `stream` like tspws_hip_stack's
+ * (the call waits for the stream itself only when it had to upload the tables of a selection it has not seen in its last call). */
 int  tspws_hip_stack_jackknife(tspws_hip_plan *plan, const t_tsPWS *p, const float *d_sigall, size_t ld, size_t mtr,
                                float *d_ls, float *d_tsPWS, const char *h_sel, unsigned C,
                                float *d_ls_out, float *d_ts_out, unsigned *h_mtr_out, void *stream);

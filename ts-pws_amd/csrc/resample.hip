@@ -521,6 +521,7 @@ struct MaskedDev {
 	char *tb = nullptr;
 	double *carryblk = nullptr;
 	bool have_carry = false;
+	bool uploaded = false; // this call enqueued a copy of the memo's host tables: the call must not return before it has been read
 };
 
 static int masked_tables(tspws_hip_plan *pl, const MaskedPlan &mp, hipStream_t st, MaskedDev &dv)
@@ -534,6 +535,7 @@ static int masked_tables(tspws_hip_plan *pl, const MaskedPlan &mp, hipStream_t s
 		pl->jk_gen = 0;
 		HIP_TRY(hipMemcpyAsync(dv.tb, mp.blob.data(), mp.blob.size(), hipMemcpyHostToDevice, st));
 		pl->jk_gen = mp.gen;
+		dv.uploaded = true;
 	}
 	dv.have_carry = false;
 	return 0;
@@ -742,7 +744,11 @@ static int masked_two_stage_pipelined(tspws_hip_plan *pl, const t_tsPWS *p, cons
 	for (unsigned c = 0; c < C; c++) h_mtr_out[c] = (unsigned)mp.Kc[c];
 	if (lin_side) HIP_TRY(hipStreamWaitEvent(st, pl->ev_lin, 0)); // (long done)
 	HIP_TRY(hipGetLastError());
-	return cs_done(st); // (the memo's tables may still be on their way; the caller reads h_mtr_out and, usually, the outputs next)
+	// A call that uploaded the memo's tables waits for its stream (the host block may be rebuilt by the next call).  A call that found them
+	// on the device -- the same selection as last time: the steady state of a caller that stacks many ensembles with the same time stamps --
+	// returns like tspws_hip_stack does, with its kernels in flight: h_mtr_out is host data, the device outputs are stream-ordered.  (The
+	// synchronisation cost such a loop ~0.13 ms of idle GPU per call at cfg4: wake-up, return, re-entry and the first launches of the next call.)
+	return dv.uploaded ? cs_done(st) : 0;
 }
 
 // All C masked two-stage replicas from ONE pass over the traces (shared by the jackknife and the two-stage
