@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--collective-timeout", type=int, default=180, help="N > 1: seconds after which a hung collective fails the run")
     ap.add_argument("--leg-deadline", type=int, default=60,
                     help="N > 1: seconds an A/B leg (another schedule, the strong-scaling leg) may take before rank 0 prints the line it has and every rank exits")
+    ap.add_argument("--inject-hang", choices=["single", "split", "sharded-finish", "strong"], default=None,
+                    help="TEST ONLY (tests/test_cli_gpu.py): the last rank never enters this optional leg -- its peers sit in the leg's first collective until "
+                         "the deadline prints the line measured so far")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline, host-path and other-config legs")
     ap.add_argument("--no-extra", action="store_true", help="skip the host-path and other-config legs only")
     return ap.parse_args()
@@ -387,6 +390,8 @@ def run(args):
                             "runs_as": schedule, "output_sha1": out_sha, "is_default": True}
                 continue
             with Deadline(f"schedule {sc}"):
+                if args.inject_hang == sc and rank == world - 1:
+                    time.sleep(10 ** 6)
                 st2, ev2, _, eff = make_leg(sc, X, first, mtr_global)
                 d2 = time_leg(st2, min(2, max(1, args.warmup)))
                 cols2, sha2 = rank_columns(ev2), digest()
@@ -397,6 +402,8 @@ def run(args):
         if total and total >= world:
             lo, cnt = tspws.shard_range(total, rank, world)
             with Deadline("strong scaling"):
+                if args.inject_hang == "strong" and rank == world - 1:
+                    time.sleep(10 ** 6)
                 X5 = tspws.synth(cnt, N, seed=1, first=lo, device=local)
                 st5, ev5, _, eff5 = make_leg(schedule, X5, lo, total)
                 d5 = time_leg(st5, min(2, max(1, args.warmup)))

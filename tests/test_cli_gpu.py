@@ -188,6 +188,23 @@ def test_bench_starts_its_own_ranks():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("leg", ["split", "strong"])
+def test_bench_prints_its_line_when_an_optional_leg_hangs(leg):
+    """The N > 1 line must survive a schedule that hangs on real hardware (the overlapped schedules have never had a second RCCL rank): every
+    optional leg runs under a deadline; when the last rank never shows up in a leg's collective, rank 0 prints the line measured so far --
+    headline, roofline, per-rank columns, CPU baseline, the legs that did finish -- names the leg, and every rank leaves with status 0."""
+    r = _bench(["--gpus", "2", "--traces", "64", "--samples", "4096", "--steps", "2", "--warmup", "1", "--strong-total", "200", "--leg-deadline", "6",
+                "--inject-hang", leg], {"BENCH_BACKEND": "gloo"})
+    assert r["aborted_leg"]["leg"] == ("schedule split" if leg == "split" else "strong scaling") and r["aborted_leg"]["deadline_s"] == 6
+    assert r["value"] > 0 and r["n_gpus"] == 2 and "cpu_baseline" in r and "roofline" in r and len(r["per_rank_ms"]["ranks"]) == 2
+    assert r["schedules"]["single"]["is_default"] and r["schedules"]["single"]["ms_per_step"] > 0
+    if leg == "strong":
+        assert set(r["schedules"]) == {"single", "split", "sharded-finish"} and "strong_scaling" not in r
+    else:
+        assert "split" not in r["schedules"]
+
+
+@pytest.mark.gpu
 def test_bench_single_gpu_line_has_the_contract_keys():
     """One GPU, small size: the line carries the contract keys, the roofline object, the per-step statistics, the D2H-inclusive
     figure and the CPU baseline with the full-size comparison against it."""
