@@ -28,20 +28,22 @@
 
 
 // ------------------------------------------------------------------------------------------
-// compile-time twiddles of the register transforms: cos / sin (2 pi k / 32)
+// compile-time twiddles of the register transforms: cos / sin (2 pi k / 64)
 // ------------------------------------------------------------------------------------------
 namespace {
-constexpr double quarter32(int k)
-{ // cos(2 pi k / 32), 0 <= k <= 8
-	return k == 0 ? 1.0 : k == 1 ? 0.9807852804032304 : k == 2 ? 0.9238795325112867 : k == 3 ? 0.8314696123025452 : k == 4 ? 0.7071067811865476
-	     : k == 5 ? 0.5555702330196023 : k == 6 ? 0.38268343236508984 : k == 7 ? 0.19509032201612833 : 0.0;
+constexpr double quarter64(int k)
+{ // cos(2 pi k / 64), 0 <= k <= 16
+	return k == 0 ? 1.0 : k == 1 ? 0.9951847266721969 : k == 2 ? 0.9807852804032304 : k == 3 ? 0.9569403357322088 : k == 4 ? 0.9238795325112867
+	     : k == 5 ? 0.881921264348355 : k == 6 ? 0.8314696123025452 : k == 7 ? 0.773010453362737 : k == 8 ? 0.7071067811865476
+	     : k == 9 ? 0.6343932841636455 : k == 10 ? 0.5555702330196023 : k == 11 ? 0.4713967368259978 : k == 12 ? 0.38268343236508984
+	     : k == 13 ? 0.29028467725446233 : k == 14 ? 0.19509032201612833 : k == 15 ? 0.09801714032956077 : 0.0;
 }
-constexpr double cos32(int k)
+constexpr double cos64(int k)
 {
-	k = ((k % 32) + 32) % 32;
-	return k <= 8 ? quarter32(k) : k <= 16 ? -quarter32(16 - k) : k <= 24 ? -quarter32(k - 16) : quarter32(32 - k);
+	k = ((k % 64) + 64) % 64;
+	return k <= 16 ? quarter64(k) : k <= 32 ? -quarter64(32 - k) : k <= 48 ? -quarter64(k - 32) : quarter64(64 - k);
 }
-constexpr double sin32(int k) { return cos32(k - 8); }
+constexpr double sin64(int k) { return cos64(k - 16); }
 
 __device__ __forceinline__ double2 cadd(const double2 a, const double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ double2 csub(const double2 a, const double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
@@ -52,7 +54,7 @@ __device__ __forceinline__ double2 cmul(const double2 a, const double2 b) { retu
 template <int R, bool INV, int K> struct SpecBfly {
 	static __device__ __forceinline__ void run(double2 (&v)[R], const double2 (&e)[R / 2], const double2 (&o)[R / 2])
 	{
-		constexpr double cs = cos32(K * (32 / R)), sn = INV ? sin32(K * (32 / R)) : -sin32(K * (32 / R));
+		constexpr double cs = cos64(K * (64 / R)), sn = INV ? sin64(K * (64 / R)) : -sin64(K * (64 / R));
 		double2 t;
 		if constexpr (K == 0) t = o[0];
 		else if constexpr (4 * K == R) t = INV ? make_double2(-o[K].y, o[K].x) : make_double2(o[K].y, -o[K].x);
@@ -186,7 +188,8 @@ __device__ __forceinline__ void spec_fwd_first_body(const TIn *__restrict__ col,
 	for (int n = 0; n < R; n++) dst[((size_t)j * R + n) * 64] = v[n];
 }
 
-template <typename TIn>
+// (R64: the 64-point instantiation on its own -- 256 VGPRs, one wave per SIMD; in one kernel with the smaller radices it would set THEIR register count too)
+template <typename TIn, bool R64 = false>
 __global__ void __launch_bounds__(256) k_spec_fwd_first(const TIn *__restrict__ xT, unsigned TP, double2 *__restrict__ dst, size_t dst_rows, unsigned M, unsigned radix,
                                                         unsigned Nx, unsigned split)
 {
@@ -196,6 +199,7 @@ __global__ void __launch_bounds__(256) k_spec_fwd_first(const TIn *__restrict__ 
 	if (j >= m) return;
 	const TIn *col = xT + (size_t)tb * 64 + lane;
 	double2 *d = dst + (size_t)tb * dst_rows * 64 + lane;
+	if constexpr (R64) { spec_fwd_first_body<TIn, 64>(col, TP, d, j, m, Nx, split); return; }
 	switch (radix) {
 	case 32: spec_fwd_first_body<TIn, 32>(col, TP, d, j, m, Nx, split); break;
 	case 16: spec_fwd_first_body<TIn, 16>(col, TP, d, j, m, Nx, split); break;
@@ -237,7 +241,7 @@ __device__ __forceinline__ void spec_mid_body(const double2 *__restrict__ src, d
 	for (int n = 0; n < R; n++) dst[(j0 + (size_t)n * L) * 64] = v[n];
 }
 
-template <bool INV>
+template <bool INV, bool R64 = false>
 __global__ void __launch_bounds__(256) k_spec_mid(const SpecSeg *__restrict__ segs, unsigned nseg, unsigned nitems, const double2 *__restrict__ src, size_t src_rows,
                                                   double2 *__restrict__ dst, size_t dst_rows, const double2 *__restrict__ tw)
 {
@@ -248,6 +252,7 @@ __global__ void __launch_bounds__(256) k_spec_mid(const SpecSeg *__restrict__ se
 	const unsigned j = item - sg->item0;
 	const double2 *s = src + ((size_t)tb * src_rows + sg->src) * 64 + lane;
 	double2 *d = dst + ((size_t)tb * dst_rows + sg->dst) * 64 + lane;
+	if constexpr (R64) { spec_mid_body<64, INV>(s, d, sg, j, tw); return; }
 	switch (sg->radix) {
 	case 32: spec_mid_body<32, INV>(s, d, sg, j, tw); break;
 	case 16: spec_mid_body<16, INV>(s, d, sg, j, tw); break;
@@ -932,6 +937,18 @@ static int spec_build(tspws_hip_plan *p, unsigned s_first, unsigned nblk_hint, S
 	// ---- trace transform: M = N / 2 complex points, last pass <= 16 (it holds two butterflies) ----
 	sp->fwd_bits = radix_bits(ilog2u(M), 4);
 	{
+		// One pass fewer where ONE 64-point pass makes it possible (every pass moves the whole batch through HBM / MALL once each way): M = 32 768
+		// (N = 65 536) 16 x 16 x 16 x 8 -> 64 x 32 x 16, the 64-point pass first (no twiddles): 512 x 65 536 single-stage 1.76 -> 1.64 ms.  The
+		// 64-point butterfly takes 256 VGPRs (one wave per SIMD, its own kernel instantiation): M = 65 536 as 64 x 64 x 16 -- TWO such passes -- lost
+		// (256 x 131 072 1.85 -> 1.88 ms; cfg4's two trace blocks beside k_fwd_lds 1.92 -> 2.00: 512 one-wave workgroups take 0.54 ms for the first
+		// pass), so only plans with one 64-point pass are taken (tools/experiments/r6_r64.sh).  TSPWS_SPEC_R64=0 (sweeps): never.
+		static const bool r64_off = sweep_env("TSPWS_SPEC_R64") && !strcmp(sweep_env("TSPWS_SPEC_R64"), "0");
+		const unsigned m = ilog2u(M);
+		if (!r64_off && nblk_hint >= 4 && m == 15) { // (11 bits in front of the 16-point last pass: 6 + 5; batches of >= 4 trace blocks: enough one-wave workgroups)
+			if (3 < sp->fwd_bits.size()) sp->fwd_bits = std::vector<unsigned>{6u, 5u, 4u};
+		}
+	}
+	{
 		std::vector<SpecSeg> fs;
 		unsigned L = 1;
 		for (size_t i = 0; i < sp->fwd_bits.size(); i++) {
@@ -1088,13 +1105,16 @@ static int spectral_run(tspws_hip_plan *p, SpecDecomp *dc, const TIn *xT, unsign
 	const size_t np = sp->fwd_bits.size();
 	{
 		const unsigned R0 = 1u << sp->fwd_bits[0];
-		hipLaunchKernelGGL((k_spec_fwd_first<TIn>), dim3((M / R0 + 3) / 4, nblk), dim3(256), 0, st, xT, TP, A, xrows, M, R0, sp->Nx, sp->split);
+		if (R0 == 64) hipLaunchKernelGGL((k_spec_fwd_first<TIn, true>), dim3((M / R0 + 3) / 4, nblk), dim3(256), 0, st, xT, TP, A, xrows, M, R0, sp->Nx, sp->split);
+		else hipLaunchKernelGGL((k_spec_fwd_first<TIn>), dim3((M / R0 + 3) / 4, nblk), dim3(256), 0, st, xT, TP, A, xrows, M, R0, sp->Nx, sp->split);
 	}
 	double2 *cur = A, *oth = B;
 	for (size_t i = 1; i + 1 < np; i++) {
 		const unsigned items = M >> sp->fwd_bits[i];
-		hipLaunchKernelGGL((k_spec_mid<false>), dim3((items + 3) / 4, nblk), dim3(256), 0, st, (const SpecSeg *)(sp->d_fseg + i), 1u, items, (const double2 *)cur, xrows, oth,
-		                   xrows, (const double2 *)sp->d_tw);
+		if (sp->fwd_bits[i] == 6) hipLaunchKernelGGL((k_spec_mid<false, true>), dim3((items + 3) / 4, nblk), dim3(256), 0, st, (const SpecSeg *)(sp->d_fseg + i), 1u, items, (const double2 *)cur, xrows, oth,
+		                                             xrows, (const double2 *)sp->d_tw);
+		else hipLaunchKernelGGL((k_spec_mid<false>), dim3((items + 3) / 4, nblk), dim3(256), 0, st, (const SpecSeg *)(sp->d_fseg + i), 1u, items, (const double2 *)cur, xrows, oth,
+		                        xrows, (const double2 *)sp->d_tw);
 		std::swap(cur, oth);
 	}
 	{
