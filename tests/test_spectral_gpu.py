@@ -86,6 +86,8 @@ def test_spectral_coefficients_golden(lib, torch, golden):
     # N not a power of two (the shipped example's 16501 -- five clipped scales stay outside the window --, odd, even, just above / below a power of two)
     (dict(), 16501, 3, 1 << 20), (dict(), 3000, 70, 1 << 20), (dict(type=-3), 20000, 5, 4096), (dict(w0=2 * np.pi), 1501, 66, 1 << 20),
     (dict(), 4097, 3, 1 << 20), (dict(V=5, b0=2.0), 8191, 4, 512), (dict(type=-2), 86400, 2, 2048), (dict(J=6), 1025, 130, 1 << 20),
+    # transform windows of 65 536 samples with >= 4 trace blocks: the 64-point first pass (64 x 32 x 16 instead of 16 x 16 x 16 x 8)
+    (dict(), 65536, 260, 2048), (dict(type=-3), 40000, 257, 2048),
 ])
 def test_spectral_coefficients_vs_oracle(lib, torch, kw, N, ntr, nsmax):
     """Per-trace coefficients of the spectral set [first, end) for float and double input; one trace carries a stretch of exact zeros."""
